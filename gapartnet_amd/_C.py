@@ -1,0 +1,82 @@
+"""ctypes binding of ``libgpn_hip.so`` (the C-ABI declared in ``include/gpn.h``).
+
+The library is the product: there is no CPU fallback.  ``lib()`` raises if the shared object has not been
+built (``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C gapartnet_amd/csrc``).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libgpn_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+_SIZE_T_FUNCS = (
+    "gpn_voxelize_ws_bytes", "gpn_rulebook_subm3_ws_bytes", "gpn_rulebook_down_ws_bytes",
+    "gpn_rulebook_down_lists_ws_bytes", "gpn_spconv_wgrad_ws_bytes", "gpn_ccl_ws_bytes", "gpn_nms_ws_bytes",
+)
+
+
+class GpnError(RuntimeError):
+    pass
+
+
+def build(jobs: int = 8) -> str:
+    """Compile every HIP source for gfx950 into gapartnet_amd/libgpn_hip.so (in-tree)."""
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j", str(jobs)])
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise GpnError(
+                f"{SO_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+        _lib = ctypes.CDLL(SO_PATH)
+        _lib.gpn_last_error.restype = ctypes.c_char_p
+        _lib.gpn_entry_point_name.restype = ctypes.c_char_p
+        for name in _SIZE_T_FUNCS:
+            getattr(_lib, name).restype = ctypes.c_size_t
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().gpn_last_error().decode("utf-8", "replace")
+        raise GpnError(f"{what or 'gpn call'} failed (code {rc}): {msg}")
+
+
+# argument helpers ------------------------------------------------------------------------------------
+def ptr(t):
+    """device pointer of a (contiguous) torch tensor, or NULL for None."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def i64(v):
+    return ctypes.c_int64(int(v))
+
+
+def i32(v):
+    return ctypes.c_int(int(v))
+
+
+def f32(v):
+    return ctypes.c_float(float(v))
+
+
+def szt(v):
+    return ctypes.c_size_t(int(v))
+
+
+def host_f32x3(v):
+    return (ctypes.c_float * 3)(*[float(x) for x in v])
+
+
+def host_i32x3(v):
+    return (ctypes.c_int32 * 3)(*[int(x) for x in v])

@@ -1,0 +1,104 @@
+// gpn_core.hip — error reporting, entry-point registry and the in-library hipEvent profiler.
+#include <cstdarg>
+#include <mutex>
+#include <vector>
+
+#include "gpn_common.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+struct ProfRec {
+  hipEvent_t a, b;
+};
+struct ProfSlot {
+  std::vector<ProfRec> recs;
+  double flops = 0, bytes = 0;
+  int64_t launches = 0;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+ProfSlot g_prof[GPN_K_COUNT];
+
+const char* kEntryPoints[] = {
+    "gpn_voxelize", "gpn_voxelize_ws_bytes", "gpn_rulebook_subm3", "gpn_rulebook_subm3_ws_bytes",
+    "gpn_rulebook_down", "gpn_rulebook_down_ws_bytes", "gpn_rulebook_down_lists",
+    "gpn_rulebook_down_lists_ws_bytes", "gpn_spconv_pack_weights", "gpn_spconv_fwd", "gpn_spconv_wgrad",
+    "gpn_spconv_wgrad_ws_bytes", "gpn_gather_rows", "gpn_scatter_rows_csr", "gpn_ball_query", "gpn_ccl",
+    "gpn_ccl_ws_bytes", "gpn_segmented_reduce", "gpn_segmented_maxpool_fwd", "gpn_segmented_maxpool_bwd",
+    "gpn_instance_iou", "gpn_nms", "gpn_nms_ws_bytes", "gpn_pn2_ball_query", "gpn_pn2_group_points",
+    "gpn_pn2_group_points_grad", "gpn_pn2_gather_points", "gpn_pn2_gather_points_grad",
+    "gpn_pn2_furthest_point_sampling", "gpn_pn2_three_nn", "gpn_pn2_knn", "gpn_pn2_three_interpolate",
+    "gpn_pn2_three_interpolate_grad", "gpn_prof_enable", "gpn_prof_reset", "gpn_prof_get",
+    "gpn_last_error", "gpn_version"};
+}  // namespace
+
+namespace gpn {
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+ProfScope::ProfScope(int kernel_id, hipStream_t s, double flops, double bytes) : id(kernel_id), stream(s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof[id].flops += flops;
+  g_prof[id].bytes += bytes;
+  g_prof[id].launches += 1;
+  if (hipEventCreate(&start) != hipSuccess) { start = nullptr; return; }
+  hipEventRecord(start, stream);
+}
+ProfScope::~ProfScope() {
+  if (!start) return;
+  hipEvent_t stop;
+  if (hipEventCreate(&stop) != hipSuccess) return;
+  hipEventRecord(stop, stream);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof[id].recs.push_back({start, stop});
+}
+}  // namespace gpn
+
+extern "C" {
+const char* gpn_last_error(void) { return g_err; }
+int gpn_version(void) { return 1; }
+int gpn_num_entry_points(void) { return (int)(sizeof(kEntryPoints) / sizeof(kEntryPoints[0])); }
+const char* gpn_entry_point_name(int i) {
+  return (i >= 0 && i < gpn_num_entry_points()) ? kEntryPoints[i] : nullptr;
+}
+
+int gpn_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return GPN_OK;
+}
+int gpn_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& s : g_prof) {
+    for (auto& r : s.recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    s.recs.clear();
+    s.flops = s.bytes = 0;
+    s.launches = 0;
+  }
+  return GPN_OK;
+}
+int gpn_prof_get(int kernel_id, int64_t* launches_host, double* ms_host, double* flops_host,
+                 double* bytes_host) {
+  GPN_CHECK_ARG(kernel_id >= 0 && kernel_id < GPN_K_COUNT);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfSlot& s = g_prof[kernel_id];
+  double ms = 0;
+  for (auto& r : s.recs) {
+    GPN_CHECK_HIP(hipEventSynchronize(r.b));
+    float t = 0;
+    GPN_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t;
+  }
+  if (launches_host) *launches_host = s.launches;
+  if (ms_host) *ms_host = ms;
+  if (flops_host) *flops_host = s.flops;
+  if (bytes_host) *bytes_host = s.bytes;
+  return GPN_OK;
+}
+}

@@ -1,0 +1,381 @@
+// pointnet2.hip — kernel family F: the PointNet++ point ops behind the reference's
+// pybind module `pointnet2_cuda` (dataset/process_tools/utils/pointnet_lib/src/pointnet2_api.cpp:10-25).
+// Same argument meaning and results as the vendored kernels; written for wave64 / LDS broadcast.
+#include <cmath>
+
+#include "gpn_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float dist2_nofma(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ---- ball_query_gpu.cu:9-45 : thread per query, candidates broadcast from LDS tiles ----------------
+__global__ __launch_bounds__(kThreads) void pn2_ball_query_kernel(int n, int m, float radius2, int nsample,
+                                                                  const float* __restrict__ new_xyz,
+                                                                  const float* __restrict__ xyz,
+                                                                  int32_t* __restrict__ idx) {
+  __shared__ float tile[kThreads * 3];
+  const int bs = blockIdx.y;
+  const int pt = blockIdx.x * kThreads + threadIdx.x;
+  const bool active = pt < m;
+  const float* base = xyz + (int64_t)bs * n * 3;
+  float qx = 0, qy = 0, qz = 0;
+  if (active) {
+    const float* q = new_xyz + ((int64_t)bs * m + pt) * 3;
+    qx = q[0]; qy = q[1]; qz = q[2];
+  }
+  int32_t* out = idx + ((int64_t)bs * m + pt) * nsample;
+  int cnt = 0;
+  for (int k0 = 0; k0 < n; k0 += kThreads) {
+    const int n_here = (n - k0 < kThreads) ? (n - k0) : kThreads;
+    for (int e = threadIdx.x; e < n_here * 3; e += kThreads) tile[e] = base[(int64_t)k0 * 3 + e];
+    __syncthreads();
+    if (active && cnt < nsample) {
+      for (int t = 0; t < n_here; ++t) {
+        const float d2 = dist2_nofma(qx, qy, qz, tile[t * 3], tile[t * 3 + 1], tile[t * 3 + 2]);
+        if (d2 < radius2) {
+          const int k = k0 + t;
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) out[l] = k;
+          out[cnt] = k;
+          ++cnt;
+          if (cnt >= nsample) break;
+        }
+      }
+    }
+    if (__syncthreads_and((!active) || cnt >= nsample)) break;
+  }
+}
+
+// ---- group_points_gpu.cu:47-66 / :8-25 ---------------------------------------------------------------
+__global__ void pn2_group_points_kernel(int c, int n, int npoints, int nsample, const float* __restrict__ points,
+                                        const int32_t* __restrict__ idx, float* __restrict__ out) {
+  const int bs = blockIdx.z, ch = blockIdx.y;
+  const int index = blockIdx.x * blockDim.x + threadIdx.x;
+  if (index >= npoints * nsample) return;
+  const int32_t j = idx[(int64_t)bs * npoints * nsample + index];
+  out[((int64_t)bs * c + ch) * npoints * nsample + index] = points[((int64_t)bs * c + ch) * n + j];
+}
+__global__ void pn2_group_points_grad_kernel(int c, int n, int npoints, int nsample,
+                                             const float* __restrict__ grad_out, const int32_t* __restrict__ idx,
+                                             float* __restrict__ grad_points) {
+  const int bs = blockIdx.z, ch = blockIdx.y;
+  const int index = blockIdx.x * blockDim.x + threadIdx.x;
+  if (index >= npoints * nsample) return;
+  const int32_t j = idx[(int64_t)bs * npoints * nsample + index];
+  atomicAdd(grad_points + ((int64_t)bs * c + ch) * n + j,
+            grad_out[((int64_t)bs * c + ch) * npoints * nsample + index]);
+}
+
+// ---- sampling_gpu.cu:8-24 / :46-63 -------------------------------------------------------------------
+__global__ void pn2_gather_points_kernel(int c, int n, int m, const float* __restrict__ points,
+                                         const int32_t* __restrict__ idx, float* __restrict__ out) {
+  const int bs = blockIdx.z, ch = blockIdx.y;
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= m) return;
+  out[((int64_t)bs * c + ch) * m + pt] = points[((int64_t)bs * c + ch) * n + idx[(int64_t)bs * m + pt]];
+}
+__global__ void pn2_gather_points_grad_kernel(int c, int n, int m, const float* __restrict__ grad_out,
+                                              const int32_t* __restrict__ idx, float* __restrict__ grad_points) {
+  const int bs = blockIdx.z, ch = blockIdx.y;
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= m) return;
+  atomicAdd(grad_points + ((int64_t)bs * c + ch) * n + idx[(int64_t)bs * m + pt],
+            grad_out[((int64_t)bs * c + ch) * m + pt]);
+}
+
+// ---- sampling_gpu.cu:93-209 : furthest point sampling ----------------------------------------------
+// One 1024-thread workgroup per cloud.  The arg-max reproduces the reference's result for ITS block size
+// Bref = opt_n_threads(n): highest distance, ties to the lowest reference thread id (k mod Bref), then
+// to the lowest k.  Wave-level reduction by shuffles, cross-wave through LDS.
+struct FpsCand {
+  float v;
+  int k;
+};
+__device__ __forceinline__ bool fps_better(float av, int ak, float bv, int bk, int bmask) {
+  if (av != bv) return av > bv;
+  const int ta = ak & bmask, tb = bk & bmask;
+  if (ta != tb) return ta < tb;
+  return ak < bk;
+}
+
+__global__ __launch_bounds__(1024) void pn2_fps_kernel(int n, int m, int bmask, const float* __restrict__ dataset,
+                                                       float* __restrict__ temp, int32_t* __restrict__ idxs) {
+  __shared__ float wv[16];
+  __shared__ int wk[16];
+  __shared__ int s_old;
+  const int bs = blockIdx.x;
+  const float* d = dataset + (int64_t)bs * n * 3;
+  float* t = temp + (int64_t)bs * n;
+  int32_t* out = idxs + (int64_t)bs * m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = d[old * 3], y1 = d[old * 3 + 1], z1 = d[old * 3 + 2];
+    float best = -1.f;
+    int besti = 0;
+    for (int k = tid; k < n; k += 1024) {
+      const float dd = dist2_nofma(d[k * 3], d[k * 3 + 1], d[k * 3 + 2], x1, y1, z1);
+      const float tk = t[k];
+      const float d2 = dd < tk ? dd : tk;
+      t[k] = d2;
+      if (d2 > best) { best = d2; besti = k; }
+    }
+    // threads with no point (tid >= n) carry (-1, tid): never better than a real candidate
+    if (tid >= n) besti = tid;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float ov = __shfl_down(best, off, 64);
+      const int ok = __shfl_down(besti, off, 64);
+      if (lane + off < 64 && fps_better(ov, ok, best, besti, bmask)) { best = ov; besti = ok; }
+    }
+    if (lane == 0) { wv[wave] = best; wk[wave] = besti; }
+    __syncthreads();
+    if (wave == 0) {
+      float v = lane < 16 ? wv[lane] : -2.f;
+      int k = lane < 16 ? wk[lane] : 0x7fffffff;
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const float ov = __shfl_down(v, off, 64);
+        const int ok = __shfl_down(k, off, 64);
+        if (fps_better(ov, ok, v, k, bmask)) { v = ov; k = ok; }
+      }
+      if (lane == 0) { s_old = k; out[j] = k; }
+    }
+    __syncthreads();
+    old = s_old;
+  }
+}
+
+// ---- interpolate_gpu.cu:81-124 : three_nn ------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void pn2_three_nn_kernel(int n, int m, const float* __restrict__ unknown,
+                                                                const float* __restrict__ known,
+                                                                float* __restrict__ dist2,
+                                                                int32_t* __restrict__ idx) {
+  __shared__ float tile[kThreads * 3];
+  const int bs = blockIdx.y;
+  const int pt = blockIdx.x * kThreads + threadIdx.x;
+  const bool active = pt < n;
+  const float* kn = known + (int64_t)bs * m * 3;
+  float ux = 0, uy = 0, uz = 0;
+  if (active) {
+    const float* u = unknown + ((int64_t)bs * n + pt) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  for (int k0 = 0; k0 < m; k0 += kThreads) {
+    const int n_here = (m - k0 < kThreads) ? (m - k0) : kThreads;
+    for (int e = threadIdx.x; e < n_here * 3; e += kThreads) tile[e] = kn[(int64_t)k0 * 3 + e];
+    __syncthreads();
+    if (active) {
+      for (int t = 0; t < n_here; ++t) {
+        const float d = dist2_nofma(ux, uy, uz, tile[t * 3], tile[t * 3 + 1], tile[t * 3 + 2]);
+        const int k = k0 + t;
+        if (d < best1) { best3 = best2; besti3 = besti2; best2 = best1; besti2 = besti1; best1 = d; besti1 = k; }
+        else if (d < best2) { best3 = best2; besti3 = besti2; best2 = d; besti2 = k; }
+        else if (d < best3) { best3 = d; besti3 = k; }
+      }
+    }
+    __syncthreads();
+  }
+  if (active) {
+    float* d2 = dist2 + ((int64_t)bs * n + pt) * 3;
+    int32_t* id = idx + ((int64_t)bs * n + pt) * 3;
+    d2[0] = (float)best1; d2[1] = (float)best2; d2[2] = (float)best3;
+    id[0] = besti1; id[1] = besti2; id[2] = besti3;
+  }
+}
+
+// ---- interpolate_gpu.cu:9-57 : knn (k <= 200), insertion into a sorted per-thread list ---------------
+__global__ __launch_bounds__(64) void pn2_knn_kernel(int n, int m, int k, const float* __restrict__ unknown,
+                                                     const float* __restrict__ known, float* __restrict__ dist2,
+                                                     int32_t* __restrict__ idx) {
+  const int bs = blockIdx.y;
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= n) return;
+  const float* u = unknown + ((int64_t)bs * n + pt) * 3;
+  const float* kn = known + (int64_t)bs * m * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  double best[200];
+  int besti[200];
+  for (int i = 0; i < k; ++i) { best[i] = 1e40; besti[i] = 0; }
+  for (int i = 0; i < m; ++i) {
+    const float d = dist2_nofma(ux, uy, uz, kn[i * 3], kn[i * 3 + 1], kn[i * 3 + 2]);
+    for (int j = 0; j < k; ++j) {
+      if (d < best[j]) {
+        for (int l = k - 1; l > j; --l) { best[l] = best[l - 1]; besti[l] = besti[l - 1]; }
+        best[j] = d; besti[j] = i;
+        break;
+      }
+    }
+  }
+  for (int i = 0; i < k; ++i) {
+    idx[((int64_t)bs * n + pt) * k + i] = besti[i];
+    dist2[((int64_t)bs * n + pt) * k + i] = (float)best[i];
+  }
+}
+
+// ---- interpolate_gpu.cu:149-169 / :192-214 -----------------------------------------------------------
+__global__ void pn2_three_interpolate_kernel(int c, int m, int n, const float* __restrict__ points,
+                                             const int32_t* __restrict__ idx, const float* __restrict__ weight,
+                                             float* __restrict__ out) {
+  const int bs = blockIdx.z, ch = blockIdx.y;
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= n) return;
+  const float* w = weight + ((int64_t)bs * n + pt) * 3;
+  const int32_t* id = idx + ((int64_t)bs * n + pt) * 3;
+  const float* p = points + ((int64_t)bs * c + ch) * m;
+  out[((int64_t)bs * c + ch) * n + pt] =
+      __fadd_rn(__fadd_rn(__fmul_rn(w[0], p[id[0]]), __fmul_rn(w[1], p[id[1]])), __fmul_rn(w[2], p[id[2]]));
+}
+__global__ void pn2_three_interpolate_grad_kernel(int c, int n, int m, const float* __restrict__ grad_out,
+                                                  const int32_t* __restrict__ idx,
+                                                  const float* __restrict__ weight,
+                                                  float* __restrict__ grad_points) {
+  const int bs = blockIdx.z, ch = blockIdx.y;
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= n) return;
+  const float g = grad_out[((int64_t)bs * c + ch) * n + pt];
+  const float* w = weight + ((int64_t)bs * n + pt) * 3;
+  const int32_t* id = idx + ((int64_t)bs * n + pt) * 3;
+  float* gp = grad_points + ((int64_t)bs * c + ch) * m;
+  atomicAdd(gp + id[0], __fmul_rn(g, w[0]));
+  atomicAdd(gp + id[1], __fmul_rn(g, w[1]));
+  atomicAdd(gp + id[2], __fmul_rn(g, w[2]));
+}
+
+int opt_n_threads(int work_size) {  // cuda_utils.h:10-14
+  const int pow_2 = (int)(std::log((double)work_size) / std::log(2.0));
+  int v = 1 << pow_2;
+  if (v > 1024) v = 1024;
+  if (v < 1) v = 1;
+  return v;
+}
+
+}  // namespace
+
+extern "C" int gpn_pn2_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz,
+                                  const float* xyz, int32_t* idx, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && nsample >= 1);
+  if (b == 0 || m == 0) return GPN_OK;
+  GPN_CHECK_ARG(new_xyz && xyz && idx);
+  hipLaunchKernelGGL(pn2_ball_query_kernel, dim3((unsigned)gpn::cdiv(m, kThreads), b), dim3(kThreads), 0, stream, n,
+                     m, radius * radius, nsample, new_xyz, xyz, idx);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_pn2_group_points(int b, int c, int n, int npoints, int nsample, const float* points,
+                                    const int32_t* idx, float* out, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+  if (b == 0 || c == 0 || npoints * nsample == 0) return GPN_OK;
+  GPN_CHECK_ARG(points && idx && out);
+  hipLaunchKernelGGL(pn2_group_points_kernel, dim3((unsigned)gpn::cdiv((int64_t)npoints * nsample, kThreads), c, b),
+                     dim3(kThreads), 0, stream, c, n, npoints, nsample, points, idx, out);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+extern "C" int gpn_pn2_group_points_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                                         const int32_t* idx, float* grad_points, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+  if (b == 0 || c == 0 || npoints * nsample == 0) return GPN_OK;
+  GPN_CHECK_ARG(grad_out && idx && grad_points);
+  hipLaunchKernelGGL(pn2_group_points_grad_kernel,
+                     dim3((unsigned)gpn::cdiv((int64_t)npoints * nsample, kThreads), c, b), dim3(kThreads), 0, stream,
+                     c, n, npoints, nsample, grad_out, idx, grad_points);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_pn2_gather_points(int b, int c, int n, int npoints, const float* points, const int32_t* idx,
+                                     float* out, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && npoints >= 0);
+  if (b == 0 || c == 0 || npoints == 0) return GPN_OK;
+  GPN_CHECK_ARG(points && idx && out);
+  hipLaunchKernelGGL(pn2_gather_points_kernel, dim3((unsigned)gpn::cdiv(npoints, kThreads), c, b), dim3(kThreads),
+                     0, stream, c, n, npoints, points, idx, out);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+extern "C" int gpn_pn2_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out,
+                                          const int32_t* idx, float* grad_points, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && npoints >= 0);
+  if (b == 0 || c == 0 || npoints == 0) return GPN_OK;
+  GPN_CHECK_ARG(grad_out && idx && grad_points);
+  hipLaunchKernelGGL(pn2_gather_points_grad_kernel, dim3((unsigned)gpn::cdiv(npoints, kThreads), c, b),
+                     dim3(kThreads), 0, stream, c, n, npoints, grad_out, idx, grad_points);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
+                                               int32_t* idxs, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && n >= 1 && m >= 0);
+  if (b == 0 || m == 0) return GPN_OK;
+  GPN_CHECK_ARG(dataset && temp && idxs);
+  const int bref = opt_n_threads(n);
+  hipLaunchKernelGGL(pn2_fps_kernel, dim3(b), dim3(1024), 0, stream, n, m, bref - 1, dataset, temp, idxs);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_pn2_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                                int32_t* idx, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && n >= 0 && m >= 0);
+  if (b == 0 || n == 0) return GPN_OK;
+  GPN_CHECK_ARG(unknown && known && dist2 && idx);
+  hipLaunchKernelGGL(pn2_three_nn_kernel, dim3((unsigned)gpn::cdiv(n, kThreads), b), dim3(kThreads), 0, stream, n,
+                     m, unknown, known, dist2, idx);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_pn2_knn(int b, int n, int m, int k, const float* unknown, const float* known, float* dist2,
+                           int32_t* idx, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && k >= 1 && k <= 200);
+  if (b == 0 || n == 0) return GPN_OK;
+  GPN_CHECK_ARG(unknown && known && dist2 && idx);
+  hipLaunchKernelGGL(pn2_knn_kernel, dim3((unsigned)gpn::cdiv(n, 64), b), dim3(64), 0, stream, n, m, k, unknown,
+                     known, dist2, idx);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_pn2_three_interpolate(int b, int c, int m, int n, const float* points, const int32_t* idx,
+                                         const float* weight, float* out, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && c >= 0 && m >= 0 && n >= 0);
+  if (b == 0 || c == 0 || n == 0) return GPN_OK;
+  GPN_CHECK_ARG(points && idx && weight && out);
+  hipLaunchKernelGGL(pn2_three_interpolate_kernel, dim3((unsigned)gpn::cdiv(n, kThreads), c, b), dim3(kThreads), 0,
+                     stream, c, m, n, points, idx, weight, out);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+extern "C" int gpn_pn2_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
+                                              const int32_t* idx, const float* weight, float* grad_points,
+                                              gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && c >= 0 && m >= 0 && n >= 0);
+  if (b == 0 || c == 0 || n == 0) return GPN_OK;
+  GPN_CHECK_ARG(grad_out && idx && weight && grad_points);
+  hipLaunchKernelGGL(pn2_three_interpolate_grad_kernel, dim3((unsigned)gpn::cdiv(n, kThreads), c, b),
+                     dim3(kThreads), 0, stream, c, n, m, grad_out, idx, weight, grad_points);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}

@@ -1,0 +1,379 @@
+// rulebook.hip — kernels K1/K2: rulebook (indice-pair) construction for
+// SubMConv3d(k=3,pad=1), SparseConv3d(k=2,s=2) and its SparseInverseConv3d partner.
+// Replaces the indice-pair build inside spconv (network/backbone.py:19-36,74-90,149-152).
+//
+// Design (MI355X): coordinates -> row lookups go through an open-addressing hash table in HBM/L2
+// (64-bit linear keys, linear probing, one atomicCAS per insert); every other step is a coalesced
+// streaming pass over a tap-major [K][n_dst] table: lookup -> exclusive scan (rocPRIM) -> compaction
+// into pair lists ordered by (tap, dst).  The scan doubles as the per-tile offset table the fused
+// conv kernel walks, so no sort is ever needed for SubM rulebooks.
+#include "gpn_common.h"  // first: pulls <cstring> ahead of the HIP/rocPRIM headers
+
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint64_t kEmpty = ~0ull;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
+__device__ __forceinline__ uint64_t lin_key(int b, int x, int y, int z, int s0, int s1, int s2) {
+  return (((uint64_t)b * (uint64_t)s0 + (uint64_t)x) * (uint64_t)s1 + (uint64_t)y) * (uint64_t)s2 + (uint64_t)z;
+}
+
+__global__ void hash_insert_kernel(const int32_t* __restrict__ indices, int64_t N, int s0, int s1, int s2,
+                                   uint64_t* __restrict__ hkeys, int32_t* __restrict__ hvals,
+                                   uint64_t mask) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int4 c = reinterpret_cast<const int4*>(indices)[i];
+  const uint64_t key = lin_key(c.x, c.y, c.z, c.w, s0, s1, s2);
+  uint64_t slot = mix64(key) & mask;
+  while (true) {
+    unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(hkeys + slot),
+                                        (unsigned long long)kEmpty, (unsigned long long)key);
+    if (prev == kEmpty || prev == key) {
+      // duplicates: the highest row id wins deterministically
+      atomicMax(hvals + slot, (int32_t)i);
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ int32_t hash_find(const uint64_t* __restrict__ hkeys,
+                                             const int32_t* __restrict__ hvals, uint64_t mask,
+                                             uint64_t key) {
+  uint64_t slot = mix64(key) & mask;
+  while (true) {
+    uint64_t k = hkeys[slot];
+    if (k == key) return hvals[slot];
+    if (k == kEmpty) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// table[k][o] = row of the voxel at coord(o)+delta_k, or -1.  One thread per (k,o); o fastest.
+__global__ void subm3_lookup_kernel(const int32_t* __restrict__ indices, int64_t N, int s0, int s1, int s2,
+                                    const uint64_t* __restrict__ hkeys, const int32_t* __restrict__ hvals,
+                                    uint64_t mask, int32_t* __restrict__ table) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 27 * N) return;
+  const int k = (int)(t / N);
+  const int64_t o = t - (int64_t)k * N;
+  const int4 c = reinterpret_cast<const int4*>(indices)[o];
+  const int x = c.y + (k / 9 - 1), y = c.z + ((k / 3) % 3 - 1), z = c.w + (k % 3 - 1);
+  int32_t r = -1;
+  if (k == 13) {
+    r = (int32_t)o;  // centre tap: the row itself
+  } else if (x >= 0 && x < s0 && y >= 0 && y < s1 && z >= 0 && z < s2) {
+    r = hash_find(hkeys, hvals, mask, lin_key(c.x, x, y, z, s0, s1, s2));
+  }
+  table[t] = r;
+}
+
+struct ValidFlag {
+  __device__ __host__ int32_t operator()(int32_t v) const { return v >= 0 ? 1 : 0; }
+};
+
+// pos = exclusive scan of (table >= 0) over K*n_dst+1 entries (last entry is a -1 sentinel)
+__global__ void compact_kernel(const int32_t* __restrict__ table, const int32_t* __restrict__ pos, int K,
+                               int64_t n_dst, int64_t n_tiles, int32_t* __restrict__ pair_src,
+                               int32_t* __restrict__ pair_dst, int32_t* __restrict__ tile_off,
+                               int64_t* __restrict__ num_pairs) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * n_dst;
+  if (t > total) return;
+  if (t == total) {
+    if (num_pairs) num_pairs[0] = pos[total];
+    tile_off[(int64_t)(K - 1) * (n_tiles + 1) + n_tiles] = pos[total];
+    return;
+  }
+  const int k = (int)(t / n_dst);
+  const int64_t o = t - (int64_t)k * n_dst;
+  const int32_t p = pos[t];
+  if ((o & (GPN_TILE_ROWS - 1)) == 0) tile_off[(int64_t)k * (n_tiles + 1) + o / GPN_TILE_ROWS] = p;
+  if (o == 0 && k > 0) tile_off[(int64_t)(k - 1) * (n_tiles + 1) + n_tiles] = p;
+  const int32_t s = table[t];
+  if (s >= 0) {
+    pair_src[p] = s;
+    pair_dst[p] = (int32_t)o;
+  }
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) p[t] = v;
+}
+__global__ void fill_u64_kernel(uint64_t* p, int64_t n, uint64_t v) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) p[t] = v;
+}
+
+size_t scan_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  auto in = rocprim::make_transform_iterator((const int32_t*)nullptr, ValidFlag());
+  rocprim::exclusive_scan(nullptr, bytes, in, (int32_t*)nullptr, 0, (size_t)(n > 0 ? n : 1),
+                          rocprim::plus<int32_t>(), (hipStream_t) nullptr);
+  return bytes;
+}
+
+// table: [K*n_dst + 1] with table[K*n_dst] == -1.  pos: [K*n_dst + 1].
+int lists_from_table(const int32_t* table, int32_t* pos, int K, int64_t n_dst, int32_t* pair_src,
+                     int32_t* pair_dst, int32_t* tile_off, int64_t* num_pairs, void* prim_tmp,
+                     size_t prim_bytes, hipStream_t stream) {
+  const int64_t total = (int64_t)K * n_dst + 1;
+  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
+  auto in = rocprim::make_transform_iterator(table, ValidFlag());
+  size_t tmp = prim_bytes;
+  GPN_CHECK_HIP(rocprim::exclusive_scan(prim_tmp, tmp, in, pos, 0, (size_t)total, rocprim::plus<int32_t>(),
+                                        stream));
+  hipLaunchKernelGGL(compact_kernel, dim3((int)gpn::cdiv(total, kThreads)), dim3(kThreads), 0, stream, table,
+                     pos, K, n_dst, n_tiles, pair_src, pair_dst, tile_off, num_pairs);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+uint64_t hash_capacity(int64_t N) {
+  uint64_t cap = 1024;
+  while (cap < (uint64_t)(2 * N)) cap <<= 1;
+  return cap;
+}
+
+// ------------------------------------------------------------------------------------------ down
+__global__ void down_keys_kernel(const int32_t* __restrict__ indices, int64_t N, int nb, int o0, int o1, int o2,
+                                 uint64_t invalid_key, uint64_t* __restrict__ keys,
+                                 uint32_t* __restrict__ vals, int32_t* __restrict__ tap) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int4 c = reinterpret_cast<const int4*>(indices)[i];
+  const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
+  tap[i] = (c.y & 1) * 4 + (c.z & 1) * 2 + (c.w & 1);
+  const bool ok = c.x >= 0 && c.x < nb && c.y >= 0 && c.z >= 0 && c.w >= 0 && x < o0 && y < o1 && z < o2;
+  keys[i] = ok ? lin_key(c.x, x, y, z, o0, o1, o2) : invalid_key;
+  vals[i] = (uint32_t)i;
+}
+
+__global__ void down_flags_kernel(const uint64_t* __restrict__ ks, int64_t N, uint64_t invalid_key,
+                                  int32_t* __restrict__ flags) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  uint64_t k = ks[j];
+  flags[j] = (k != invalid_key && (j == 0 || ks[j - 1] != k)) ? 1 : 0;
+}
+
+__global__ void down_emit_kernel(const uint64_t* __restrict__ ks, const uint32_t* __restrict__ order,
+                                 const int32_t* __restrict__ incl, const int32_t* __restrict__ indices,
+                                 int64_t N, uint64_t invalid_key, int32_t* __restrict__ out_indices,
+                                 int32_t* __restrict__ fine_to_coarse, int64_t* __restrict__ num_out) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  if (j == N - 1) num_out[0] = incl[j];
+  const uint64_t k = ks[j];
+  const uint32_t i = order[j];
+  if (k == invalid_key) {
+    fine_to_coarse[i] = -1;
+    return;
+  }
+  const int32_t v = incl[j] - 1;
+  fine_to_coarse[i] = v;
+  if (j == 0 || ks[j - 1] != k) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[i];
+    reinterpret_cast<int4*>(out_indices)[v] = make_int4(c.x, c.y >> 1, c.z >> 1, c.w >> 1);
+  }
+}
+
+__global__ void down_scatter_tables_kernel(const int32_t* __restrict__ fine_to_coarse,
+                                           const int32_t* __restrict__ tap, int64_t N, int64_t n_out,
+                                           int32_t* __restrict__ tf, int32_t* __restrict__ tb) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int32_t o = fine_to_coarse[i];
+  if (o < 0) return;
+  const int k = tap[i];
+  tf[(int64_t)k * n_out + o] = (int32_t)i;
+  tb[(int64_t)k * N + i] = o;
+}
+
+size_t sort_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                            (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)(n > 0 ? n : 1), 0u, 64u,
+                            (hipStream_t) nullptr);
+  return bytes;
+}
+size_t iscan_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  rocprim::inclusive_scan(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr,
+                          (size_t)(n > 0 ? n : 1), rocprim::plus<int32_t>(), (hipStream_t) nullptr);
+  return bytes;
+}
+
+}  // namespace
+
+// ================================================================================================ subm3
+extern "C" size_t gpn_rulebook_subm3_ws_bytes(int64_t N) {
+  gpn::WsCarver w(nullptr, 0);
+  size_t n = (size_t)(N > 0 ? N : 1);
+  w.take<uint64_t>(hash_capacity(N));
+  w.take<int32_t>(hash_capacity(N));
+  w.take<int32_t>(27 * n + 1);
+  w.take<int32_t>(27 * n + 1);
+  w.take<char>(scan_temp_bytes(27 * (int64_t)n + 1));
+  return w.used;
+}
+
+extern "C" int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32_t* spatial_shape_host,
+                                  int32_t* pair_src, int32_t* pair_dst, int32_t* tile_off,
+                                  int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(N >= 0 && spatial_shape_host && tile_off);
+  GPN_CHECK_ARG(27 * N + 1 < (int64_t)0x7fffffff);
+  const int s0 = spatial_shape_host[0], s1 = spatial_shape_host[1], s2 = spatial_shape_host[2];
+  GPN_CHECK_ARG(s0 > 0 && s1 > 0 && s2 > 0);
+  const int64_t n_tiles = gpn::cdiv(N, GPN_TILE_ROWS);
+  if (N == 0) {
+    GPN_CHECK_HIP(hipMemsetAsync(tile_off, 0, sizeof(int32_t) * 27 * (n_tiles + 1), stream));
+    if (num_pairs) GPN_CHECK_HIP(hipMemsetAsync(num_pairs, 0, sizeof(int64_t), stream));
+    return GPN_OK;
+  }
+  GPN_CHECK_ARG(indices && pair_src && pair_dst);
+  gpn::WsCarver w(ws, ws_bytes);
+  const uint64_t cap = hash_capacity(N);
+  uint64_t* hkeys = w.take<uint64_t>(cap);
+  int32_t* hvals = w.take<int32_t>(cap);
+  int32_t* table = w.take<int32_t>(27 * (size_t)N + 1);
+  int32_t* pos = w.take<int32_t>(27 * (size_t)N + 1);
+  size_t prim_bytes = scan_temp_bytes(27 * N + 1);
+  void* prim_tmp = w.take<char>(prim_bytes);
+  GPN_CHECK_WS(w);
+
+  gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 16.0 * (double)N + 8.0 * 27.0 * (double)N);
+  hipLaunchKernelGGL(fill_u64_kernel, dim3((int)gpn::cdiv((int64_t)cap, kThreads)), dim3(kThreads), 0, stream,
+                     hkeys, (int64_t)cap, kEmpty);
+  GPN_CHECK_HIP(hipMemsetAsync(hvals, 0xff, sizeof(int32_t) * cap, stream));  // -1
+  hipLaunchKernelGGL(hash_insert_kernel, dim3((int)gpn::cdiv(N, kThreads)), dim3(kThreads), 0, stream, indices,
+                     N, s0, s1, s2, hkeys, hvals, cap - 1);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(subm3_lookup_kernel, dim3((int)gpn::cdiv(27 * N, kThreads)), dim3(kThreads), 0, stream,
+                     indices, N, s0, s1, s2, hkeys, hvals, cap - 1, table);
+  GPN_CHECK_LAUNCH();
+  GPN_CHECK_HIP(hipMemsetAsync(table + 27 * N, 0xff, sizeof(int32_t), stream));
+  return lists_from_table(table, pos, 27, N, pair_src, pair_dst, tile_off, num_pairs, prim_tmp, prim_bytes,
+                          stream);
+}
+
+// ================================================================================================ down
+extern "C" size_t gpn_rulebook_down_ws_bytes(int64_t N) {
+  gpn::WsCarver w(nullptr, 0);
+  size_t n = (size_t)(N > 0 ? N : 1);
+  w.take<uint64_t>(n);
+  w.take<uint64_t>(n);
+  w.take<uint32_t>(n);
+  w.take<uint32_t>(n);
+  w.take<int32_t>(n);
+  w.take<int32_t>(n);
+  size_t a = sort_temp_bytes(N), b = iscan_temp_bytes(N);
+  w.take<char>(a > b ? a : b);
+  return w.used;
+}
+
+extern "C" int gpn_rulebook_down(const int32_t* indices, int64_t N, int64_t batch_size,
+                                 const int32_t* spatial_shape_host, int32_t* out_indices, int32_t* fine_to_coarse, int32_t* tap,
+                                 int64_t* num_out, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(N >= 0 && spatial_shape_host && num_out);
+  if (N == 0) {
+    GPN_CHECK_HIP(hipMemsetAsync(num_out, 0, sizeof(int64_t), stream));
+    return GPN_OK;
+  }
+  GPN_CHECK_ARG(indices && out_indices && fine_to_coarse && tap);
+  GPN_CHECK_ARG(N < (int64_t)0x7fffffff);
+  const int o0 = spatial_shape_host[0] / 2, o1 = spatial_shape_host[1] / 2, o2 = spatial_shape_host[2] / 2;
+  GPN_CHECK_ARG(o0 > 0 && o1 > 0 && o2 > 0);
+  GPN_CHECK_ARG(batch_size >= 1);
+  const uint64_t batch_bound = (uint64_t)batch_size;  // rows with batch >= batch_size are dropped
+  long double total = (long double)batch_bound * o0 * o1 * o2;
+  GPN_CHECK_ARG(total < 9.0e18L);
+  const uint64_t invalid_key = batch_bound * (uint64_t)o0 * (uint64_t)o1 * (uint64_t)o2;
+  unsigned key_bits = 1;
+  while (key_bits < 64 && (invalid_key >> key_bits) != 0) ++key_bits;
+
+  gpn::WsCarver w(ws, ws_bytes);
+  uint64_t* keys = w.take<uint64_t>((size_t)N);
+  uint64_t* ks = w.take<uint64_t>((size_t)N);
+  uint32_t* vals = w.take<uint32_t>((size_t)N);
+  uint32_t* order = w.take<uint32_t>((size_t)N);
+  int32_t* flags = w.take<int32_t>((size_t)N);
+  int32_t* incl = w.take<int32_t>((size_t)N);
+  size_t a = sort_temp_bytes(N), b = iscan_temp_bytes(N);
+  size_t prim_bytes = a > b ? a : b;
+  void* prim_tmp = w.take<char>(prim_bytes);
+  GPN_CHECK_WS(w);
+
+  const int grid = (int)gpn::cdiv(N, kThreads);
+  gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 16.0 * (double)N * 2 + 8.0 * (double)N);
+  hipLaunchKernelGGL(down_keys_kernel, dim3(grid), dim3(kThreads), 0, stream, indices, N, (int)batch_size, o0,
+                     o1, o2, invalid_key, keys, vals, tap);
+  GPN_CHECK_LAUNCH();
+  size_t tmp = prim_bytes;
+  GPN_CHECK_HIP(rocprim::radix_sort_pairs(prim_tmp, tmp, keys, ks, vals, order, (size_t)N, 0u, key_bits, stream));
+  hipLaunchKernelGGL(down_flags_kernel, dim3(grid), dim3(kThreads), 0, stream, ks, N, invalid_key, flags);
+  GPN_CHECK_LAUNCH();
+  tmp = prim_bytes;
+  GPN_CHECK_HIP(rocprim::inclusive_scan(prim_tmp, tmp, flags, incl, (size_t)N, rocprim::plus<int32_t>(), stream));
+  hipLaunchKernelGGL(down_emit_kernel, dim3(grid), dim3(kThreads), 0, stream, ks, order, incl, indices, N,
+                     invalid_key, out_indices, fine_to_coarse, num_out);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" size_t gpn_rulebook_down_lists_ws_bytes(int64_t N, int64_t n_out) {
+  gpn::WsCarver w(nullptr, 0);
+  size_t n = (size_t)(N > 0 ? N : 1), no = (size_t)(n_out > 0 ? n_out : 1);
+  w.take<int32_t>(8 * no + 1);
+  w.take<int32_t>(8 * n + 1);
+  w.take<int32_t>(8 * n + 1);  // pos (shared, sized for the larger table)
+  w.take<char>(scan_temp_bytes(8 * (int64_t)n + 1));
+  return w.used;
+}
+
+extern "C" int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N,
+                                       int64_t n_out, int32_t* fwd_src, int32_t* fwd_dst,
+                                       int32_t* fwd_tile_off, int32_t* bwd_src, int32_t* bwd_dst,
+                                       int32_t* bwd_tile_off, int64_t* num_pairs, void* ws, size_t ws_bytes,
+                                       gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(N >= 0 && n_out >= 0 && n_out <= N && fwd_tile_off && bwd_tile_off);
+  const int64_t nt_f = gpn::cdiv(n_out, GPN_TILE_ROWS), nt_b = gpn::cdiv(N, GPN_TILE_ROWS);
+  if (N == 0 || n_out == 0) {
+    GPN_CHECK_HIP(hipMemsetAsync(fwd_tile_off, 0, sizeof(int32_t) * 8 * (nt_f + 1), stream));
+    GPN_CHECK_HIP(hipMemsetAsync(bwd_tile_off, 0, sizeof(int32_t) * 8 * (nt_b + 1), stream));
+    if (num_pairs) GPN_CHECK_HIP(hipMemsetAsync(num_pairs, 0, sizeof(int64_t), stream));
+    return GPN_OK;
+  }
+  GPN_CHECK_ARG(fine_to_coarse && tap && fwd_src && fwd_dst && bwd_src && bwd_dst);
+  gpn::WsCarver w(ws, ws_bytes);
+  int32_t* tf = w.take<int32_t>(8 * (size_t)n_out + 1);
+  int32_t* tb = w.take<int32_t>(8 * (size_t)N + 1);
+  int32_t* pos = w.take<int32_t>(8 * (size_t)N + 1);
+  size_t prim_bytes = scan_temp_bytes(8 * N + 1);
+  void* prim_tmp = w.take<char>(prim_bytes);
+  GPN_CHECK_WS(w);
+  gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 8.0 * (double)N + 16.0 * (double)N);
+  GPN_CHECK_HIP(hipMemsetAsync(tf, 0xff, sizeof(int32_t) * (8 * (size_t)n_out + 1), stream));
+  GPN_CHECK_HIP(hipMemsetAsync(tb, 0xff, sizeof(int32_t) * (8 * (size_t)N + 1), stream));
+  hipLaunchKernelGGL(down_scatter_tables_kernel, dim3((int)gpn::cdiv(N, kThreads)), dim3(kThreads), 0, stream,
+                     fine_to_coarse, tap, N, n_out, tf, tb);
+  GPN_CHECK_LAUNCH();
+  int rc = lists_from_table(tf, pos, 8, n_out, fwd_src, fwd_dst, fwd_tile_off, num_pairs, prim_tmp, prim_bytes,
+                            stream);
+  if (rc != GPN_OK) return rc;
+  return lists_from_table(tb, pos, 8, N, bwd_src, bwd_dst, bwd_tile_off, nullptr, prim_tmp, prim_bytes, stream);
+}

@@ -1,0 +1,431 @@
+// spconv.hip — kernel C: sparse convolution forward / dgrad / wgrad for gfx950.
+// Replaces the gather-GEMM-scatter conv inside spconv (network/backbone.py:19-36,74-90,149-152).
+//
+// Design (MI355X / CDNA4, wave64):
+//  * ONE fused kernel per conv, output-stationary: a wave owns a tile of 32*TM destination rows and
+//    keeps that tile's fp32 accumulators in its private slice of LDS.  For each tap k it walks the
+//    tile's slice of pair list k (rulebook tile_off), 16 pairs per step: the 16 gathered source rows
+//    are the MFMA A operand, the tap's weight slab the B operand, v_mfma_f32_16x16x4_f32 does the
+//    per-rule dense contraction (exact fp32, == an fmaf chain), and the 16x(16*NT) result is added
+//    to the owning rows of the LDS tile.  Each output row is written to HBM exactly once — no global
+//    atomics, no separate gather/scatter kernels, deterministic summation order (tap-major).
+//  * A operand straight from global memory with one 16-byte load per lane: lane (i = l&15, g = l>>4)
+//    loads channels [16cb+4g, 16cb+4g+4) of pair i's source row, i.e. every gathered row is read as
+//    whole contiguous 64-byte pieces.  The 4 loaded channels feed 4 consecutive MFMA steps; the
+//    matching K-permutation is baked into the packed weights (gpn_spconv_pack_weights), whose
+//    per-(tap, channel-block, column-tile) fragment is one coalesced 1 KiB load per wave.
+//  * dgrad is the same kernel on the transposed rulebook with transposed (and for SubM, tap-reversed)
+//    packed weights.  wgrad contracts over pairs: A = in[src]^T, B = dout[dst], 4 pairs per MFMA,
+//    split over (tap, pair-range, cin-group) workgroups with a fixed-order partial reduction.
+#include "gpn_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// weight packing:  packed[k][cb][nt][lane][s] = Wop[k][16cb + 4(lane>>4) + s][16nt + (lane&15)]
+__global__ void pack_weights_kernel(const float* __restrict__ W, int K, int cin_w, int cout_w, int flags,
+                                    float* __restrict__ packed) {
+  const int cin = (flags & GPN_PACK_TRANSPOSE) ? cout_w : cin_w;
+  const int cout = (flags & GPN_PACK_TRANSPOSE) ? cin_w : cout_w;
+  const int64_t total = (int64_t)K * cin * cout;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int s = (int)(t & 3);
+  const int lane = (int)((t >> 2) & 63);
+  int64_t r = t >> 8;
+  const int NT = cout / 16, CB = cin / 16;
+  const int nt = (int)(r % NT); r /= NT;
+  const int cb = (int)(r % CB); r /= CB;
+  const int k = (int)r;
+  const int ci = cb * 16 + 4 * (lane >> 4) + s;
+  const int co = nt * 16 + (lane & 15);
+  const int kk = (flags & GPN_PACK_REVERSE) ? (K - 1 - k) : k;
+  float v;
+  if (flags & GPN_PACK_TRANSPOSE) v = W[((int64_t)kk * cin_w + co) * cout_w + ci];
+  else v = W[((int64_t)kk * cin_w + ci) * cout_w + co];
+  packed[t] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused gather-MFMA-scatter conv.  blockDim = 256 (4 independent waves), wave tile = 32*TM rows.
+template <int NT, int TM>
+__global__ __launch_bounds__(256) void spconv_fwd_kernel(
+    const float* __restrict__ in, const float* __restrict__ packed, const int32_t* __restrict__ pair_src,
+    const int32_t* __restrict__ pair_dst, const int32_t* __restrict__ tile_off, int K, int64_t n_dst,
+    int64_t n_tiles, int cin, float* __restrict__ out) {
+  constexpr int COUT = NT * 16;
+  constexpr int LDW = COUT + 16;  // +16 floats: rows an odd distance apart land on disjoint bank halves
+  constexpr int ROWS = 32 * TM;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* acc_lds = smem + (size_t)wave * ROWS * LDW;
+
+  const int64_t wtile = (int64_t)blockIdx.x * 4 + wave;  // wave-tile index
+  const int64_t t0 = wtile * TM;                         // first 32-row tile
+  if (t0 >= n_tiles) return;
+  const int64_t t1 = (t0 + TM < n_tiles) ? (t0 + TM) : n_tiles;
+  const int64_t row0 = t0 * GPN_TILE_ROWS;
+
+  // zero the accumulator tile
+  for (int e = lane * 4; e < ROWS * LDW; e += 64 * 4) *reinterpret_cast<f32x4*>(acc_lds + e) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int i16 = lane & 15, g = lane >> 4;
+  const int CB = cin >> 4;
+  const f32x4* __restrict__ pw = reinterpret_cast<const f32x4*>(packed);
+
+  for (int k = 0; k < K; ++k) {
+    const int32_t p_begin = tile_off[(int64_t)k * (n_tiles + 1) + t0];
+    const int32_t p_end = tile_off[(int64_t)k * (n_tiles + 1) + t1];
+    for (int32_t p0 = p_begin; p0 < p_end; p0 += 16) {
+      const int32_t p = p0 + i16;
+      const bool valid = p < p_end;
+      const int32_t src = valid ? pair_src[p] : 0;
+      const int32_t dstl = valid ? (int32_t)(pair_dst[p] - row0) : -1;
+      const float* arow = in + (int64_t)src * cin + 4 * g;
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int cb = 0; cb < CB; ++cb) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (valid) a = *reinterpret_cast<const f32x4*>(arow + cb * 16);
+        const f32x4* wrow = pw + ((int64_t)(k * CB + cb) * NT) * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const f32x4 b = wrow[nt * 64];
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nt], 0, 0, 0);
+        }
+      }
+      // D[row = 4g + r][col = i16] belongs to pair p0 + 4g + r, whose local dst row lane (4g+r) holds
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = __shfl(dstl, 4 * g + r, 64);
+        if (row >= 0) {
+          float* dstp = acc_lds + row * LDW + i16;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) dstp[nt * 16] += acc[nt][r];
+        }
+      }
+    }
+  }
+
+  // write the tile: COUT/4 float4 per row
+  const int64_t rows_here = (n_dst - row0 < ROWS) ? (n_dst - row0) : ROWS;
+  constexpr int V4 = COUT / 4;
+  for (int e = lane; e < (int)rows_here * V4; e += 64) {
+    const int r = e / V4, c4 = e - r * V4;
+    *reinterpret_cast<f32x4*>(out + (row0 + r) * COUT + c4 * 4) =
+        *reinterpret_cast<const f32x4*>(acc_lds + r * LDW + c4 * 4);
+  }
+}
+
+template <int NT, int TM>
+int launch_fwd(const float* in, const float* packed, const int32_t* pair_src, const int32_t* pair_dst,
+               const int32_t* tile_off, int K, int64_t n_dst, int cin, float* out, hipStream_t stream) {
+  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
+  const int64_t n_wtiles = gpn::cdiv(n_tiles, TM);
+  const int grid = (int)gpn::cdiv(n_wtiles, 4);
+  const size_t lds = (size_t)4 * 32 * TM * (NT * 16 + 16) * sizeof(float);
+  auto kfn = spconv_fwd_kernel<NT, TM>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    GPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, in, packed, pair_src, pair_dst, tile_off, K,
+                     n_dst, n_tiles, cin, out);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+template <int TM>
+int dispatch_fwd_nt(int nt, const float* in, const float* packed, const int32_t* pair_src,
+                    const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin, float* out,
+                    hipStream_t stream) {
+  switch (nt) {
+#define GPN_CASE(N) \
+  case N: return launch_fwd<N, TM>(in, packed, pair_src, pair_dst, tile_off, K, n_dst, cin, out, stream);
+    GPN_CASE(1) GPN_CASE(2) GPN_CASE(3) GPN_CASE(4) GPN_CASE(5) GPN_CASE(6) GPN_CASE(7) GPN_CASE(8)
+    GPN_CASE(9) GPN_CASE(10) GPN_CASE(11) GPN_CASE(12) GPN_CASE(13) GPN_CASE(14)
+#undef GPN_CASE
+    default:
+      gpn::set_error("gpn_spconv_fwd: cout=%d not supported (must be a multiple of 16, <= 224)", nt * 16);
+      return GPN_ERR_ARG;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: partial[s][k][ci][co] = sum over the s-th slice of pair list k of in[src][ci] * dout[dst][co]
+// grid = (K, S, CIG); 256 threads = 4 waves striding over 4-pair groups; fixed-order LDS reduction.
+template <int CT, int NT>
+__global__ __launch_bounds__(256) void spconv_wgrad_kernel(
+    const float* __restrict__ in, const float* __restrict__ dout, const int32_t* __restrict__ pair_src,
+    const int32_t* __restrict__ pair_dst, const int32_t* __restrict__ tile_off, int64_t n_tiles, int cin,
+    int S, float* __restrict__ partial) {
+  constexpr int COUT = NT * 16;
+  __shared__ float red[CT * NT * 256];
+  const int k = blockIdx.x, s = blockIdx.y, cig = blockIdx.z;
+  const int K = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int ct_tiles = cin >> 4;
+  const int ct0 = cig * CT;
+
+  const int32_t l_begin = tile_off[(int64_t)k * (n_tiles + 1)];
+  const int32_t l_end = tile_off[(int64_t)k * (n_tiles + 1) + n_tiles];
+  const int32_t len = l_end - l_begin;
+  int32_t chunk = (len + S - 1) / S;
+  chunk = (chunk + 3) & ~3;
+  const int32_t a = l_begin + s * chunk;
+  int32_t b = a + chunk;
+  if (b > l_end) b = l_end;
+
+  f32x4 acc[CT][NT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int32_t p0 = a + 4 * wave; p0 < b; p0 += 16) {
+    const int32_t p = p0 + g;
+    const bool valid = p < b;
+    const int32_t src = valid ? pair_src[p] : 0;
+    const int32_t dst = valid ? pair_dst[p] : 0;
+    float av[CT], bv[NT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      av[ct] = 0.f;
+      if (valid && ct0 + ct < ct_tiles) av[ct] = in[(int64_t)src * cin + (ct0 + ct) * 16 + i16];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bv[nt] = 0.f;
+      if (valid) bv[nt] = dout[(int64_t)dst * COUT + nt * 16 + i16];
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct], bv[nt], acc[ct][nt], 0, 0, 0);
+  }
+
+  // fixed-order reduction over the 4 waves through LDS (element (ct,nt,r,lane) -> red[((ct*NT+nt)*4+r)*64+lane])
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* q = red + ((ct * NT + nt) * 4 + r) * 64 + lane;
+            if (w == 0) *q = acc[ct][nt][r];
+            else *q += acc[ct][nt][r];
+          }
+    }
+    __syncthreads();
+  }
+  // store: D[row = 4g + r][col = i16] -> ci = (ct0+ct)*16 + 4g + r, co = nt*16 + i16
+  float* pbase = partial + ((int64_t)s * K + k) * (int64_t)cin * COUT;
+  for (int e = threadIdx.x; e < CT * NT * 256; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, tn = e >> 8;
+    const int nt = tn % NT, ct = tn / NT;
+    if (ct0 + ct >= ct_tiles) continue;
+    const int ci = (ct0 + ct) * 16 + 4 * (l >> 4) + r;
+    const int co = nt * 16 + (l & 15);
+    pbase[(int64_t)ci * COUT + co] = red[e];
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t elems,
+                                    float* __restrict__ dW) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= elems) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += partial[(int64_t)s * elems + t];
+  dW[t] = acc;
+}
+
+int wgrad_splits(int K, int cin, int64_t n_dst) {
+  const int ct_tiles = cin / 16;
+  const int CT = ct_tiles < 4 ? ct_tiles : 4;
+  const int cig = (ct_tiles + CT - 1) / CT;
+  int64_t S = 1024 / ((int64_t)K * cig);
+  int64_t cap = n_dst / 256;
+  if (S > cap) S = cap;
+  if (S < 1) S = 1;
+  if (S > 256) S = 256;
+  return (int)S;
+}
+
+template <int CT, int NT>
+int launch_wgrad(const float* in, const float* dout, const int32_t* pair_src, const int32_t* pair_dst,
+                 const int32_t* tile_off, int K, int64_t n_dst, int cin, int S, float* partial,
+                 hipStream_t stream) {
+  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
+  const int ct_tiles = cin / 16;
+  const int cig = (ct_tiles + CT - 1) / CT;
+  hipLaunchKernelGGL((spconv_wgrad_kernel<CT, NT>), dim3(K, S, cig), dim3(256), 0, stream, in, dout, pair_src,
+                     pair_dst, tile_off, n_tiles, cin, S, partial);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+template <int CT>
+int dispatch_wgrad_nt(int nt, const float* in, const float* dout, const int32_t* pair_src,
+                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin, int S,
+                      float* partial, hipStream_t stream) {
+  switch (nt) {
+#define GPN_CASE(N) \
+  case N: return launch_wgrad<CT, N>(in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream);
+    GPN_CASE(1) GPN_CASE(2) GPN_CASE(3) GPN_CASE(4) GPN_CASE(5) GPN_CASE(6) GPN_CASE(7) GPN_CASE(8)
+#undef GPN_CASE
+    default:
+      gpn::set_error("gpn_spconv_wgrad: cout=%d not supported (multiple of 16, <= 128)", nt * 16);
+      return GPN_ERR_ARG;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ G
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, int64_t n,
+                                   int C4, float* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C4) return;
+  const int64_t i = t / C4;
+  const int c = (int)(t - i * C4);
+  const int32_t r = idx[i];
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (r >= 0) v = reinterpret_cast<const f32x4*>(table)[(int64_t)r * C4 + c];
+  reinterpret_cast<f32x4*>(out)[t] = v;
+}
+__global__ void gather_rows_scalar_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx,
+                                          int64_t n, int C, float* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  const int64_t i = t / C;
+  const int c = (int)(t - i * C);
+  const int32_t r = idx[i];
+  out[t] = r >= 0 ? table[(int64_t)r * C + c] : 0.f;
+}
+// dtable[r][c] = ordered sum over the points of row r
+__global__ void scatter_rows_csr_kernel(const float* __restrict__ dout, const int32_t* __restrict__ order,
+                                        const int32_t* __restrict__ starts, int64_t n_rows, int C,
+                                        float* __restrict__ dtable) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_rows * C) return;
+  const int64_t r = t / C;
+  const int c = (int)(t - r * C);
+  float acc = 0.f;
+  for (int32_t j = starts[r]; j < starts[r + 1]; ++j) acc += dout[(int64_t)order[j] * C + c];
+  dtable[t] = acc;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cout_w, int flags, float* packed,
+                                       gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(W && packed && K >= 1);
+  GPN_CHECK_ARG(cin_w >= 16 && cout_w >= 16 && cin_w % 16 == 0 && cout_w % 16 == 0);
+  const int64_t total = (int64_t)K * cin_w * cout_w;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((int)gpn::cdiv(total, 256)), dim3(256), 0, stream, W, K, cin_w,
+                     cout_w, flags, packed);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* pair_src,
+                              const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
+                              int cout, float* out, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(K >= 1 && n_dst >= 0);
+  GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
+  if (n_dst == 0) return GPN_OK;
+  GPN_CHECK_ARG(in && packed_w && pair_src && pair_dst && tile_off && out);
+  const int nt = cout / 16;
+  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
+  // 64-row wave tiles once there are enough of them to fill the chip (256 CUs x 2 workgroups x 4 waves)
+  const bool big = n_tiles >= 2 * 2048 && nt <= 8;
+  gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
+  if (big) return dispatch_fwd_nt<2>(nt, in, packed_w, pair_src, pair_dst, tile_off, K, n_dst, cin, out, stream);
+  return dispatch_fwd_nt<1>(nt, in, packed_w, pair_src, pair_dst, tile_off, K, n_dst, cin, out, stream);
+}
+
+extern "C" size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst) {
+  const int S = wgrad_splits(K, cin, n_dst);
+  return gpn::align_up((size_t)S * K * cin * cout * sizeof(float));
+}
+
+extern "C" int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
+                                const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
+                                int cout, float* dW, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(K >= 1 && n_dst >= 0 && dW);
+  GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
+  const int64_t elems = (int64_t)K * cin * cout;
+  if (n_dst == 0) {
+    GPN_CHECK_HIP(hipMemsetAsync(dW, 0, sizeof(float) * elems, stream));
+    return GPN_OK;
+  }
+  GPN_CHECK_ARG(in && dout && pair_src && pair_dst && tile_off);
+  const int S = wgrad_splits(K, cin, n_dst);
+  if (ws_bytes < (size_t)S * elems * sizeof(float) || !ws) {
+    gpn::set_error("gpn_spconv_wgrad: workspace too small");
+    return GPN_ERR_WS;
+  }
+  float* partial = static_cast<float*>(ws);
+  const int ct_tiles = cin / 16;
+  const int CT = ct_tiles < 4 ? ct_tiles : 4;
+  const int nt = cout / 16;
+  int rc;
+  {
+    gpn::ProfScope prof(GPN_K_SPCONV_WGRAD, stream, 0.0, 0.0);
+    switch (CT) {
+      case 1: rc = dispatch_wgrad_nt<1>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream); break;
+      case 2: rc = dispatch_wgrad_nt<2>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream); break;
+      case 3: rc = dispatch_wgrad_nt<3>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream); break;
+      default: rc = dispatch_wgrad_nt<4>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream); break;
+    }
+  }
+  if (rc != GPN_OK) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)gpn::cdiv(elems, 256)), dim3(256), 0, stream, partial, S,
+                     elems, dW);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_gather_rows(const float* table, const int32_t* idx, int64_t n, int C, float* out,
+                               gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(n >= 0 && C >= 1);
+  if (n == 0) return GPN_OK;
+  GPN_CHECK_ARG(table && idx && out);
+  if (C % 4 == 0) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((int)gpn::cdiv(n * (C / 4), 256)), dim3(256), 0, stream, table,
+                       idx, n, C / 4, out);
+  } else {
+    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((int)gpn::cdiv(n * C, 256)), dim3(256), 0, stream, table,
+                       idx, n, C, out);
+  }
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_scatter_rows_csr(const float* dout, const int32_t* order, const int32_t* starts,
+                                    int64_t n_rows, int C, float* dtable, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(n_rows >= 0 && C >= 1);
+  if (n_rows == 0) return GPN_OK;
+  GPN_CHECK_ARG(dout && order && starts && dtable);
+  hipLaunchKernelGGL(scatter_rows_csr_kernel, dim3((int)gpn::cdiv(n_rows * C, 256)), dim3(256), 0, stream, dout,
+                     order, starts, n_rows, C, dtable);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}

@@ -1,0 +1,114 @@
+"""Autograd wrappers over the raw operators (backend-neutral: they call ``backend.raw()``).
+
+  sparse_conv        — kernel C (forward / dgrad / wgrad) as one differentiable op
+  gather_rows        — kernel G: voxel rows -> points, deterministic CSR transpose in backward
+  segmented_maxpool  — kernel R (differentiable max-pool over proposal segments)
+"""
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import backend
+
+# optional log of conv launches for bench.py's roofline accounting: entries (num_pairs tensor, cin, cout, n_src, n_dst, K, kind)
+CONV_LOG = None
+
+
+def _log(rb, cin, cout, kind):
+    if CONV_LOG is not None:
+        CONV_LOG.append((rb.num_pairs, cin, cout, rb.n_src, rb.n_dst, rb.K, kind))
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """out[dst] = sum_k features[src] @ W[k] over rulebook ``rb``; ``rb_t`` is the transposed rulebook used by
+    dgrad (for SubM convs rb_t is rb and the taps are reversed)."""
+
+    @staticmethod
+    def forward(ctx, features, weight, rb, rb_t, reverse_taps):
+        ops = backend.raw()
+        features = features.contiguous()
+        weight = weight.contiguous()
+        out = ops.conv_fwd(features, weight, rb)
+        _log(rb, weight.shape[1], weight.shape[2], "fwd")
+        ctx.save_for_backward(features, weight)
+        ctx.rb, ctx.rb_t, ctx.reverse_taps = rb, rb_t, reverse_taps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops = backend.raw()
+        features, weight = ctx.saved_tensors
+        dout = dout.contiguous()
+        din = dW = None
+        if ctx.needs_input_grad[0]:
+            din = ops.conv_dgrad(dout, weight, ctx.rb, ctx.rb_t, ctx.reverse_taps)
+            _log(ctx.rb_t, weight.shape[2], weight.shape[1], "dgrad")
+        if ctx.needs_input_grad[1]:
+            dW = ops.conv_wgrad(features, dout, ctx.rb)
+            _log(ctx.rb, weight.shape[1], weight.shape[2], "wgrad")
+        return din, dW, None, None, None
+
+
+def sparse_conv(features: torch.Tensor, weight: torch.Tensor, rb, rb_t, reverse_taps: bool) -> torch.Tensor:
+    """features [n_src, cin], weight canonical [K, cin, cout] -> [n_dst, cout].
+
+    The kernels need channel counts that are multiples of 16; other sizes (the 6-channel stem) are zero-padded
+    here, inside autograd, so gradients are sliced back automatically."""
+    K, cin, cout = weight.shape
+    cin_p, cout_p = _pad16(cin), _pad16(cout)
+    if cin_p != cin:
+        features = F.pad(features, (0, cin_p - cin))
+    if cin_p != cin or cout_p != cout:
+        weight = F.pad(weight, (0, cout_p - cout, 0, cin_p - cin))
+    out = _SparseConvFn.apply(features, weight, rb, rb_t, reverse_taps)
+    if cout_p != cout:
+        out = out[:, :cout]
+    return out
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, idx, csr):
+        ops = backend.raw()
+        ctx.save_for_backward(idx)
+        ctx.csr = csr
+        ctx.n_rows = table.shape[0]
+        return ops.gather_rows(table.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops = backend.raw()
+        (idx,) = ctx.saved_tensors
+        return ops.scatter_rows(dout.contiguous(), idx, ctx.n_rows, ctx.csr), None, None
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor, csr=None) -> torch.Tensor:
+    """table[idx] with idx<0 -> zero row (reference: ``voxel_features.features[pc_voxel_id]``, model.py:153,359,394).
+    ``csr`` = (order, starts) of points grouped by row, if the caller already has it (voxelize returns it)."""
+    return _GatherRowsFn.apply(table, idx, csr)
+
+
+class _SegmentedMaxpoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, values, begin, end):
+        ops = backend.raw()
+        pooled, argmax = ops.segmented_maxpool_fwd(values.contiguous(), begin, end)
+        ctx.save_for_backward(argmax)
+        ctx.M = values.shape[0]
+        ctx.mark_non_differentiable(argmax)
+        return pooled, argmax
+
+    @staticmethod
+    def backward(ctx, dpooled, _dargmax):
+        ops = backend.raw()
+        (argmax,) = ctx.saved_tensors
+        return ops.segmented_maxpool_bwd(dpooled.contiguous(), argmax, ctx.M), None, None
+
+
+def segmented_maxpool(values, begin, end):
+    return _SegmentedMaxpoolFn.apply(values, begin, end)

@@ -1,0 +1,424 @@
+"""Raw (no autograd) HIP operators: torch CUDA tensors in/out, every computation inside libgpn_hip.so.
+
+PyTorch is used here only for device memory (caching allocator) and the current HIP stream.  Every function
+raises if given non-CUDA tensors — there is no CPU path in the product (the CPU oracle lives in ``oracle/``
+and is test infrastructure).
+"""
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _C
+from ._C import check, f32, host_f32x3, host_i32x3, i32, i64, ptr, szt
+
+TILE_ROWS = 32
+PACK_TRANSPOSE = 1
+PACK_REVERSE = 2
+name = "hip"
+
+
+def _stream():
+    return _C.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _C.GpnError("gapartnet_amd HIP operators need CUDA(HIP) tensors; got a CPU tensor "
+                              "(there is no CPU fallback in the product path)")
+        dev = t.device
+    return dev
+
+
+def _c(t, dtype):
+    if t is None:
+        return None
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+
+
+def n_tiles(n):
+    return (int(n) + TILE_ROWS - 1) // TILE_ROWS
+
+
+@dataclass
+class Rulebook:
+    """K pair lists ordered by (tap, dst) + per-32-row tile offsets (see include/gpn.h)."""
+    pair_src: torch.Tensor
+    pair_dst: torch.Tensor
+    tile_off: torch.Tensor
+    K: int
+    n_src: int
+    n_dst: int
+    num_pairs: torch.Tensor  # 0-dim int64 on device (no host sync)
+
+    def pairs_host(self) -> int:
+        return int(self.num_pairs.item())
+
+
+# ---------------------------------------------------------------------------------------------------- V
+def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_size, grid_dims, want_csr=False):
+    """Kernel V. Returns (voxel_feats [V,C], voxel_coords [V,3] i32, voxel_seg [V] i32, pc_voxel_id [M] i32
+    [, point_order [M] i32, voxel_point_start [V+1] i32]).  One host sync (number of voxels)."""
+    dev = _dev(points, feats, seg_offsets)
+    points, feats = _c(points, torch.float32), _c(feats, torch.float32)
+    seg_offsets = _c(seg_offsets, torch.int64)
+    M, C, S = points.shape[0], feats.shape[1], seg_offsets.shape[0] - 1
+    rmin = _c(seg_range_min.reshape(-1, 3).expand(S, 3), torch.float32)
+    rmax = _c(seg_range_max.reshape(-1, 3).expand(S, 3), torch.float32)
+    vf = torch.empty((M, C), dtype=torch.float32, device=dev)
+    vc = torch.empty((M, 3), dtype=torch.int32, device=dev)
+    vseg = torch.empty((M,), dtype=torch.int32, device=dev)
+    pid = torch.empty((M,), dtype=torch.int32, device=dev)
+    nv = torch.zeros((1,), dtype=torch.int64, device=dev)
+    order = torch.empty((M,), dtype=torch.int32, device=dev) if want_csr else None
+    vstart = torch.empty((M + 1,), dtype=torch.int32, device=dev) if want_csr else None
+    L = _C.lib()
+    ws = _ws(L.gpn_voxelize_ws_bytes(i64(M), i32(C)), dev)
+    check(L.gpn_voxelize_ex(ptr(points), ptr(feats), ptr(seg_offsets), ptr(rmin), ptr(rmax), i64(M), i32(C),
+                            i64(S), host_f32x3(voxel_size), host_i32x3(grid_dims), ptr(vf), ptr(vc), ptr(vseg),
+                            ptr(pid), ptr(nv), ptr(order), ptr(vstart), ptr(ws), szt(ws.numel()), _stream()),
+          "gpn_voxelize")
+    V = int(nv.item())
+    out = (vf[:V], vc[:V], vseg[:V], pid)
+    if want_csr:
+        out = out + (order, vstart[:V + 1])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- K
+def rulebook_subm3(indices, spatial_shape) -> Rulebook:
+    dev = _dev(indices)
+    indices = _c(indices, torch.int32)
+    N = indices.shape[0]
+    cap = max(27 * N, 1)
+    src = torch.empty((cap,), dtype=torch.int32, device=dev)
+    dst = torch.empty((cap,), dtype=torch.int32, device=dev)
+    toff = torch.empty((27, n_tiles(N) + 1), dtype=torch.int32, device=dev)
+    npairs = torch.zeros((1,), dtype=torch.int64, device=dev)
+    L = _C.lib()
+    ws = _ws(L.gpn_rulebook_subm3_ws_bytes(i64(N)), dev)
+    check(L.gpn_rulebook_subm3(ptr(indices), i64(N), host_i32x3(spatial_shape), ptr(src), ptr(dst), ptr(toff),
+                               ptr(npairs), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_subm3")
+    return Rulebook(src, dst, toff, 27, N, N, npairs[0])
+
+
+def rulebook_down(indices, spatial_shape, batch_size):
+    """Returns (out_indices [No,4] i32, out_shape, rb_fwd (dst=coarse), rb_bwd (dst=fine)). One host sync."""
+    dev = _dev(indices)
+    indices = _c(indices, torch.int32)
+    N = indices.shape[0]
+    out_idx = torch.empty((max(N, 1), 4), dtype=torch.int32, device=dev)
+    f2c = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
+    tap = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
+    nout = torch.zeros((1,), dtype=torch.int64, device=dev)
+    L = _C.lib()
+    ws = _ws(L.gpn_rulebook_down_ws_bytes(i64(N)), dev)
+    check(L.gpn_rulebook_down(ptr(indices), i64(N), i64(batch_size), host_i32x3(spatial_shape), ptr(out_idx),
+                              ptr(f2c), ptr(tap), ptr(nout), ptr(ws), szt(ws.numel()), _stream()),
+          "gpn_rulebook_down")
+    No = int(nout.item())
+    cap = max(N, 1)
+    fs = torch.empty((cap,), dtype=torch.int32, device=dev)
+    fd = torch.empty((cap,), dtype=torch.int32, device=dev)
+    bs = torch.empty((cap,), dtype=torch.int32, device=dev)
+    bd = torch.empty((cap,), dtype=torch.int32, device=dev)
+    ft = torch.empty((8, n_tiles(No) + 1), dtype=torch.int32, device=dev)
+    bt = torch.empty((8, n_tiles(N) + 1), dtype=torch.int32, device=dev)
+    npairs = torch.zeros((1,), dtype=torch.int64, device=dev)
+    ws = _ws(L.gpn_rulebook_down_lists_ws_bytes(i64(N), i64(No)), dev)
+    check(L.gpn_rulebook_down_lists(ptr(f2c), ptr(tap), i64(N), i64(No), ptr(fs), ptr(fd), ptr(ft), ptr(bs),
+                                    ptr(bd), ptr(bt), ptr(npairs), ptr(ws), szt(ws.numel()), _stream()),
+          "gpn_rulebook_down_lists")
+    out_shape = [int(s) // 2 for s in spatial_shape]
+    rb_fwd = Rulebook(fs, fd, ft, 8, N, No, npairs[0])
+    rb_bwd = Rulebook(bs, bd, bt, 8, No, N, npairs[0])
+    return out_idx[:No], out_shape, rb_fwd, rb_bwd
+
+
+# ---------------------------------------------------------------------------------------------------- C
+def pack_weights(W, flags):
+    dev = _dev(W)
+    W = _c(W, torch.float32)
+    K, cin, cout = W.shape
+    packed = torch.empty((K * cin * cout,), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_spconv_pack_weights(ptr(W), i32(K), i32(cin), i32(cout), i32(flags), ptr(packed), _stream()),
+          "gpn_spconv_pack_weights")
+    return packed
+
+
+def _conv_packed(features, packed, rb: Rulebook, cin, cout):
+    dev = _dev(features)
+    features = _c(features, torch.float32)
+    assert features.shape[0] == rb.n_src and features.shape[1] == cin, (features.shape, rb.n_src, cin)
+    out = torch.empty((rb.n_dst, cout), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_spconv_fwd(ptr(features), ptr(packed), ptr(rb.pair_src), ptr(rb.pair_dst), ptr(rb.tile_off),
+                                  i32(rb.K), i64(rb.n_dst), i32(cin), i32(cout), ptr(out), _stream()),
+          "gpn_spconv_fwd")
+    return out
+
+
+def conv_fwd(features, W, rb: Rulebook):
+    """out[dst] = sum_k in[src] @ W[k];  W canonical [K, cin, cout] (both multiples of 16)."""
+    K, cin, cout = W.shape
+    return _conv_packed(features, pack_weights(W, 0), rb, cin, cout)
+
+
+def conv_dgrad(dout, W, rb: Rulebook, rb_t: Rulebook, reverse_taps: bool):
+    """din[src] = sum_k dout[dst] @ W[k]^T, computed as a forward conv over the transposed rulebook rb_t."""
+    K, cin, cout = W.shape
+    flags = PACK_TRANSPOSE | (PACK_REVERSE if reverse_taps else 0)
+    return _conv_packed(dout, pack_weights(W, flags), rb_t, cout, cin)
+
+
+def conv_wgrad(features, dout, rb: Rulebook):
+    dev = _dev(features, dout)
+    features, dout = _c(features, torch.float32), _c(dout, torch.float32)
+    cin, cout = features.shape[1], dout.shape[1]
+    dW = torch.empty((rb.K, cin, cout), dtype=torch.float32, device=dev)
+    L = _C.lib()
+    ws = _ws(L.gpn_spconv_wgrad_ws_bytes(i32(rb.K), i32(cin), i32(cout), i64(rb.n_dst)), dev)
+    check(L.gpn_spconv_wgrad(ptr(features), ptr(dout), ptr(rb.pair_src), ptr(rb.pair_dst), ptr(rb.tile_off),
+                             i32(rb.K), i64(rb.n_dst), i32(cin), i32(cout), ptr(dW), ptr(ws), szt(ws.numel()),
+                             _stream()), "gpn_spconv_wgrad")
+    return dW
+
+
+# ---------------------------------------------------------------------------------------------------- G
+def gather_rows(table, idx):
+    dev = _dev(table, idx)
+    table, idx = _c(table, torch.float32), _c(idx, torch.int32)
+    out = torch.empty((idx.shape[0], table.shape[1]), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_gather_rows(ptr(table), ptr(idx), i64(idx.shape[0]), i32(table.shape[1]), ptr(out), _stream()),
+          "gpn_gather_rows")
+    return out
+
+
+def rows_csr(idx, n_rows):
+    """CSR of positions grouped by row id (stable): (order [n] i32 with idx<0 entries last, starts [n_rows+1] i32)."""
+    idx = idx.to(torch.int64)
+    key = torch.where(idx >= 0, idx, torch.full_like(idx, n_rows))
+    _, order = torch.sort(key, stable=True)
+    counts = torch.bincount(key, minlength=n_rows + 1)[:n_rows]
+    starts = torch.zeros((n_rows + 1,), dtype=torch.int32, device=idx.device)
+    starts[1:] = counts.cumsum(0).to(torch.int32)
+    return order.to(torch.int32), starts
+
+
+def scatter_rows(dout, idx, n_rows, csr=None):
+    """transpose of gather_rows: dtable[r] = ordered sum of dout[i] over idx[i] == r."""
+    dev = _dev(dout, idx)
+    dout = _c(dout, torch.float32)
+    order, starts = csr if csr is not None else rows_csr(idx, n_rows)
+    out = torch.empty((n_rows, dout.shape[1]), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_scatter_rows_csr(ptr(dout), ptr(_c(order, torch.int32)), ptr(_c(starts, torch.int32)),
+                                        i64(n_rows), i32(dout.shape[1]), ptr(out), _stream()),
+          "gpn_scatter_rows_csr")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- B/L
+def ball_query(points, query, batch_indices, batch_offsets, radius, num_samples, point_labels=None,
+               query_labels=None):
+    dev = _dev(points, query)
+    points, query = _c(points, torch.float32), _c(query, torch.float32)
+    bi, bo = _c(batch_indices, torch.int32), _c(batch_offsets, torch.int32)
+    pl, ql = _c(point_labels, torch.int32), _c(query_labels, torch.int32)
+    Q, K = query.shape[0], int(num_samples)
+    idx = torch.empty((Q, K), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((Q,), dtype=torch.int32, device=dev)
+    check(_C.lib().gpn_ball_query(ptr(points), ptr(query), ptr(bi), ptr(bo), ptr(pl), ptr(ql), i64(points.shape[0]),
+                                  i64(Q), i64(bo.shape[0] - 1), f32(radius), i32(K), ptr(idx), ptr(cnt), _stream()),
+          "gpn_ball_query")
+    return idx, cnt
+
+
+def ccl(begin_end, edges, compacted=False):
+    dev = _dev(begin_end, edges)
+    be, edges = _c(begin_end, torch.int32), _c(edges, torch.int32)
+    Q = be.shape[0] // 2
+    labels = torch.empty((Q,), dtype=torch.int32, device=dev)
+    L = _C.lib()
+    ws = _ws(L.gpn_ccl_ws_bytes(i64(Q)), dev)
+    check(L.gpn_ccl(ptr(be), ptr(edges), i64(Q), i64(edges.shape[0]), i32(1 if compacted else 0), ptr(labels),
+                    ptr(ws), szt(ws.numel()), _stream()), "gpn_ccl")
+    return labels
+
+
+# ---------------------------------------------------------------------------------------------------- R/I/N
+_MODES = {"sum": 0, "min": 1, "max": 2}
+
+
+def segmented_reduce(values, begin, end, mode):
+    dev = _dev(values, begin, end)
+    values, begin, end = _c(values, torch.float32), _c(begin, torch.int32), _c(end, torch.int32)
+    P, C = begin.shape[0], values.shape[1]
+    out = torch.empty((P, C), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_segmented_reduce(ptr(values), ptr(begin), ptr(end), i64(P), i32(C), i32(_MODES[mode]), ptr(out),
+                                        _stream()), "gpn_segmented_reduce")
+    return out
+
+
+def segmented_maxpool_fwd(values, begin, end):
+    dev = _dev(values, begin, end)
+    values, begin, end = _c(values, torch.float32), _c(begin, torch.int32), _c(end, torch.int32)
+    P, C = begin.shape[0], values.shape[1]
+    pooled = torch.empty((P, C), dtype=torch.float32, device=dev)
+    arg = torch.empty((P, C), dtype=torch.int32, device=dev)
+    check(_C.lib().gpn_segmented_maxpool_fwd(ptr(values), ptr(begin), ptr(end), i64(P), i32(C), ptr(pooled), ptr(arg),
+                                             _stream()), "gpn_segmented_maxpool_fwd")
+    return pooled, arg
+
+
+def segmented_maxpool_bwd(dpooled, argmax, M):
+    dev = _dev(dpooled, argmax)
+    dpooled, argmax = _c(dpooled, torch.float32), _c(argmax, torch.int32)
+    P, C = dpooled.shape
+    dv = torch.empty((M, C), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_segmented_maxpool_bwd(ptr(dpooled), ptr(argmax), i64(P), i32(C), i64(M), ptr(dv), _stream()),
+          "gpn_segmented_maxpool_bwd")
+    return dv
+
+
+def instance_iou(proposal_offsets, instance_labels, batch_indices, num_points_per_instance):
+    dev = _dev(proposal_offsets, instance_labels, batch_indices, num_points_per_instance)
+    po, il = _c(proposal_offsets, torch.int32), _c(instance_labels, torch.int32)
+    bi, npi = _c(batch_indices, torch.int32), _c(num_points_per_instance, torch.int32)
+    P, (B, I) = po.shape[0] - 1, npi.shape
+    out = torch.zeros((P, I), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_instance_iou(ptr(po), ptr(il), ptr(bi), ptr(npi), i64(P), i64(B), i32(I), ptr(out), _stream()),
+          "gpn_instance_iou")
+    return out
+
+
+def nms(ious, scores, threshold):
+    dev = _dev(ious, scores)
+    ious, scores = _c(ious, torch.float32), _c(scores, torch.float32)
+    P = scores.shape[0]
+    order = torch.sort(scores, descending=True, stable=True)[1].to(torch.int32)
+    keep = torch.empty((max(P, 1),), dtype=torch.int32, device=dev)
+    nk = torch.zeros((1,), dtype=torch.int32, device=dev)
+    L = _C.lib()
+    ws = _ws(L.gpn_nms_ws_bytes(i64(P)), dev)
+    check(L.gpn_nms(ptr(ious), ptr(order), i64(P), f32(threshold), ptr(keep), ptr(nk), ptr(ws), szt(ws.numel()),
+                    _stream()), "gpn_nms")
+    return keep[: int(nk.item())].to(torch.int64)
+
+
+# ---------------------------------------------------------------------------------------------------- F
+def pn2_ball_query(radius, nsample, xyz, new_xyz):
+    dev = _dev(xyz, new_xyz)
+    xyz, new_xyz = _c(xyz, torch.float32), _c(new_xyz, torch.float32)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.zeros((b, m, nsample), dtype=torch.int32, device=dev)
+    check(_C.lib().gpn_pn2_ball_query(i32(b), i32(n), i32(m), f32(radius), i32(nsample), ptr(new_xyz), ptr(xyz),
+                                      ptr(idx), _stream()), "gpn_pn2_ball_query")
+    return idx
+
+
+def pn2_group_points(points, idx):
+    dev = _dev(points, idx)
+    points, idx = _c(points, torch.float32), _c(idx, torch.int32)
+    b, c, n = points.shape
+    _, npts, ns = idx.shape
+    out = torch.empty((b, c, npts, ns), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_pn2_group_points(i32(b), i32(c), i32(n), i32(npts), i32(ns), ptr(points), ptr(idx), ptr(out),
+                                        _stream()), "gpn_pn2_group_points")
+    return out
+
+
+def pn2_group_points_grad(grad_out, idx, n):
+    dev = _dev(grad_out, idx)
+    grad_out, idx = _c(grad_out, torch.float32), _c(idx, torch.int32)
+    b, c, npts, ns = grad_out.shape
+    gp = torch.zeros((b, c, n), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_pn2_group_points_grad(i32(b), i32(c), i32(n), i32(npts), i32(ns), ptr(grad_out), ptr(idx),
+                                             ptr(gp), _stream()), "gpn_pn2_group_points_grad")
+    return gp
+
+
+def pn2_gather_points(points, idx):
+    dev = _dev(points, idx)
+    points, idx = _c(points, torch.float32), _c(idx, torch.int32)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_pn2_gather_points(i32(b), i32(c), i32(n), i32(m), ptr(points), ptr(idx), ptr(out), _stream()),
+          "gpn_pn2_gather_points")
+    return out
+
+
+def pn2_gather_points_grad(grad_out, idx, n):
+    dev = _dev(grad_out, idx)
+    grad_out, idx = _c(grad_out, torch.float32), _c(idx, torch.int32)
+    b, c, m = grad_out.shape
+    gp = torch.zeros((b, c, n), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_pn2_gather_points_grad(i32(b), i32(c), i32(n), i32(m), ptr(grad_out), ptr(idx), ptr(gp),
+                                              _stream()), "gpn_pn2_gather_points_grad")
+    return gp
+
+
+def pn2_furthest_point_sampling(xyz, npoint):
+    dev = _dev(xyz)
+    xyz = _c(xyz, torch.float32)
+    b, n, _ = xyz.shape
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device=dev)
+    idx = torch.zeros((b, npoint), dtype=torch.int32, device=dev)
+    check(_C.lib().gpn_pn2_furthest_point_sampling(i32(b), i32(n), i32(npoint), ptr(xyz), ptr(temp), ptr(idx), _stream()),
+          "gpn_pn2_furthest_point_sampling")
+    return idx
+
+
+def pn2_three_nn(unknown, known):
+    dev = _dev(unknown, known)
+    unknown, known = _c(unknown, torch.float32), _c(known, torch.float32)
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
+    check(_C.lib().gpn_pn2_three_nn(i32(b), i32(n), i32(m), ptr(unknown), ptr(known), ptr(d2), ptr(idx), _stream()),
+          "gpn_pn2_three_nn")
+    return d2, idx
+
+
+def pn2_knn(unknown, known, k):
+    dev = _dev(unknown, known)
+    unknown, known = _c(unknown, torch.float32), _c(known, torch.float32)
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = torch.empty((b, n, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((b, n, k), dtype=torch.int32, device=dev)
+    check(_C.lib().gpn_pn2_knn(i32(b), i32(n), i32(m), i32(k), ptr(unknown), ptr(known), ptr(d2), ptr(idx), _stream()),
+          "gpn_pn2_knn")
+    return d2, idx
+
+
+def pn2_three_interpolate(points, idx, weight):
+    dev = _dev(points, idx, weight)
+    points, idx, weight = _c(points, torch.float32), _c(idx, torch.int32), _c(weight, torch.float32)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_pn2_three_interpolate(i32(b), i32(c), i32(m), i32(n), ptr(points), ptr(idx), ptr(weight),
+                                             ptr(out), _stream()), "gpn_pn2_three_interpolate")
+    return out
+
+
+def pn2_three_interpolate_grad(grad_out, idx, weight, m):
+    dev = _dev(grad_out, idx, weight)
+    grad_out, idx, weight = _c(grad_out, torch.float32), _c(idx, torch.int32), _c(weight, torch.float32)
+    b, c, n = grad_out.shape
+    gp = torch.zeros((b, c, m), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_pn2_three_interpolate_grad(i32(b), i32(c), i32(n), i32(m), ptr(grad_out), ptr(idx),
+                                                  ptr(weight), ptr(gp), _stream()), "gpn_pn2_three_interpolate_grad")
+    return gp

@@ -1,0 +1,238 @@
+/*
+ * gpn.h — C-ABI of libgpn_hip.so: the MI355X (gfx950) implementation of the GAPartNet
+ * sparse-3D-conv perception hot path.
+ *
+ * Boundary contract:
+ *   - extern "C", plain pointers and sizes, no torch types.  Every pointer is a DEVICE pointer
+ *     unless the parameter name ends in `_host`.
+ *   - the caller allocates every output and the workspace (query `*_ws_bytes`); kernels never allocate.
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*).
+ *   - return value 0 = ok; otherwise an error code, message via gpn_last_error().  The library never
+ *     calls exit() (the vendored reference lib does: ball_query_gpu.cu:62-66) so DDP ranks survive.
+ *   - data-dependent sizes are written to a device counter; the caller sizes buffers by the stated
+ *     upper bound and reads the counter when it needs the value on the host.
+ *
+ * Each entry point cites the reference interface it replaces (file:line relative to the
+ * PKU-EPIC/GAPartNet tree).
+ */
+#ifndef GPN_H
+#define GPN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gpn_stream_t; /* hipStream_t */
+
+#define GPN_OK 0
+#define GPN_ERR_ARG 1      /* bad argument (null pointer, unsupported size) */
+#define GPN_ERR_WS 2       /* workspace too small */
+#define GPN_ERR_HIP 3      /* a HIP runtime call / kernel launch failed */
+
+const char* gpn_last_error(void);
+int gpn_version(void);
+/* number of exported compute entry points and their names (used by the symbol test) */
+int gpn_num_entry_points(void);
+const char* gpn_entry_point_name(int i);
+
+/* ---- optional in-library kernel timing (hipEvent pairs around launches; used by bench.py) ------- */
+/* kernel ids for gpn_prof_get */
+enum {
+  GPN_K_SPCONV_FWD = 0, /* fused gather-MFMA-scatter conv (forward and dgrad launches) */
+  GPN_K_SPCONV_WGRAD = 1,
+  GPN_K_VOXELIZE = 2,
+  GPN_K_RULEBOOK = 3,
+  GPN_K_BALL_QUERY = 4,
+  GPN_K_CCL = 5,
+  GPN_K_COUNT = 6
+};
+int gpn_prof_enable(int on);
+int gpn_prof_reset(void);
+/* synchronises the recorded events; returns launches, total milliseconds, algorithmic flops and bytes */
+int gpn_prof_get(int kernel_id, int64_t* launches_host, double* ms_host, double* flops_host,
+                 double* bytes_host);
+
+/* ================================================================================================
+ * V — voxelize.   replaces epic_ops.voxelize.voxelize (call sites dataset/gapartnet.py:188-195,
+ * network/grouping_utils.py:93-101).
+ *   points [M,3] f32, feats [M,C] f32, seg_offsets [S+1] i64 (CSR over points),
+ *   seg_range_min/max [S,3] f32 (per segment; the reference passes one range per call — the
+ *   host wrapper broadcasts it), voxel_size_host[3], grid_dims_host[3] = cells per axis used to
+ *   linearise keys (points whose cell index >= grid_dims are dropped like out-of-range points).
+ *   coord = floor((p - range_min) / voxel_size) evaluated in fp32 without contraction.
+ * outputs (capacity M rows each): voxel_feats [V,C] (mean, summed in ascending point order),
+ *   voxel_coords [V,3] i32, voxel_seg [V] i32, pc_voxel_id [M] i32 (-1 = dropped),
+ *   num_voxels [1] i64.  Voxels are ordered by ascending (segment,x,y,z).
+ * ================================================================================================ */
+size_t gpn_voxelize_ws_bytes(int64_t M, int C);
+int gpn_voxelize(const float* points, const float* feats, const int64_t* seg_offsets,
+                 const float* seg_range_min, const float* seg_range_max, int64_t M, int C, int64_t S,
+                 const float* voxel_size_host, const int32_t* grid_dims_host, float* voxel_feats,
+                 int32_t* voxel_coords, int32_t* voxel_seg, int32_t* pc_voxel_id, int64_t* num_voxels,
+                 void* ws, size_t ws_bytes, gpn_stream_t stream);
+
+/* same, plus the CSR of points grouped by voxel: point_order [M] i32 (point ids sorted by voxel,
+ * ascending point id inside a voxel; dropped points last) and voxel_point_start [M+1] i32 (first V+1
+ * entries valid).  Either may be NULL.  Feeds gpn_scatter_rows_csr (the gather's transpose). */
+int gpn_voxelize_ex(const float* points, const float* feats, const int64_t* seg_offsets,
+                    const float* seg_range_min, const float* seg_range_max, int64_t M, int C, int64_t S,
+                    const float* voxel_size_host, const int32_t* grid_dims_host, float* voxel_feats,
+                    int32_t* voxel_coords, int32_t* voxel_seg, int32_t* pc_voxel_id, int64_t* num_voxels,
+                    int32_t* point_order, int32_t* voxel_point_start, void* ws, size_t ws_bytes,
+                    gpn_stream_t stream);
+
+/* ================================================================================================
+ * K1/K2 — rulebooks.   replace the indice-pair construction inside spconv.pytorch.SubMConv3d /
+ * SparseConv3d / SparseInverseConv3d (call sites network/backbone.py:19-36,74-90,149-152).
+ *
+ * A rulebook is a set of K pair lists, stored flat and ordered by (tap k, dst row):
+ *   pair_src [P] i32, pair_dst [P] i32, tile_off [K, n_tiles+1] i32 where
+ *   tile_off[k][t] = index of the first pair of tap k whose dst >= t*GPN_TILE_ROWS
+ *   (so tile_off[k][0] is the start of list k and tile_off[k][n_tiles] its end).
+ * Each dst row appears at most once per tap.  n_tiles = ceil(n_dst / GPN_TILE_ROWS).
+ * ================================================================================================ */
+#define GPN_TILE_ROWS 32
+
+/* SubM k=3 pad=1: indices [N,4] i32 (batch,x,y,z); tap = (dx+1)*9+(dy+1)*3+(dz+1); src = row at
+ * coord(dst)+delta.  pair arrays need capacity 27*N.  num_pairs [1] i64. */
+size_t gpn_rulebook_subm3_ws_bytes(int64_t N);
+int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32_t* spatial_shape_host,
+                       int32_t* pair_src, int32_t* pair_dst, int32_t* tile_off, int64_t* num_pairs,
+                       void* ws, size_t ws_bytes, gpn_stream_t stream);
+
+/* k=2 stride=2 down-conv.  out shape = floor(D/2) per axis; inputs mapping outside are dropped.
+ * Produces the coarse index set (ascending linear key; capacity N rows), fine_to_coarse [N] i32
+ * (-1 = dropped), tap [N] i32 = (x&1)*4+(y&1)*2+(z&1), num_out [1] i64.
+ * The two pair-list views (dst = coarse for the down conv / dgrad of the inverse conv;
+ * dst = fine for the inverse conv / dgrad of the down conv) are then built with
+ * gpn_rulebook_down_lists once num_out is known on the host. */
+size_t gpn_rulebook_down_ws_bytes(int64_t N);
+int gpn_rulebook_down(const int32_t* indices, int64_t N, int64_t batch_size,
+                      const int32_t* spatial_shape_host, int32_t* out_indices, int32_t* fine_to_coarse, int32_t* tap, int64_t* num_out,
+                      void* ws, size_t ws_bytes, gpn_stream_t stream);
+size_t gpn_rulebook_down_lists_ws_bytes(int64_t N, int64_t n_out);
+int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N,
+                            int64_t n_out,
+                            int32_t* fwd_src, int32_t* fwd_dst, int32_t* fwd_tile_off, /* dst = coarse, cap N */
+                            int32_t* bwd_src, int32_t* bwd_dst, int32_t* bwd_tile_off, /* dst = fine, cap N */
+                            int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream);
+
+/* ================================================================================================
+ * C — sparse convolution.  replaces the conv forward/backward inside spconv (network/backbone.py).
+ * weights: canonical layout W [K, Cin, Cout] row-major fp32 (tap-major).
+ * gpn_spconv_pack_weights writes the MFMA-fragment layout the kernels read:
+ *   flags bit0 = transpose (use W_k^T: Cin/Cout swap), bit1 = reverse taps (k -> K-1-k); dgrad of
+ *   a SubM conv uses both, dgrad of down/inverse convs uses transpose only.
+ *   cin/cout here are the dims of the *packed* operator (after the optional transpose); both must be
+ *   multiples of 16.  packed size = K*cin*cout floats.
+ * gpn_spconv_fwd: out[dst] = sum_k W_k^T-applied in[src]  (out is fully overwritten; rows with no
+ *   pair get zeros).  in [n_src, cin], out [n_dst, cout].
+ * gpn_spconv_wgrad: dW[k] = sum_{pairs of k} in[src]^T (x) dout[dst]  -> dW [K, cin, cout] canonical.
+ * ================================================================================================ */
+#define GPN_PACK_TRANSPOSE 1
+#define GPN_PACK_REVERSE 2
+int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cout_w, int flags, float* packed,
+                            gpn_stream_t stream);
+int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* pair_src,
+                   const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
+                   int cout, float* out, gpn_stream_t stream);
+size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst);
+int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
+                     const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
+                     int cout, float* dW, void* ws, size_t ws_bytes, gpn_stream_t stream);
+
+/* G — row gather voxels->points and its deterministic transpose (model.py:153,359,394).
+ * out[i] = idx[i] >= 0 ? table[idx[i]] : 0.   bwd: dtable[r] = sum_{i: idx[i]==r} dout[i] using the
+ * CSR (order,starts) of points grouped by row (ascending point order inside a row). */
+int gpn_gather_rows(const float* table, const int32_t* idx, int64_t n, int C, float* out,
+                    gpn_stream_t stream);
+int gpn_scatter_rows_csr(const float* dout, const int32_t* order, const int32_t* starts,
+                         int64_t n_rows, int C, float* dtable, gpn_stream_t stream);
+
+/* ================================================================================================
+ * B — ball query.  replaces epic_ops.ball_query.ball_query (network/grouping_utils.py:119-128).
+ * points [Np,3], query [Q,3], batch_indices [Q] i32, batch_offsets [S+1] i32 (CSR over points),
+ * point_labels [Np] / query_labels [Q] i32 (both may be NULL = no label filter).
+ * hit: same segment, equal label, d2 < radius^2 (strict; d2 = (dx*dx+dy*dy)+dz*dz, fp32, no fma),
+ * first K hits in ascending point index.  indices [Q,K] i32 (-1 padded), count [Q] i32.
+ * ================================================================================================ */
+int gpn_ball_query(const float* points, const float* query, const int32_t* batch_indices,
+                   const int32_t* batch_offsets, const int32_t* point_labels,
+                   const int32_t* query_labels, int64_t Np, int64_t Q, int64_t S, float radius, int K,
+                   int32_t* indices, int32_t* count, gpn_stream_t stream);
+
+/* L — connected components.  replaces epic_ops.ccl.connected_components_labeling
+ * (network/grouping_utils.py:135-137).  begin_end [2Q] i32 interleaved (begin,end) into edges [E];
+ * edges are treated as undirected; labels [Q] i32 = minimum vertex index of the component.
+ * compacted != 0 -> labels renumbered 0..n_comp-1 in order of that minimum (needs ws). */
+size_t gpn_ccl_ws_bytes(int64_t Q);
+int gpn_ccl(const int32_t* begin_end, const int32_t* edges, int64_t Q, int64_t E, int compacted,
+            int32_t* labels, void* ws, size_t ws_bytes, gpn_stream_t stream);
+
+/* R — segmented reductions.  replace epic_ops.reduce.segmented_reduce (grouping_utils.py:59-70) and
+ * epic_ops.reduce.segmented_maxpool (model.py:360-362).  values [M,C], begin/end [P] i32.
+ * mode 0=sum 1=min 2=max; summation in ascending row order. empty segment -> 0.
+ * maxpool: ties -> lowest row; argmax [P,C] i32 (-1 for empty). bwd scatters dpooled to drows. */
+int gpn_segmented_reduce(const float* values, const int32_t* begin, const int32_t* end, int64_t P,
+                         int C, int mode, float* out, gpn_stream_t stream);
+int gpn_segmented_maxpool_fwd(const float* values, const int32_t* begin, const int32_t* end, int64_t P,
+                              int C, float* pooled, int32_t* argmax, gpn_stream_t stream);
+int gpn_segmented_maxpool_bwd(const float* dpooled, const int32_t* argmax, int64_t P, int C, int64_t M,
+                              float* dvalues, gpn_stream_t stream);
+
+/* I — instance IoU.  replaces epic_ops.iou.batch_instance_seg_iou (model.py:373-378).
+ * proposal_offsets [P+1] i32, instance_labels [M] i32, batch_indices [M] i32,
+ * num_points_per_instance [B,I] i32 -> ious [P,I] f32. */
+int gpn_instance_iou(const int32_t* proposal_offsets, const int32_t* instance_labels,
+                     const int32_t* batch_indices, const int32_t* num_points_per_instance, int64_t P,
+                     int64_t B, int I, float* ious, gpn_stream_t stream);
+
+/* N — greedy NMS on a precomputed IoU matrix.  replaces epic_ops.nms.nms (grouping_utils.py:244).
+ * ious [P,P] f32, order [P] i32 = proposal ids by descending score (ties -> lower id; the host
+ * wrapper sorts).  keep [P] i32 receives kept ids in visiting order, num_keep [1] i32. */
+size_t gpn_nms_ws_bytes(int64_t P);
+int gpn_nms(const float* ious, const int32_t* order, int64_t P, float threshold, int32_t* keep,
+            int32_t* num_keep, void* ws, size_t ws_bytes, gpn_stream_t stream);
+
+/* ================================================================================================
+ * F — PointNet++ family.  replace the pybind module pointnet2_cuda
+ * (dataset/process_tools/utils/pointnet_lib/src/pointnet2_api.cpp:10-25); argument order and meaning
+ * follow the vendored wrappers (ball_query.cpp:14-25, sampling.cpp, interpolate.cpp, group_points.cpp).
+ * ================================================================================================ */
+/* ball_query_gpu.cu:9-45 — first nsample (d2<r2) in index order; row prefilled with first hit;
+ * rows without hits are left untouched. */
+int gpn_pn2_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz,
+                       const float* xyz, int32_t* idx, gpn_stream_t stream);
+/* group_points_gpu.cu:47-66 / :8-25 */
+int gpn_pn2_group_points(int b, int c, int n, int npoints, int nsample, const float* points,
+                         const int32_t* idx, float* out, gpn_stream_t stream);
+int gpn_pn2_group_points_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                              const int32_t* idx, float* grad_points, gpn_stream_t stream);
+/* sampling_gpu.cu:8-24 / :46-63 */
+int gpn_pn2_gather_points(int b, int c, int n, int npoints, const float* points, const int32_t* idx,
+                          float* out, gpn_stream_t stream);
+int gpn_pn2_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out,
+                               const int32_t* idx, float* grad_points, gpn_stream_t stream);
+/* sampling_gpu.cu:93-209 — start index 0; temp [b,n] must be pre-filled with 1e10 by the caller
+ * (pointnet2_utils.py:27); ties resolved as the reference's block reduction does for its block size
+ * opt_n_threads(n) (cuda_utils.h:10-14). */
+int gpn_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
+                                    int32_t* idxs, gpn_stream_t stream);
+/* interpolate_gpu.cu:81-124 / :9-57 / :149-169 / :192-214 */
+int gpn_pn2_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                     int32_t* idx, gpn_stream_t stream);
+int gpn_pn2_knn(int b, int n, int m, int k, const float* unknown, const float* known, float* dist2,
+                int32_t* idx, gpn_stream_t stream);
+int gpn_pn2_three_interpolate(int b, int c, int m, int n, const float* points, const int32_t* idx,
+                              const float* weight, float* out, gpn_stream_t stream);
+int gpn_pn2_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
+                                   const int32_t* idx, const float* weight, float* grad_points,
+                                   gpn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPN_H */

@@ -1,0 +1,606 @@
+/*
+ * gpn_oracle.c — CPU restatement (TEST INFRASTRUCTURE, not product code) of the algorithms on the
+ * GAPartNet sparse-conv perception hot path.
+ *
+ * PARITY STATUS: the arithmetic of spconv / epic_ops is third-party, un-vendored and un-pinned in the
+ * reference tree, so for V, K1, K2, C, B, L, R, I, N this file restates the operator
+ * contracts derived from the reference's call sites (cited per function) — "parity unpinned" against
+ * the reference binaries; it is pinned instead against independent oracles in tests/ (torch dense
+ * conv3d, numpy unique, scipy connected_components, torch.cdist, torch.segment_reduce).  The
+ * PointNet++ family (F) follows the vendored CUDA sources line by line and is cited per kernel.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no fused multiply-add, so distance and
+ * coordinate arithmetic is bit-identical to the HIP kernels, which use __fmul_rn/__fadd_rn).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TILE_ROWS 32
+
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  uint64_t key;
+  int64_t idx;
+} key_idx_t;
+
+static int cmp_key_idx(const void* a, const void* b) {
+  const key_idx_t* x = (const key_idx_t*)a;
+  const key_idx_t* y = (const key_idx_t*)b;
+  if (x->key < y->key) return -1;
+  if (x->key > y->key) return 1;
+  if (x->idx < y->idx) return -1;
+  if (x->idx > y->idx) return 1;
+  return 0;
+}
+
+/* V — epic_ops.voxelize contract (dataset/gapartnet.py:188-195, grouping_utils.py:93-101;
+ * SURVEY.md Appendix A.1).  Returns the number of voxels. */
+int64_t orc_voxelize(const float* points, const float* feats, const int64_t* seg_offsets,
+                     const float* seg_range_min, const float* seg_range_max, int64_t M, int C, int64_t S,
+                     const float* voxel_size, const int32_t* grid_dims, float* voxel_feats,
+                     int32_t* voxel_coords, int32_t* voxel_seg, int32_t* pc_voxel_id) {
+  key_idx_t* ki = (key_idx_t*)malloc(sizeof(key_idx_t) * (size_t)(M > 0 ? M : 1));
+  const uint64_t D0 = (uint64_t)grid_dims[0], D1 = (uint64_t)grid_dims[1], D2 = (uint64_t)grid_dims[2];
+  for (int64_t i = 0; i < M; ++i) { ki[i].key = UINT64_MAX; ki[i].idx = i; }
+  for (int64_t s = 0; s < S; ++s) {
+    for (int64_t i = seg_offsets[s]; i < seg_offsets[s + 1]; ++i) {
+      uint64_t key = UINT64_MAX;
+      int32_t c[3];
+      int ok = 1;
+      for (int a = 0; a < 3; ++a) {
+        float p = points[i * 3 + a];
+        float mn = seg_range_min[s * 3 + a], mx = seg_range_max[s * 3 + a];
+        if (!(p >= mn && p < mx)) { ok = 0; break; }
+        float q = (p - mn) / voxel_size[a];
+        int32_t ci = (int32_t)floorf(q);
+        if (ci < 0 || ci >= grid_dims[a]) { ok = 0; break; }
+        c[a] = ci;
+      }
+      if (ok) key = (((uint64_t)s * D0 + (uint64_t)c[0]) * D1 + (uint64_t)c[1]) * D2 + (uint64_t)c[2];
+      ki[i].key = key;
+      ki[i].idx = i;
+    }
+  }
+  qsort(ki, (size_t)M, sizeof(key_idx_t), cmp_key_idx);
+  int64_t V = 0;
+  int64_t i = 0;
+  for (int64_t j = 0; j < M; ++j) pc_voxel_id[j] = -1;
+  while (i < M && ki[i].key != UINT64_MAX) {
+    int64_t j = i;
+    uint64_t key = ki[i].key;
+    while (j < M && ki[j].key == key) ++j;
+    /* mean in ascending point order */
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+      for (int64_t t = i; t < j; ++t) acc = acc + feats[ki[t].idx * C + c];
+      voxel_feats[V * C + c] = acc / (float)(j - i);
+    }
+    uint64_t r = key;
+    voxel_coords[V * 3 + 2] = (int32_t)(r % D2); r /= D2;
+    voxel_coords[V * 3 + 1] = (int32_t)(r % D1); r /= D1;
+    voxel_coords[V * 3 + 0] = (int32_t)(r % D0); r /= D0;
+    voxel_seg[V] = (int32_t)r;
+    for (int64_t t = i; t < j; ++t) pc_voxel_id[ki[t].idx] = (int32_t)V;
+    ++V;
+    i = j;
+  }
+  free(ki);
+  return V;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+static uint64_t lin_key(const int32_t* idx4, const int32_t* shape) {
+  return (((uint64_t)idx4[0] * (uint64_t)shape[0] + (uint64_t)idx4[1]) * (uint64_t)shape[1] +
+          (uint64_t)idx4[2]) * (uint64_t)shape[2] + (uint64_t)idx4[3];
+}
+
+static int64_t find_key(const key_idx_t* sorted, int64_t n, uint64_t key) {
+  int64_t lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (sorted[mid].key == key) return sorted[mid].idx;
+    if (sorted[mid].key < key) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+
+/* turn a [K][n_dst] table of src rows (-1 = none) into pair lists ordered by (k, dst) + tile offsets */
+static int64_t table_to_lists(const int32_t* table, int K, int64_t n_dst, int32_t* pair_src,
+                              int32_t* pair_dst, int32_t* tile_off) {
+  int64_t n_tiles = (n_dst + TILE_ROWS - 1) / TILE_ROWS;
+  int64_t P = 0;
+  for (int k = 0; k < K; ++k) {
+    for (int64_t o = 0; o < n_dst; ++o) {
+      if (o % TILE_ROWS == 0) tile_off[k * (n_tiles + 1) + o / TILE_ROWS] = (int32_t)P;
+      int32_t s = table[(int64_t)k * n_dst + o];
+      if (s >= 0) { pair_src[P] = s; pair_dst[P] = (int32_t)o; ++P; }
+    }
+    tile_off[k * (n_tiles + 1) + n_tiles] = (int32_t)P;
+  }
+  return P;
+}
+
+/* K1 — SubMConv3d(k=3,pad=1) rulebook (backbone.py:25-28,33-36,149-152). */
+int64_t orc_rulebook_subm3(const int32_t* indices, int64_t N, const int32_t* shape, int32_t* pair_src,
+                           int32_t* pair_dst, int32_t* tile_off) {
+  key_idx_t* ki = (key_idx_t*)malloc(sizeof(key_idx_t) * (size_t)(N > 0 ? N : 1));
+  for (int64_t i = 0; i < N; ++i) { ki[i].key = lin_key(indices + i * 4, shape); ki[i].idx = i; }
+  qsort(ki, (size_t)N, sizeof(key_idx_t), cmp_key_idx);
+  int32_t* table = (int32_t*)malloc(sizeof(int32_t) * (size_t)(27 * (N > 0 ? N : 1)));
+  for (int k = 0; k < 27; ++k) {
+    int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
+    for (int64_t o = 0; o < N; ++o) {
+      int32_t q[4] = {indices[o * 4], indices[o * 4 + 1] + dx, indices[o * 4 + 2] + dy,
+                      indices[o * 4 + 3] + dz};
+      int32_t s = -1;
+      if (q[1] >= 0 && q[1] < shape[0] && q[2] >= 0 && q[2] < shape[1] && q[3] >= 0 && q[3] < shape[2])
+        s = (int32_t)find_key(ki, N, lin_key(q, shape));
+      table[(int64_t)k * N + o] = s;
+    }
+  }
+  int64_t P = table_to_lists(table, 27, N, pair_src, pair_dst, tile_off);
+  free(table);
+  free(ki);
+  return P;
+}
+
+/* K2 — SparseConv3d(k=2,s=2) coarse set (backbone.py:74-77). */
+int64_t orc_rulebook_down(const int32_t* indices, int64_t N, const int32_t* shape,
+                          int32_t* out_indices, int32_t* fine_to_coarse, int32_t* tap) {
+  int32_t oshape[3] = {shape[0] / 2, shape[1] / 2, shape[2] / 2};
+  key_idx_t* ki = (key_idx_t*)malloc(sizeof(key_idx_t) * (size_t)(N > 0 ? N : 1));
+  for (int64_t i = 0; i < N; ++i) {
+    const int32_t* c = indices + i * 4;
+    int32_t q[4] = {c[0], c[1] / 2, c[2] / 2, c[3] / 2};
+    tap[i] = (c[1] & 1) * 4 + (c[2] & 1) * 2 + (c[3] & 1);
+    int ok = q[1] < oshape[0] && q[2] < oshape[1] && q[3] < oshape[2];
+    ki[i].key = ok ? lin_key(q, oshape) : UINT64_MAX;
+    ki[i].idx = i;
+  }
+  qsort(ki, (size_t)N, sizeof(key_idx_t), cmp_key_idx);
+  int64_t V = 0, i = 0;
+  for (int64_t j = 0; j < N; ++j) fine_to_coarse[j] = -1;
+  while (i < N && ki[i].key != UINT64_MAX) {
+    int64_t j = i;
+    while (j < N && ki[j].key == ki[i].key) ++j;
+    const int32_t* c = indices + ki[i].idx * 4;
+    out_indices[V * 4] = c[0];
+    out_indices[V * 4 + 1] = c[1] / 2;
+    out_indices[V * 4 + 2] = c[2] / 2;
+    out_indices[V * 4 + 3] = c[3] / 2;
+    for (int64_t t = i; t < j; ++t) fine_to_coarse[ki[t].idx] = (int32_t)V;
+    ++V;
+    i = j;
+  }
+  free(ki);
+  return V;
+}
+
+int64_t orc_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N,
+                                int64_t n_out, int32_t* fwd_src, int32_t* fwd_dst, int32_t* fwd_tile_off,
+                                int32_t* bwd_src, int32_t* bwd_dst, int32_t* bwd_tile_off) {
+  int32_t* tf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(8 * (n_out > 0 ? n_out : 1)));
+  int32_t* tb = (int32_t*)malloc(sizeof(int32_t) * (size_t)(8 * (N > 0 ? N : 1)));
+  for (int64_t t = 0; t < 8 * n_out; ++t) tf[t] = -1;
+  for (int64_t t = 0; t < 8 * N; ++t) tb[t] = -1;
+  for (int64_t i = 0; i < N; ++i) {
+    int32_t o = fine_to_coarse[i];
+    if (o < 0) continue;
+    tf[(int64_t)tap[i] * n_out + o] = (int32_t)i;
+    tb[(int64_t)tap[i] * N + i] = o;
+  }
+  int64_t P = table_to_lists(tf, 8, n_out, fwd_src, fwd_dst, fwd_tile_off);
+  table_to_lists(tb, 8, N, bwd_src, bwd_dst, bwd_tile_off);
+  free(tf);
+  free(tb);
+  return P;
+}
+
+/* C — sparse conv (gather-GEMM-scatter), W canonical [K,cin,cout].  out fully overwritten. */
+void orc_spconv_fwd(const float* in, const float* W, const int32_t* pair_src, const int32_t* pair_dst,
+                    const int32_t* tile_off, int K, int64_t n_dst, int cin, int cout, float* out) {
+  int64_t n_tiles = (n_dst + TILE_ROWS - 1) / TILE_ROWS;
+  memset(out, 0, sizeof(float) * (size_t)(n_dst * cout));
+  for (int k = 0; k < K; ++k) {
+    const float* Wk = W + (int64_t)k * cin * cout;
+    int64_t p0 = tile_off[k * (n_tiles + 1)], p1 = tile_off[k * (n_tiles + 1) + n_tiles];
+    for (int64_t p = p0; p < p1; ++p) {
+      const float* a = in + (int64_t)pair_src[p] * cin;
+      float* o = out + (int64_t)pair_dst[p] * cout;
+      for (int ci = 0; ci < cin; ++ci) {
+        float av = a[ci];
+        const float* w = Wk + (int64_t)ci * cout;
+        for (int co = 0; co < cout; ++co) o[co] = o[co] + av * w[co];
+      }
+    }
+  }
+}
+
+/* din[src] += dout[dst] W_k^T ; din [n_src,cin] fully overwritten */
+void orc_spconv_dgrad(const float* dout, const float* W, const int32_t* pair_src,
+                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst,
+                      int64_t n_src, int cin, int cout, float* din) {
+  int64_t n_tiles = (n_dst + TILE_ROWS - 1) / TILE_ROWS;
+  memset(din, 0, sizeof(float) * (size_t)(n_src * cin));
+  for (int k = 0; k < K; ++k) {
+    const float* Wk = W + (int64_t)k * cin * cout;
+    int64_t p0 = tile_off[k * (n_tiles + 1)], p1 = tile_off[k * (n_tiles + 1) + n_tiles];
+    for (int64_t p = p0; p < p1; ++p) {
+      const float* g = dout + (int64_t)pair_dst[p] * cout;
+      float* d = din + (int64_t)pair_src[p] * cin;
+      for (int ci = 0; ci < cin; ++ci) {
+        const float* w = Wk + (int64_t)ci * cout;
+        float acc = 0.f;
+        for (int co = 0; co < cout; ++co) acc = acc + g[co] * w[co];
+        d[ci] = d[ci] + acc;
+      }
+    }
+  }
+}
+
+void orc_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
+                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
+                      int cout, float* dW) {
+  int64_t n_tiles = (n_dst + TILE_ROWS - 1) / TILE_ROWS;
+  memset(dW, 0, sizeof(float) * (size_t)((int64_t)K * cin * cout));
+  for (int k = 0; k < K; ++k) {
+    float* Wk = dW + (int64_t)k * cin * cout;
+    int64_t p0 = tile_off[k * (n_tiles + 1)], p1 = tile_off[k * (n_tiles + 1) + n_tiles];
+    for (int64_t p = p0; p < p1; ++p) {
+      const float* a = in + (int64_t)pair_src[p] * cin;
+      const float* g = dout + (int64_t)pair_dst[p] * cout;
+      for (int ci = 0; ci < cin; ++ci) {
+        float av = a[ci];
+        float* w = Wk + (int64_t)ci * cout;
+        for (int co = 0; co < cout; ++co) w[co] = w[co] + av * g[co];
+      }
+    }
+  }
+}
+
+/* G */
+void orc_gather_rows(const float* table, const int32_t* idx, int64_t n, int C, float* out) {
+  for (int64_t i = 0; i < n; ++i)
+    for (int c = 0; c < C; ++c) out[i * C + c] = idx[i] >= 0 ? table[(int64_t)idx[i] * C + c] : 0.f;
+}
+void orc_scatter_rows(const float* dout, const int32_t* idx, int64_t n, int64_t n_rows, int C,
+                      float* dtable) {
+  memset(dtable, 0, sizeof(float) * (size_t)(n_rows * C));
+  for (int64_t i = 0; i < n; ++i)
+    if (idx[i] >= 0)
+      for (int c = 0; c < C; ++c) dtable[(int64_t)idx[i] * C + c] += dout[i * C + c];
+}
+
+/* B — epic_ops.ball_query contract (grouping_utils.py:119-134); distance
+ * test as the vendored kernel (ball_query_gpu.cu:33-34) with strict < and no contraction. */
+void orc_ball_query(const float* points, const float* query, const int32_t* batch_indices,
+                    const int32_t* batch_offsets, const int32_t* point_labels,
+                    const int32_t* query_labels, int64_t Np, int64_t Q, int64_t S, float radius, int K,
+                    int32_t* indices, int32_t* count) {
+  (void)Np; (void)S;
+  float r2 = radius * radius;
+  for (int64_t i = 0; i < Q; ++i) {
+    int32_t b = batch_indices[i];
+    int cnt = 0;
+    float qx = query[i * 3], qy = query[i * 3 + 1], qz = query[i * 3 + 2];
+    for (int k = 0; k < K; ++k) indices[i * K + k] = -1;
+    for (int32_t j = batch_offsets[b]; j < batch_offsets[b + 1] && cnt < K; ++j) {
+      if (point_labels && query_labels && point_labels[j] != query_labels[i]) continue;
+      float dx = qx - points[j * 3], dy = qy - points[j * 3 + 1], dz = qz - points[j * 3 + 2];
+      float d2 = (dx * dx + dy * dy) + dz * dz;
+      if (d2 < r2) indices[i * K + cnt++] = j;
+    }
+    count[i] = cnt;
+  }
+}
+
+/* L — epic_ops.connected_components_labeling contract (grouping_utils.py:130-139; Appendix A.4). */
+static int32_t uf_find(int32_t* parent, int32_t x) {
+  while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+  return x;
+}
+void orc_ccl(const int32_t* begin_end, const int32_t* edges, int64_t Q, int64_t E, int compacted,
+             int32_t* labels) {
+  (void)E;
+  int32_t* parent = (int32_t*)malloc(sizeof(int32_t) * (size_t)(Q > 0 ? Q : 1));
+  for (int64_t i = 0; i < Q; ++i) parent[i] = (int32_t)i;
+  for (int64_t i = 0; i < Q; ++i) {
+    for (int32_t e = begin_end[2 * i]; e < begin_end[2 * i + 1]; ++e) {
+      int32_t j = edges[e];
+      if (j < 0 || j >= Q) continue;
+      int32_t a = uf_find(parent, (int32_t)i), b = uf_find(parent, j);
+      if (a < b) parent[b] = a; else if (b < a) parent[a] = b;
+    }
+  }
+  for (int64_t i = 0; i < Q; ++i) labels[i] = uf_find(parent, (int32_t)i);
+  if (compacted) {
+    int32_t* remap = (int32_t*)malloc(sizeof(int32_t) * (size_t)(Q > 0 ? Q : 1));
+    int32_t n = 0;
+    for (int64_t i = 0; i < Q; ++i) if (labels[i] == i) remap[i] = n++;
+    for (int64_t i = 0; i < Q; ++i) labels[i] = remap[labels[i]];
+    free(remap);
+  }
+  free(parent);
+}
+
+/* R — epic_ops.reduce contracts (grouping_utils.py:59-70, model.py:360-362; Appendix A.5). */
+void orc_segmented_reduce(const float* values, const int32_t* begin, const int32_t* end, int64_t P,
+                          int C, int mode, float* out) {
+  for (int64_t p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+      for (int32_t r = begin[p]; r < end[p]; ++r) {
+        float v = values[(int64_t)r * C + c];
+        if (r == begin[p]) acc = v;
+        else if (mode == 0) acc = acc + v;
+        else if (mode == 1) acc = v < acc ? v : acc;
+        else acc = v > acc ? v : acc;
+      }
+      out[p * C + c] = acc;
+    }
+}
+void orc_segmented_maxpool_fwd(const float* values, const int32_t* begin, const int32_t* end, int64_t P,
+                               int C, float* pooled, int32_t* argmax) {
+  for (int64_t p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c) {
+      float best = 0.f;
+      int32_t bi = -1;
+      for (int32_t r = begin[p]; r < end[p]; ++r) {
+        float v = values[(int64_t)r * C + c];
+        if (bi < 0 || v > best) { best = v; bi = r; }
+      }
+      pooled[p * C + c] = best;
+      argmax[p * C + c] = bi;
+    }
+}
+void orc_segmented_maxpool_bwd(const float* dpooled, const int32_t* argmax, int64_t P, int C, int64_t M,
+                               float* dvalues) {
+  memset(dvalues, 0, sizeof(float) * (size_t)(M * C));
+  for (int64_t p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c)
+      if (argmax[p * C + c] >= 0) dvalues[(int64_t)argmax[p * C + c] * C + c] += dpooled[p * C + c];
+}
+
+/* I — epic_ops.iou.batch_instance_seg_iou contract (model.py:373-383; Appendix A.6). */
+void orc_instance_iou(const int32_t* proposal_offsets, const int32_t* instance_labels,
+                      const int32_t* batch_indices, const int32_t* num_points_per_instance, int64_t P,
+                      int64_t B, int I, float* ious) {
+  (void)B;
+  int32_t* inter = (int32_t*)malloc(sizeof(int32_t) * (size_t)(I > 0 ? I : 1));
+  for (int64_t p = 0; p < P; ++p) {
+    int32_t b0 = proposal_offsets[p], b1 = proposal_offsets[p + 1];
+    memset(inter, 0, sizeof(int32_t) * (size_t)I);
+    for (int32_t m = b0; m < b1; ++m) {
+      int32_t l = instance_labels[m];
+      if (l >= 0 && l < I) inter[l]++;
+    }
+    int32_t b = b1 > b0 ? batch_indices[b0] : 0;
+    for (int k = 0; k < I; ++k) {
+      int32_t npi = num_points_per_instance[(int64_t)b * I + k];
+      int32_t uni = (b1 - b0) + npi - inter[k];
+      ious[p * I + k] = (npi > 0 && uni > 0) ? (float)inter[k] / (float)uni : 0.f;
+    }
+  }
+  free(inter);
+}
+
+/* N — epic_ops.nms contract (grouping_utils.py:231-250; Appendix A.7). order = ids by descending score. */
+int32_t orc_nms(const float* ious, const int32_t* order, int64_t P, float threshold, int32_t* keep) {
+  char* dead = (char*)calloc((size_t)(P > 0 ? P : 1), 1);
+  int32_t n = 0;
+  for (int64_t a = 0; a < P; ++a) {
+    int32_t i = order[a];
+    if (dead[i]) continue;
+    keep[n++] = i;
+    for (int64_t b = a + 1; b < P; ++b) {
+      int32_t j = order[b];
+      if (!dead[j] && ious[(int64_t)i * P + j] > threshold) dead[j] = 1;
+    }
+  }
+  free(dead);
+  return n;
+}
+
+/* ================================================================================================
+ * F — PointNet++ family, following the vendored CUDA sources
+ * (dataset/process_tools/utils/pointnet_lib/src/).
+ * ================================================================================================ */
+/* ball_query_gpu.cu:9-45 */
+void orc_pn2_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz,
+                        const float* xyz, int32_t* idx) {
+  float radius2 = radius * radius;
+  for (int bs = 0; bs < b; ++bs)
+    for (int pt = 0; pt < m; ++pt) {
+      const float* q = new_xyz + ((int64_t)bs * m + pt) * 3;
+      const float* base = xyz + (int64_t)bs * n * 3;
+      int32_t* out = idx + ((int64_t)bs * m + pt) * nsample;
+      int cnt = 0;
+      for (int k = 0; k < n; ++k) {
+        float dx = q[0] - base[k * 3], dy = q[1] - base[k * 3 + 1], dz = q[2] - base[k * 3 + 2];
+        float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < radius2) {
+          if (cnt == 0) for (int l = 0; l < nsample; ++l) out[l] = k;
+          out[cnt] = k;
+          ++cnt;
+          if (cnt >= nsample) break;
+        }
+      }
+    }
+}
+
+/* group_points_gpu.cu:47-66 */
+void orc_pn2_group_points(int b, int c, int n, int npoints, int nsample, const float* points,
+                          const int32_t* idx, float* out) {
+  for (int bs = 0; bs < b; ++bs)
+    for (int ch = 0; ch < c; ++ch)
+      for (int p = 0; p < npoints; ++p)
+        for (int s = 0; s < nsample; ++s) {
+          int32_t j = idx[((int64_t)bs * npoints + p) * nsample + s];
+          out[(((int64_t)bs * c + ch) * npoints + p) * nsample + s] = points[((int64_t)bs * c + ch) * n + j];
+        }
+}
+/* group_points_gpu.cu:8-25 (atomicAdd order unspecified in the reference; here ascending index) */
+void orc_pn2_group_points_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                               const int32_t* idx, float* grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)((int64_t)b * c * n));
+  for (int bs = 0; bs < b; ++bs)
+    for (int ch = 0; ch < c; ++ch)
+      for (int p = 0; p < npoints; ++p)
+        for (int s = 0; s < nsample; ++s) {
+          int32_t j = idx[((int64_t)bs * npoints + p) * nsample + s];
+          grad_points[((int64_t)bs * c + ch) * n + j] += grad_out[(((int64_t)bs * c + ch) * npoints + p) * nsample + s];
+        }
+}
+/* sampling_gpu.cu:8-24 */
+void orc_pn2_gather_points(int b, int c, int n, int npoints, const float* points, const int32_t* idx,
+                           float* out) {
+  for (int bs = 0; bs < b; ++bs)
+    for (int ch = 0; ch < c; ++ch)
+      for (int p = 0; p < npoints; ++p)
+        out[((int64_t)bs * c + ch) * npoints + p] = points[((int64_t)bs * c + ch) * n + idx[(int64_t)bs * npoints + p]];
+}
+/* sampling_gpu.cu:46-63 */
+void orc_pn2_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out,
+                                const int32_t* idx, float* grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)((int64_t)b * c * n));
+  for (int bs = 0; bs < b; ++bs)
+    for (int ch = 0; ch < c; ++ch)
+      for (int p = 0; p < npoints; ++p)
+        grad_points[((int64_t)bs * c + ch) * n + idx[(int64_t)bs * npoints + p]] += grad_out[((int64_t)bs * c + ch) * npoints + p];
+}
+
+/* cuda_utils.h:10-14 */
+static int opt_n_threads(int work_size) {
+  int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int v = 1 << pow_2;
+  if (v > 1024) v = 1024;
+  if (v < 1) v = 1;
+  return v;
+}
+
+/* sampling_gpu.cu:93-209: per-thread strided scan with strict '>' then a tree reduction whose
+ * __update (sampling_gpu.cu:86-91) keeps the lower thread on ties. temp is updated in place. */
+void orc_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
+                                     int32_t* idxs) {
+  if (m <= 0) return;
+  int B = opt_n_threads(n);
+  float* dists = (float*)malloc(sizeof(float) * (size_t)B);
+  int* dists_i = (int*)malloc(sizeof(int) * (size_t)B);
+  for (int bs = 0; bs < b; ++bs) {
+    const float* d = dataset + (int64_t)bs * n * 3;
+    float* t = temp + (int64_t)bs * n;
+    int32_t* out = idxs + (int64_t)bs * m;
+    int old = 0;
+    out[0] = old;
+    for (int j = 1; j < m; ++j) {
+      float x1 = d[old * 3], y1 = d[old * 3 + 1], z1 = d[old * 3 + 2];
+      for (int tid = 0; tid < B; ++tid) {
+        int besti = 0;
+        float best = -1;
+        for (int k = tid; k < n; k += B) {
+          float dx = d[k * 3] - x1, dy = d[k * 3 + 1] - y1, dz = d[k * 3 + 2] - z1;
+          float dd = (dx * dx + dy * dy) + dz * dz;
+          float d2 = dd < t[k] ? dd : t[k];
+          t[k] = d2;
+          besti = d2 > best ? k : besti;
+          best = d2 > best ? d2 : best;
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+      }
+      for (int s = B / 2; s >= 1; s >>= 1)
+        for (int tid = 0; tid < s; ++tid) {
+          float v1 = dists[tid], v2 = dists[tid + s];
+          int i1 = dists_i[tid], i2 = dists_i[tid + s];
+          dists[tid] = v1 > v2 ? v1 : v2;
+          dists_i[tid] = v2 > v1 ? i2 : i1;
+        }
+      old = dists_i[0];
+      out[j] = old;
+    }
+  }
+  free(dists);
+  free(dists_i);
+}
+
+/* interpolate_gpu.cu:81-124 */
+void orc_pn2_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                      int32_t* idx) {
+  for (int bs = 0; bs < b; ++bs)
+    for (int pt = 0; pt < n; ++pt) {
+      const float* u = unknown + ((int64_t)bs * n + pt) * 3;
+      const float* kn = known + (int64_t)bs * m * 3;
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        float dx = u[0] - kn[k * 3], dy = u[1] - kn[k * 3 + 1], dz = u[2] - kn[k * 3 + 2];
+        float d = (dx * dx + dy * dy) + dz * dz;
+        if (d < best1) { best3 = best2; besti3 = besti2; best2 = best1; besti2 = besti1; best1 = d; besti1 = k; }
+        else if (d < best2) { best3 = best2; besti3 = besti2; best2 = d; besti2 = k; }
+        else if (d < best3) { best3 = d; besti3 = k; }
+      }
+      float* d2 = dist2 + ((int64_t)bs * n + pt) * 3;
+      int32_t* id = idx + ((int64_t)bs * n + pt) * 3;
+      d2[0] = (float)best1; d2[1] = (float)best2; d2[2] = (float)best3;
+      id[0] = besti1; id[1] = besti2; id[2] = besti3;
+    }
+}
+
+/* interpolate_gpu.cu:9-57 (k <= 200) */
+void orc_pn2_knn(int b, int n, int m, int k, const float* unknown, const float* known, float* dist2,
+                 int32_t* idx) {
+  double best[200];
+  int besti[200];
+  for (int bs = 0; bs < b; ++bs)
+    for (int pt = 0; pt < n; ++pt) {
+      const float* u = unknown + ((int64_t)bs * n + pt) * 3;
+      const float* kn = known + (int64_t)bs * m * 3;
+      for (int i = 0; i < k; ++i) { best[i] = 1e40; besti[i] = 0; }
+      for (int i = 0; i < m; ++i) {
+        float dx = u[0] - kn[i * 3], dy = u[1] - kn[i * 3 + 1], dz = u[2] - kn[i * 3 + 2];
+        float d = (dx * dx + dy * dy) + dz * dz;
+        for (int j = 0; j < k; ++j)
+          if (d < best[j]) {
+            for (int l = k - 1; l > j; --l) { best[l] = best[l - 1]; besti[l] = besti[l - 1]; }
+            best[j] = d; besti[j] = i;
+            break;
+          }
+      }
+      for (int i = 0; i < k; ++i) {
+        idx[((int64_t)bs * n + pt) * k + i] = besti[i];
+        dist2[((int64_t)bs * n + pt) * k + i] = (float)best[i];
+      }
+    }
+}
+
+/* interpolate_gpu.cu:149-169 */
+void orc_pn2_three_interpolate(int b, int c, int m, int n, const float* points, const int32_t* idx,
+                               const float* weight, float* out) {
+  for (int bs = 0; bs < b; ++bs)
+    for (int ch = 0; ch < c; ++ch)
+      for (int pt = 0; pt < n; ++pt) {
+        const float* w = weight + ((int64_t)bs * n + pt) * 3;
+        const int32_t* id = idx + ((int64_t)bs * n + pt) * 3;
+        const float* p = points + ((int64_t)bs * c + ch) * m;
+        out[((int64_t)bs * c + ch) * n + pt] = (w[0] * p[id[0]] + w[1] * p[id[1]]) + w[2] * p[id[2]];
+      }
+}
+/* interpolate_gpu.cu:192-214 */
+void orc_pn2_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
+                                    const int32_t* idx, const float* weight, float* grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)((int64_t)b * c * m));
+  for (int bs = 0; bs < b; ++bs)
+    for (int ch = 0; ch < c; ++ch)
+      for (int pt = 0; pt < n; ++pt) {
+        const float* w = weight + ((int64_t)bs * n + pt) * 3;
+        const int32_t* id = idx + ((int64_t)bs * n + pt) * 3;
+        float g = grad_out[((int64_t)bs * c + ch) * n + pt];
+        float* gp = grad_points + ((int64_t)bs * c + ch) * m;
+        gp[id[0]] += g * w[0];
+        gp[id[1]] += g * w[1];
+        gp[id[2]] += g * w[2];
+      }
+}

@@ -1,0 +1,293 @@
+"""GPU parity: every C-ABI entry point of libgpn_hip.so (called through gapartnet_amd.hip_ops) against the
+CPU oracle on the same seeded inputs.  Integer outputs (voxel ids, rulebooks, neighbour lists, labels, argmax,
+NMS keep lists, FPS / kNN indices) must be bit-exact; floating-point outputs are compared with the tolerance
+written next to each check (north_star: 1e-4 for features)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+FP_TOL = 1e-4  # north_star tolerance for features
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def H():
+    from gapartnet_amd import hip_ops
+    return hip_ops
+
+
+if os.environ.get("GPN_TEST_LOGIC_ON_CPU"):
+    # self-check of the test logic in a GPU-less container: oracle vs oracle on CPU tensors (proves nothing about
+    # the kernels; never set on the GPU box)
+    @pytest.fixture(scope="module")
+    def H():  # noqa: F811
+        from oracle import torch_ops
+        return torch_ops
+
+    @pytest.fixture(scope="module")
+    def cuda():  # noqa: F811
+        return torch.device("cpu")
+
+
+# ------------------------------------------------------------------------------------------------ V
+@pytest.mark.parametrize("M,S,C,vs", [(20000, 1, 6, 0.01), (30000, 4, 6, 0.01), (5000, 37, 16, 0.05), (1, 1, 3, 0.1)])
+def test_voxelize_matches_oracle(H, cuda, M, S, C, vs):
+    rng = np.random.default_rng(M + S)
+    pts = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    pts[: M // 10] = pts[M // 10: 2 * (M // 10)][: M // 10]  # exact duplicates
+    feats = rng.normal(size=(M, C)).astype(np.float32)
+    cuts = np.sort(rng.choice(np.arange(1, M), size=S - 1, replace=False)) if S > 1 else np.array([], np.int64)
+    offs = np.concatenate([[0], cuts, [M]]).astype(np.int64)
+    rmin = np.stack([pts[offs[s]:offs[s + 1]].min(0) - 1e-4 for s in range(S)]).astype(np.float32)
+    rmax = np.stack([pts[offs[s]:offs[s + 1]].max(0) + 1e-4 for s in range(S)]).astype(np.float32)
+    grid = [int(2.1 / vs) + 2] * 3
+    ref = O.voxelize(pts, feats, offs, rmin, rmax, [vs] * 3, grid)
+    got = H.voxelize(dev(pts, cuda), dev(feats, cuda), dev(offs, cuda), dev(rmin, cuda), dev(rmax, cuda), [vs] * 3,
+                     grid, want_csr=True)
+    vf, vc, vseg, pid, order, vstart = [host(t) for t in got]
+    assert np.array_equal(vc, ref[1]) and np.array_equal(vseg, ref[2]) and np.array_equal(pid, ref[3])
+    assert np.array_equal(vf, ref[0]), "means are ordered sums: expected bit-exact"
+    # CSR consistency
+    V = vc.shape[0]
+    assert vstart[0] == 0 and vstart[V] == M and np.array_equal(pid[order[:vstart[V]]], np.repeat(np.arange(V), np.diff(vstart)))
+
+
+def test_voxelize_drops_out_of_range(H, cuda):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-1, 1, (4000, 3)).astype(np.float32)
+    feats = pts.copy()
+    offs = np.array([0, 4000], np.int64)
+    rmin, rmax = np.array([[-0.5, -0.5, -0.5]], np.float32), np.array([[0.5, 0.5, 0.5]], np.float32)
+    ref = O.voxelize(pts, feats, offs, rmin, rmax, [0.1] * 3, [12] * 3)
+    got = [host(t) for t in H.voxelize(dev(pts, cuda), dev(feats, cuda), dev(offs, cuda), dev(rmin, cuda), dev(rmax, cuda), [0.1] * 3, [12] * 3)]
+    assert (ref[3] < 0).any()
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ K
+def _check_rb(rb, ref):
+    P = ref[0].shape[0]
+    assert int(rb.num_pairs.item()) == P
+    assert np.array_equal(host(rb.pair_src)[:P], ref[0])
+    assert np.array_equal(host(rb.pair_dst)[:P], ref[1])
+    assert np.array_equal(host(rb.tile_off), ref[2])
+
+
+@pytest.mark.parametrize("kind,batch,shape,n", [("random", 2, [12, 10, 14], 700), ("surface", 3, [64, 64, 64], 5000),
+                                                 ("random", 1, [5, 5, 5], 125), ("random", 1, [3, 3, 3], 1)])
+def test_rulebooks_bit_exact(H, cuda, kind, batch, shape, n):
+    rng = np.random.default_rng(n)
+    idx = synth.random_sparse_indices(rng, batch, shape, n) if kind == "random" else synth.surface_indices(rng, batch, shape, n)
+    _check_rb(H.rulebook_subm3(dev(idx, cuda), shape), O.rulebook_subm3(idx, shape))
+    d = O.rulebook_down(idx, shape)
+    out_idx, out_shape, rb_f, rb_b = H.rulebook_down(dev(idx, cuda), shape, batch)
+    assert out_shape == d["out_shape"]
+    assert np.array_equal(host(out_idx), d["out_indices"])
+    _check_rb(rb_f, d["fwd"])
+    _check_rb(rb_b, d["bwd"])
+
+
+# ------------------------------------------------------------------------------------------------ C
+CONV_SHAPES = [(16, 16), (32, 32), (48, 48), (64, 64), (80, 80), (96, 96), (112, 112), (32, 16), (64, 32), (96, 48),
+               (128, 64), (160, 80), (192, 96), (16, 32), (96, 112)]
+
+
+@pytest.mark.parametrize("cin,cout", CONV_SHAPES)
+def test_subm_conv_fwd_dgrad_wgrad(H, cuda, cin, cout):
+    rng = np.random.default_rng(cin * 1000 + cout)
+    shape = [40, 40, 40]
+    idx = synth.surface_indices(rng, 2, shape, 1500)
+    N = idx.shape[0]
+    f = rng.normal(size=(N, cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    g = rng.normal(size=(N, cout)).astype(np.float32)
+    rb_ref = O.rulebook_subm3(idx, shape)
+    rb = H.rulebook_subm3(dev(idx, cuda), shape)
+    out = host(H.conv_fwd(dev(f, cuda), dev(W, cuda), rb))
+    assert np.allclose(out, O.spconv_fwd(f, W, rb_ref, N), atol=FP_TOL, rtol=1e-4)
+    din = host(H.conv_dgrad(dev(g, cuda), dev(W, cuda), rb, rb, True))
+    assert np.allclose(din, O.spconv_dgrad(g, W, rb_ref, N, N), atol=FP_TOL, rtol=1e-4)
+    dW = host(H.conv_wgrad(dev(f, cuda), dev(g, cuda), rb))
+    ref_dW = O.spconv_wgrad(f, g, rb_ref, N, 27)
+    assert np.allclose(dW, ref_dW, atol=1e-3, rtol=1e-4), np.abs(dW - ref_dW).max()
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 48), (96, 112)])
+def test_down_and_inverse_conv(H, cuda, cin, cout):
+    rng = np.random.default_rng(cin + cout)
+    shape = [33, 40, 37]  # odd sizes: last plane dropped
+    idx = synth.random_sparse_indices(rng, 2, shape, 4000)
+    N = idx.shape[0]
+    d = O.rulebook_down(idx, shape)
+    No = d["out_indices"].shape[0]
+    out_idx, out_shape, rb_f, rb_b = H.rulebook_down(dev(idx, cuda), shape, 2)
+    f = rng.normal(size=(N, cin)).astype(np.float32)
+    W = (rng.normal(size=(8, cin, cout)) / np.sqrt(8 * cin)).astype(np.float32)
+    out = host(H.conv_fwd(dev(f, cuda), dev(W, cuda), rb_f))
+    ref = O.spconv_fwd(f, W, d["fwd"], No)
+    assert np.allclose(out, ref, atol=FP_TOL, rtol=1e-4)
+    g = rng.normal(size=(No, cout)).astype(np.float32)
+    din = host(H.conv_dgrad(dev(g, cuda), dev(W, cuda), rb_f, rb_b, False))
+    assert np.allclose(din, O.spconv_dgrad(g, W, d["fwd"], No, N), atol=FP_TOL, rtol=1e-4)
+    assert np.allclose(host(H.conv_wgrad(dev(f, cuda), dev(g, cuda), rb_f)), O.spconv_wgrad(f, g, d["fwd"], No, 8), atol=1e-3, rtol=1e-4)
+    # inverse conv: coarse -> fine over the bwd lists
+    Wi = (rng.normal(size=(8, cout, cin)) / np.sqrt(cout)).astype(np.float32)
+    up = host(H.conv_fwd(dev(ref, cuda), dev(Wi, cuda), rb_b))
+    assert np.allclose(up, O.spconv_fwd(ref, Wi, d["bwd"], N), atol=FP_TOL, rtol=1e-4)
+    gi = rng.normal(size=(N, cin)).astype(np.float32)
+    dci = host(H.conv_dgrad(dev(gi, cuda), dev(Wi, cuda), rb_b, rb_f, False))
+    assert np.allclose(dci, O.spconv_dgrad(gi, Wi, d["bwd"], N, No), atol=FP_TOL, rtol=1e-4)
+
+
+def test_conv_large_batch_uses_wide_tiles(H, cuda):
+    """>= 4096 32-row tiles selects the 64-row wave tile variant."""
+    rng = np.random.default_rng(11)
+    shape = [128, 128, 128]
+    idx = synth.surface_indices(rng, 10, shape, 22000)
+    N = idx.shape[0]
+    assert N >= 4096 * 32
+    f = rng.normal(size=(N, 16)).astype(np.float32)
+    W = (rng.normal(size=(27, 16, 16)) / 20).astype(np.float32)
+    rb = H.rulebook_subm3(dev(idx, cuda), shape)
+    out = host(H.conv_fwd(dev(f, cuda), dev(W, cuda), rb))
+    ref = O.spconv_fwd(f, W, O.rulebook_subm3(idx, shape), N)
+    assert np.allclose(out, ref, atol=FP_TOL, rtol=1e-4)
+
+
+def test_gather_scatter_rows(H, cuda):
+    rng = np.random.default_rng(5)
+    table = rng.normal(size=(3000, 16)).astype(np.float32)
+    idx = rng.integers(-1, 3000, 20000).astype(np.int32)
+    assert np.array_equal(host(H.gather_rows(dev(table, cuda), dev(idx, cuda))), O.gather_rows(table, idx))
+    g = rng.normal(size=(20000, 16)).astype(np.float32)
+    got = host(H.scatter_rows(dev(g, cuda), dev(idx, cuda), 3000))
+    assert np.array_equal(got, O.scatter_rows(g, idx, 3000)), "ordered sums: bit-exact"
+    for C in (3, 27):
+        t2 = rng.normal(size=(100, C)).astype(np.float32)
+        i2 = rng.integers(0, 100, 1000).astype(np.int32)
+        assert np.array_equal(host(H.gather_rows(dev(t2, cuda), dev(i2, cuda))), O.gather_rows(t2, i2))
+
+
+# ------------------------------------------------------------------------------------------------ B / L
+@pytest.mark.parametrize("K,labels", [(50, True), (300, True), (8, False)])
+def test_ball_query_and_ccl(H, cuda, K, labels):
+    rng = np.random.default_rng(K)
+    pts, batch = synth.clustered_points(rng, 3, 3000)
+    offs = np.array([0, 3000, 6000, 9000], np.int32)
+    lab = rng.integers(1, 4, pts.shape[0]).astype(np.int32) if labels else None
+    ref_idx, ref_cnt = O.ball_query(pts, pts, batch, offs, 0.04, K, lab, lab)
+    idx, cnt = H.ball_query(dev(pts, cuda), dev(pts, cuda), dev(batch, cuda), dev(offs, cuda), 0.04, K,
+                            None if lab is None else dev(lab, cuda), None if lab is None else dev(lab, cuda))
+    assert np.array_equal(host(cnt), ref_cnt) and np.array_equal(host(idx), ref_idx)
+    Q = pts.shape[0]
+    begin = np.arange(Q, dtype=np.int32) * K
+    be = np.stack([begin, begin + ref_cnt], 1).reshape(-1)
+    for compacted in (False, True):
+        got = host(H.ccl(dev(be, cuda), idx.reshape(-1), compacted))
+        assert np.array_equal(got, O.ccl(be, ref_idx.reshape(-1), compacted))
+
+
+def test_ball_query_unsorted_batches_and_empty_segment(H, cuda):
+    rng = np.random.default_rng(8)
+    pts = rng.uniform(-0.2, 0.2, (1000, 3)).astype(np.float32)
+    offs = np.array([0, 400, 400, 1000], np.int32)  # segment 1 is empty
+    q = rng.uniform(-0.2, 0.2, (777, 3)).astype(np.float32)
+    qb = rng.integers(0, 3, 777).astype(np.int32)
+    ref = O.ball_query(pts, q, qb, offs, 0.05, 16)
+    got = H.ball_query(dev(pts, cuda), dev(q, cuda), dev(qb, cuda), dev(offs, cuda), 0.05, 16)
+    assert np.array_equal(host(got[0]), ref[0]) and np.array_equal(host(got[1]), ref[1])
+
+
+# ------------------------------------------------------------------------------------------------ R / I / N
+def test_segmented_ops(H, cuda):
+    rng = np.random.default_rng(9)
+    sizes = rng.integers(1, 400, 300)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    vals = rng.normal(size=(offs[-1], 16)).astype(np.float32)
+    vals[10:20] = vals[10]  # ties
+    for mode in ("sum", "min", "max"):
+        got = host(H.segmented_reduce(dev(vals, cuda), dev(offs[:-1], cuda), dev(offs[1:], cuda), mode))
+        assert np.array_equal(got, O.segmented_reduce(vals, offs[:-1], offs[1:], mode)), mode
+    p, a = H.segmented_maxpool_fwd(dev(vals, cuda), dev(offs[:-1], cuda), dev(offs[1:], cuda))
+    rp, ra = O.segmented_maxpool(vals, offs[:-1], offs[1:])
+    assert np.array_equal(host(p), rp) and np.array_equal(host(a), ra)
+    g = rng.normal(size=rp.shape).astype(np.float32)
+    assert np.array_equal(host(H.segmented_maxpool_bwd(dev(g, cuda), a, vals.shape[0])), O.segmented_maxpool_bwd(g, ra, vals.shape[0]))
+
+
+def test_instance_iou_and_nms(H, cuda):
+    rng = np.random.default_rng(10)
+    B, I, P = 4, 9, 200
+    sizes = rng.integers(5, 300, P)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    M = offs[-1]
+    prop_b = np.sort(rng.integers(0, B, P)).astype(np.int32)
+    bi = np.repeat(prop_b, sizes).astype(np.int32)
+    il = rng.integers(-1, I, M).astype(np.int32)
+    npi = rng.integers(0, 500, (B, I)).astype(np.int32)
+    npi[:, -1] = 0
+    got = host(H.instance_iou(dev(offs, cuda), dev(il, cuda), dev(bi, cuda), dev(npi, cuda)))
+    assert np.array_equal(got, O.instance_iou(offs, il, bi, npi))
+    ious = rng.uniform(0, 1, (P, P)).astype(np.float32)
+    ious = np.maximum(ious, ious.T) * (rng.uniform(size=(P, P)) < 0.1)
+    ious = np.maximum(ious, ious.T).astype(np.float32)
+    scores = rng.uniform(size=P).astype(np.float32)
+    scores[5] = scores[17]
+    got = host(H.nms(dev(ious, cuda), dev(scores, cuda), 0.3))
+    assert np.array_equal(got, O.nms(ious, scores, 0.3))
+
+
+# ------------------------------------------------------------------------------------------------ F
+def test_pointnet2_family(H, cuda):
+    rng = np.random.default_rng(12)
+    b, n, m, c = 2, 3000, 500, 8
+    xyz = rng.uniform(-1, 1, (b, n, 3)).astype(np.float32)
+    new_xyz = xyz[:, :m].copy()
+    idx = host(H.pn2_ball_query(0.2, 32, dev(xyz, cuda), dev(new_xyz, cuda)))
+    assert np.array_equal(idx, O.pn2_ball_query(0.2, 32, xyz, new_xyz))
+    feats = rng.normal(size=(b, c, n)).astype(np.float32)
+    grouped = host(H.pn2_group_points(dev(feats, cuda), dev(idx, cuda)))
+    assert np.array_equal(grouped, O.pn2_group_points(feats, idx))
+    gg = rng.normal(size=grouped.shape).astype(np.float32)
+    assert np.allclose(host(H.pn2_group_points_grad(dev(gg, cuda), dev(idx, cuda), n)), O.pn2_group_points_grad(gg, idx, n), atol=1e-4)
+    fps = host(H.pn2_furthest_point_sampling(dev(xyz, cuda), 256))
+    assert np.array_equal(fps, O.pn2_furthest_point_sampling(xyz, 256))
+    gathered = host(H.pn2_gather_points(dev(feats, cuda), dev(fps, cuda)))
+    assert np.array_equal(gathered, O.pn2_gather_points(feats, fps))
+    g2 = rng.normal(size=gathered.shape).astype(np.float32)
+    assert np.allclose(host(H.pn2_gather_points_grad(dev(g2, cuda), dev(fps, cuda), n)), O.pn2_gather_points_grad(g2, fps, n), atol=1e-5)
+    known = xyz[:, fps[0]][:, :256] if False else np.stack([xyz[i, fps[i]] for i in range(b)])
+    d2, i3 = H.pn2_three_nn(dev(xyz, cuda), dev(known, cuda))
+    rd2, ri3 = O.pn2_three_nn(xyz, known)
+    assert np.array_equal(host(i3), ri3) and np.array_equal(host(d2), rd2)
+    kd2, ki = H.pn2_knn(dev(xyz[:, :400], cuda), dev(known, cuda), 5)
+    rkd2, rki = O.pn2_knn(xyz[:, :400], known, 5)
+    assert np.array_equal(host(ki), rki) and np.array_equal(host(kd2), rkd2)
+    w = rng.uniform(size=(b, n, 3)).astype(np.float32)
+    kf = rng.normal(size=(b, c, 256)).astype(np.float32)
+    interp = host(H.pn2_three_interpolate(dev(kf, cuda), dev(ri3, cuda), dev(w, cuda)))
+    assert np.array_equal(interp, O.pn2_three_interpolate(kf, ri3, w))
+    gi = rng.normal(size=interp.shape).astype(np.float32)
+    assert np.allclose(host(H.pn2_three_interpolate_grad(dev(gi, cuda), dev(ri3, cuda), dev(w, cuda), 256)),
+                       O.pn2_three_interpolate_grad(gi, ri3, w, 256), atol=1e-3)
+
+
+def test_fps_tie_break_small_cloud(H, cuda):
+    # regular grid -> many exact distance ties; n = 1000 -> reference block size 512
+    g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(10), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    assert np.array_equal(host(H.pn2_furthest_point_sampling(dev(g, cuda), 64)), O.pn2_furthest_point_sampling(g, 64))
