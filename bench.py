@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the GAPartNet hot path on MI355X (BASELINE.json metric: point-clouds/sec, 20k-pt scenes,
+train step).
+
+One "step" = one full training step of the perception pipeline on one batch of synthetic 20k-point scenes per rank:
+on-device batched voxelisation + collate, sparse U-Net backbone, semantic / offset heads, dual-set clustering
+(ball query + CCL), proposal re-voxelisation, ScoreNet, NPCS-Net, all five losses, backward, Adam.  Inputs (raw point
+clouds + labels) are resident in HBM before the timed region.  Launch: ``python bench.py`` (1 GPU) or
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (one rank per GPU, DDP over RCCL).
+
+Prints ONE JSON line on rank 0 with the contract fields plus ``roofline`` (dominant kernel, measured with hipEvents
+inside libgpn_hip.so during an extra instrumented step) and ``cpu_baseline`` (the same train step through the CPU
+oracle on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0           # same guide, HBM3E peak (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step (BASELINE config 3: bs=8/GPU)")
+    ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--schedule", type=str, default="0,0", help="training_schedule; 0,0 = every head active")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scenes", type=int, default=3)
+    return ap.parse_args()
+
+
+def build_step(model, optimizer, world, device):
+    from gapartnet_amd.trainer import _TrainStep
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    step_module = _TrainStep(model)
+    if world > 1:
+        step_module = DDP(step_module, device_ids=[device.index], find_unused_parameters=True)
+
+    def step(batch, i):
+        optimizer.zero_grad(set_to_none=True)
+        loss = step_module(batch, i)
+        loss.backward()
+        optimizer.step()
+        return loss
+    return step
+
+
+def roofline_from_profile(device):
+    """Σ algorithmic work / Σ hipEvent time per kernel family over one instrumented step."""
+    import ctypes
+    from gapartnet_amd import _C, functional as GF
+    lib = _C.lib()
+    out = {}
+    names = {0: "spconv_fwd_kernel (fwd+dgrad launches)", 1: "spconv_wgrad_kernel"}
+    # algorithmic flops/bytes per launch from the Python-side conv log (pair counts are device scalars: read now)
+    per_kind = {"fwd": [0.0, 0.0, 0], "dgrad": [0.0, 0.0, 0], "wgrad": [0.0, 0.0, 0]}
+    for (num_pairs, cin, cout, n_src, n_dst, K, kind) in GF.CONV_LOG:
+        P = float(num_pairs.item())
+        per_kind[kind][0] += 2.0 * P * cin * cout
+        per_kind[kind][1] += 4.0 * n_src * cin + 4.0 * n_dst * cout + 8.0 * P + 4.0 * K * cin * cout
+        per_kind[kind][2] += 1
+    work = {0: (per_kind["fwd"][0] + per_kind["dgrad"][0], per_kind["fwd"][1] + per_kind["dgrad"][1]),
+            1: (per_kind["wgrad"][0], per_kind["wgrad"][1])}
+    for kid, label in names.items():
+        launches, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _C.check(lib.gpn_prof_get(kid, ctypes.byref(launches), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+        out[kid] = dict(kernel=label, launches=int(launches.value), ms=float(ms.value), flops=work[kid][0], bytes=work[kid][1])
+    return out
+
+
+def cpu_baseline(args):
+    """the same train step through the CPU oracle (C restatement, 1 thread) on a bounded sample."""
+    from gapartnet_amd import backend
+    from gapartnet_amd.smoke import make_batch, make_model
+    from oracle import torch_ops as oracle_ops
+    torch.set_num_threads(1)
+    model = make_model(tuple(int(s) for s in args.schedule.split(",")))
+    opt = model.configure_optimizers()
+    batch = make_batch(args.cpu_scenes, args.points, seed0=5000)
+    with backend.using(oracle_ops):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+    return dict(value=args.cpu_scenes / dt, unit="point-clouds/sec", cores=1, kind="port",
+                sample=f"1 full train step (fwd+bwd+Adam), {args.cpu_scenes} synthetic scene(s) x {args.points} pts, "
+                       f"CPU oracle (oracle/gpn_oracle.c, single thread), {dt:.1f} s")
+
+
+def main():
+    args = parse()
+    from gapartnet_amd.trainer import init_distributed
+    rank, local_rank, world, device = init_distributed("cuda")
+    assert device.type == "cuda", "bench.py needs a GPU (the product has no CPU path)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    from gapartnet_amd import _C, functional as GF
+    from gapartnet_amd.smoke import make_batch, make_model
+    _C.lib()  # fail loudly if the HIP extension is missing
+
+    schedule = tuple(int(s) for s in args.schedule.split(","))
+    model = make_model(schedule).to(device)
+    optimizer = model.configure_optimizers()
+    step = build_step(model, optimizer, world, device)
+    # two resident batches per rank (alternated) of distinct synthetic scenes
+    pool = [[pc.to(device) for pc in make_batch(args.batch, args.points, seed0=1000 + (2 * rank + j) * args.batch)]
+            for j in range(2)]
+    model.train()
+
+    for i in range(args.warmup):
+        step(pool[i % 2], i)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(pool[i % 2], i)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # instrumented extra step (not timed): hipEvent pairs around the conv kernels on their launch stream
+    roof = None
+    if rank == 0:
+        lib = _C.lib()
+        lib.gpn_prof_reset(); lib.gpn_prof_enable(1)
+        GF.CONV_LOG = []
+        step(pool[0], 0)
+        torch.cuda.synchronize(device)
+        lib.gpn_prof_enable(0)
+        prof = roofline_from_profile(device)
+        GF.CONV_LOG = None
+        dom = max(prof.values(), key=lambda d: d["ms"])
+        if dom["ms"] > 0 and dom["launches"] > 0:
+            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=dom["kernel"], achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None, launches=dom["launches"],
+                        avg_launch_us=dom["ms"] * 1e3 / dom["launches"],
+                        algorithmic_gbs=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
+                        hbm_frac=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        all_kernels={v["kernel"]: dict(ms=v["ms"], launches=v["launches"],
+                                                       tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0)
+                                     for v in prof.values()})
+    elif world > 1:
+        step(pool[0], 0)  # keep ranks in lock-step through the extra DDP step
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        clouds = world * args.batch * args.steps
+        out = {
+            "metric": "point-clouds/sec (20k pts, train step)", "value": clouds / elapsed, "unit": "point-clouds/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"full pipeline train step (fwd+bwd+Adam), schedule {list(schedule)}, "
+                                   f"{args.points}-pt scenes, bs={args.batch}/GPU (BASELINE config 3 per-GPU shape), "
+                                   f"voxel 0.01, random-init weights", "global_batch": world * args.batch,
+                       "points_per_scene": args.points, "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,7 +99,10 @@ struct FpsCand {
 };
 __device__ __forceinline__ bool fps_better(float av, int ak, float bv, int bk, int bmask) {
   if (av != bv) return av > bv;
-  const int ta = ak & bmask, tb = bk & bmask;
+  // the reference's tree (sampling_gpu.cu:143-200) merges slot j with j+s for s = B/2 ... 1 and keeps slot j on
+  // ties, so two tied candidates are decided at the lowest bit where their thread ids differ, the 0-bit winning:
+  // ascending order of the bit-reversed thread id
+  const unsigned ta = __brev((unsigned)(ak & bmask)), tb = __brev((unsigned)(bk & bmask));
   if (ta != tb) return ta < tb;
   return ak < bk;
 }

@@ -1,0 +1,239 @@
+"""Proposal clustering / re-voxelisation / filtering / NMS / AP glue
+(reference: gapartnet/network/grouping_utils.py:14-454) — same function names and results, written over the
+HIP operators (epic_ops mirrors) and restructured to stay on the device.
+"""
+from dataclasses import fields, replace
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ..epic_ops.ball_query import ball_query
+from ..epic_ops.ccl import connected_components_labeling
+from ..epic_ops.nms import nms
+from ..epic_ops.reduce import segmented_reduce
+from .. import backend
+from ..structure.instances import Instances
+
+
+def offsets_from_counts(counts: torch.Tensor, dtype=torch.int32) -> torch.Tensor:
+    """CSR offsets [n+1] from per-segment counts."""
+    out = torch.zeros((counts.shape[0] + 1,), dtype=dtype, device=counts.device)
+    out[1:] = counts.cumsum(0)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- NPCS loss
+def compute_npcs_loss(npcs_preds: torch.Tensor, gt_npcs: torch.Tensor, proposal_indices: torch.Tensor,
+                      symmetry_matrix: torch.Tensor) -> torch.Tensor:
+    """symmetry-aware smooth-L1-like NPCS loss (grouping_utils.py:14-43): per point and symmetry m the target is
+    gt @ S_m, residual r = pred - target - 0.5, cost = 5 r^2 if r^2 <= 0.01 else |r| - 0.05; mean per proposal,
+    min over symmetries, mean over proposals.  ``proposal_indices`` must be grouped (non-decreasing runs)."""
+    _, lengths = torch.unique_consecutive(proposal_indices, return_counts=True)
+    targets = torch.matmul(gt_npcs[:, None, None, :], symmetry_matrix).squeeze(2)          # [n, m, 3]
+    dist2 = ((npcs_preds[:, None, :] - targets - 0.5) ** 2).sum(dim=-1)                  # [n, m]
+    cost = torch.where(dist2 <= 0.01, 5 * dist2, torch.sqrt(dist2) - 0.05)
+    per_proposal = torch.segment_reduce(cost, "mean", lengths=lengths)                    # [P, m]
+    return per_proposal.min(dim=-1)[0].mean()
+
+
+# ------------------------------------------------------------------------------------------------- re-voxelise
+def segmented_voxelize(pt_xyz: torch.Tensor, pt_features: torch.Tensor, segment_offsets: torch.Tensor,
+                       segment_indices: torch.Tensor, num_points_per_segment: torch.Tensor, score_fullscale: float,
+                       score_scale: float, jitter: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Scale every proposal into a ``score_fullscale``^3 grid and voxelise it as its own batch element
+    (grouping_utils.py:47-104).  -> (voxel_features, voxel_coords [V,4] = (proposal, x, y, z), pc_voxel_id).
+
+    ``jitter`` = the two uniform 3-vectors the reference draws with torch.rand(3) (grouping_utils.py:86-90, one pair
+    shared by all proposals, drawn in eval too); pass them to make a run reproducible, else they are drawn here in
+    the same order from the device generator."""
+    begin, end = segment_offsets[:-1], segment_offsets[1:]
+    mean = segmented_reduce(pt_xyz, begin, end, mode="sum") / num_points_per_segment[:, None]
+    centered = pt_xyz - mean[segment_indices]
+    lo = segmented_reduce(centered, begin, end, mode="min")
+    hi = segmented_reduce(centered, begin, end, mode="max")
+
+    scale = 1.0 / ((hi - lo) / score_fullscale).max(-1)[0] - 0.01
+    scale = torch.clamp(scale, min=None, max=score_scale)
+    lo_s, hi_s = lo * scale[:, None], hi * scale[:, None]
+    extent = hi_s - lo_s
+    if jitter is None:
+        r_a = torch.rand(3, dtype=lo.dtype, device=lo.device)
+        r_b = torch.rand(3, dtype=lo.dtype, device=lo.device)
+    else:
+        r_a, r_b = jitter
+    shift = (-lo_s + torch.clamp(score_fullscale - extent - 0.001, min=0) * r_a
+             + torch.clamp(score_fullscale - extent + 0.001, max=0) * r_b)
+    scaled = centered * scale[segment_indices][:, None] + shift[segment_indices]
+
+    full = float(score_fullscale)
+    n_seg = segment_offsets.shape[0] - 1
+    dev = pt_xyz.device
+    rmin = torch.zeros((1, 3), dtype=torch.float32, device=dev)
+    rmax = torch.full((1, 3), full, dtype=torch.float32, device=dev)
+    # direct kernel-V call with host-known grid (no sync for the range tensors, unlike the generic wrapper)
+    vf, vc, vseg, pid = backend.raw().voxelize(scaled, pt_features, segment_offsets.to(torch.int64), rmin, rmax,
+                                               [1.0, 1.0, 1.0], [int(full) + 1] * 3)
+    voxel_coords = torch.cat([vseg[:, None], vc], dim=1)
+    return vf, voxel_coords, pid
+
+
+# ------------------------------------------------------------------------------------------------- clustering
+def cluster_proposals(pt_xyz: torch.Tensor, batch_indices: torch.Tensor, batch_offsets: torch.Tensor,
+                      sem_preds: torch.Tensor, ball_query_radius: float, max_num_points_per_query: int
+                      ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """label-aware ball query -> connected components -> points sorted by component
+    (grouping_utils.py:108-140).  Components are labelled by their minimum point index and the sort is stable, so
+    proposals come out ordered by first member and members in ascending point order."""
+    K = int(max_num_points_per_query)
+    neighbours, counts = ball_query(pt_xyz, pt_xyz, batch_indices, batch_offsets, ball_query_radius, K,
+                                    point_labels=sem_preds, query_labels=sem_preds)
+    begin = torch.arange(pt_xyz.shape[0], dtype=torch.int32, device=pt_xyz.device) * K
+    begin_end = torch.stack([begin, begin + counts.to(torch.int32)], dim=1).view(-1)
+    cc_labels = connected_components_labeling(begin_end, neighbours.view(-1), compacted=False)
+    sorted_cc_labels, sorted_indices = torch.sort(cc_labels, stable=True)
+    return sorted_cc_labels, sorted_indices
+
+
+def get_gt_scores(ious: torch.Tensor, fg_thresh: float = 0.75, bg_thresh: float = 0.25) -> torch.Tensor:
+    """soft score target: 0 below bg_thresh, 1 above fg_thresh, linear in between (grouping_utils.py:144-156)."""
+    k = 1 / (fg_thresh - bg_thresh)
+    b = bg_thresh / (bg_thresh - fg_thresh)
+    fg = ious > fg_thresh
+    mid = ~(fg | (ious < bg_thresh))
+    return torch.where(mid, ious * k + b, fg.to(ious.dtype))
+
+
+# ------------------------------------------------------------------------------------------------- filtering
+def _keep_proposals(proposals: Instances, keep_proposal: torch.Tensor) -> Instances:
+    """restrict every per-point / per-proposal field to the proposals selected by the boolean mask."""
+    keep_point = keep_proposal[proposals.proposal_indices]
+    _, new_indices, counts = torch.unique_consecutive(proposals.proposal_indices[keep_point], return_inverse=True,
+                                                      return_counts=True)
+    npcs_keep = keep_point[proposals.npcs_valid_mask] if proposals.npcs_valid_mask is not None else keep_point
+
+    def pts(t, mask=keep_point):
+        return None if t is None else t[mask]
+
+    return Instances(
+        valid_mask=proposals.valid_mask, sorted_indices=pts(proposals.sorted_indices), pt_xyz=pts(proposals.pt_xyz),
+        batch_indices=pts(proposals.batch_indices), proposal_offsets=offsets_from_counts(counts),
+        proposal_indices=new_indices, num_points_per_proposal=counts, sem_preds=pts(proposals.sem_preds),
+        score_preds=proposals.score_preds[keep_proposal], npcs_preds=pts(proposals.npcs_preds, npcs_keep),
+        sem_labels=pts(proposals.sem_labels), instance_labels=pts(proposals.instance_labels),
+        instance_sem_labels=proposals.instance_sem_labels, num_points_per_instance=proposals.num_points_per_instance,
+        gt_npcs=pts(proposals.gt_npcs, npcs_keep), npcs_valid_mask=pts(proposals.npcs_valid_mask),
+        ious=None if proposals.ious is None else proposals.ious[keep_proposal])
+
+
+def filter_invalid_proposals(proposals: Instances, score_threshold: float, min_num_points_per_proposal: int) -> Instances:
+    """drop proposals with score <= threshold or size <= min points (strict, grouping_utils.py:159-218)."""
+    keep = (proposals.score_preds > score_threshold) & (proposals.num_points_per_proposal > min_num_points_per_proposal)
+    return _keep_proposals(proposals, keep)
+
+
+@torch.no_grad()
+def proposal_intersections(sorted_indices: torch.Tensor, proposal_indices: torch.Tensor, num_proposals: int) -> torch.Tensor:
+    """[P,P] float32 number of shared points between proposals (diagonal = sizes).  Equivalent to the reference's
+    dense ``csr @ csr.T`` (grouping_utils.py:231-239) but built from the sorted (point, proposal) incidence list, so
+    memory is O(P^2 + M) instead of O(P * M)."""
+    dev = sorted_indices.device
+    inter = torch.zeros((num_proposals, num_proposals), dtype=torch.float32, device=dev)
+    sizes = torch.bincount(proposal_indices, minlength=num_proposals).to(torch.float32)
+    inter.diagonal().copy_(sizes)
+    if sorted_indices.shape[0] < 2:
+        return inter
+    pt, order = torch.sort(sorted_indices.to(torch.int64), stable=True)
+    prop = proposal_indices[order]
+    d = 1
+    while d < pt.shape[0]:
+        same = pt[d:] == pt[:-d]
+        if not bool(same.any()):
+            break
+        a, b = prop[:-d][same], prop[d:][same]
+        ones = torch.ones(a.shape[0], dtype=torch.float32, device=dev)
+        inter.index_put_((a, b), ones, accumulate=True)
+        inter.index_put_((b, a), ones, accumulate=True)
+        d += 1
+    return inter
+
+
+def apply_nms(proposals: Instances, iou_threshold: float = 0.3) -> Instances:
+    """greedy NMS on point-set IoU between proposals (grouping_utils.py:221-298)."""
+    P = proposals.score_preds.shape[0]
+    inter = proposal_intersections(proposals.sorted_indices, proposals.proposal_indices, P)
+    sizes = proposals.num_points_per_proposal.to(torch.float32)
+    union = sizes[:, None] + sizes[None, :] - inter
+    ious = inter / (union + 1e-8)
+    keep = nms(ious, proposals.score_preds, iou_threshold)
+    mask = torch.zeros(P, dtype=torch.bool, device=proposals.score_preds.device)
+    mask[keep] = True
+    return _keep_proposals(proposals, mask)
+
+
+# ------------------------------------------------------------------------------------------------- AP
+def voc_ap(rec: torch.Tensor, prec: torch.Tensor, use_07_metric: bool = False) -> float:
+    """VOC average precision: 11-point (2007) or area under the monotone precision envelope (grouping_utils.py:302-342)."""
+    rec = rec.detach().cpu().numpy()
+    prec = prec.detach().cpu().numpy().astype(rec.dtype)
+    dt = rec.dtype.type
+    if use_07_metric:
+        ap = dt(0)
+        for t in np.arange(0, 11) / 10.0:
+            sel = rec >= t
+            ap = ap + (prec[sel].max() if sel.any() else dt(0)) / dt(11.0)
+        return float(ap)
+    mrec = np.concatenate([[0.0], rec, [1.0]]).astype(rec.dtype)
+    mpre = np.concatenate([[0.0], prec, [0.0]]).astype(rec.dtype)
+    mpre = np.maximum.accumulate(mpre[::-1])[::-1]  # precision envelope
+    i = np.nonzero(mrec[1:] != mrec[:-1])[0]
+    return float(((mrec[i + 1] - mrec[i]) * mpre[i + 1]).sum(dtype=rec.dtype))
+
+
+def _compute_ap_per_class(tp: torch.Tensor, fp: torch.Tensor, num_gt_instances) -> float:
+    if tp.shape[0] == 0:
+        return 0.0
+    tp, fp = tp.cumsum(0), fp.cumsum(0)
+    return voc_ap(tp / num_gt_instances, tp / (tp + fp + 1e-8))
+
+
+def compute_ap(proposals: List[Instances], num_classes: int = 9, iou_threshold: float = 0.5, device="cpu") -> List[float]:
+    """per-class AP over a list of per-batch proposal sets (grouping_utils.py:360-454): proposals visited by
+    descending confidence; a proposal is a true positive if its best-IoU ground-truth instance of the same class
+    exceeds the threshold and is still unmatched.  The greedy matching is inherently sequential; here it runs on host
+    copies of the small per-batch tables (no per-proposal device round trips)."""
+    conf = torch.cat([p.score_preds for p in proposals]).detach().cpu()
+    classes = torch.cat([p.pt_sem_classes for p in proposals]).detach().cpu().numpy()
+    order = torch.argsort(conf, descending=True).numpy()
+    n_total = conf.shape[0]
+    set_of = np.concatenate([np.full(p.score_preds.shape[0], i, np.int64) for i, p in enumerate(proposals)]) \
+        if n_total else np.zeros((0,), np.int64)
+    sample_of = np.concatenate([p.batch_indices[p.proposal_offsets[:-1].long()].long().cpu().numpy()
+                                for p in proposals]) if n_total else np.zeros((0,), np.int64)
+    local_of = np.concatenate([np.arange(p.score_preds.shape[0]) for p in proposals]) if n_total else np.zeros((0,), np.int64)
+    inst_labels = [p.instance_sem_labels.detach().cpu().numpy() for p in proposals]
+    ious = [p.ious.detach().cpu().numpy() for p in proposals]
+    matched = [np.zeros(l.shape, dtype=bool) for l in inst_labels]
+
+    tp = np.zeros(n_total, np.float32)
+    fp = np.zeros(n_total, np.float32)
+    for rank, idx in enumerate(order):
+        s, smp, loc, cls = set_of[idx], sample_of[idx], local_of[idx], classes[idx]
+        row = np.where(inst_labels[s][smp] == cls, ious[s][loc], 0.0)
+        best = int(row.argmax()) if row.shape[0] else 0
+        best_iou = float(row[best]) if row.shape[0] else 0.0
+        if best_iou > iou_threshold and not matched[s][smp, best]:
+            tp[rank] = 1.0
+            matched[s][smp, best] = True
+        else:
+            fp[rank] = 1.0
+
+    sorted_classes = classes[order]
+    gt_classes = np.concatenate([l.reshape(-1) for l in inst_labels]) if inst_labels else np.zeros((0,), np.int32)
+    tp_t, fp_t = torch.from_numpy(tp), torch.from_numpy(fp)
+    aps: List[float] = []
+    for c in range(1, num_classes):
+        sel = torch.from_numpy(sorted_classes == c)
+        aps.append(_compute_ap_per_class(tp_t[sel], fp_t[sel], int((gt_classes == c).sum())))
+    return aps

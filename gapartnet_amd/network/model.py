@@ -1,0 +1,452 @@
+"""GAPartNet perception model (reference: gapartnet/network/model.py:27-1055) on the MI355X operators.
+
+API surface kept from the reference so this class is a drop-in for ``train.py fit/test`` with ``gapartnet.yaml``:
+constructor keyword arguments (model.py:28-55), sub-module names (=> state_dict keys), the forward_* /
+loss_* methods, the Lightning hooks (training_step, validation_step, on_validation_epoch_end, test_step,
+on_test_epoch_end, configure_optimizers) and every logged key.  Visualisation / pose rendering in
+on_test_epoch_end (model.py:930-1049) is out of scope.
+
+Pipeline of one step (model.py:466-659):
+  collate -> backbone U-Net (71 sparse convs) -> voxel->point gather -> semantic head + offset head
+  -> [epoch >= min(schedule)] dual-set clustering (ball query + CCL on xyz and xyz+offset) -> proposals >= 5 points
+     -> per-proposal re-voxelisation into 28^3 grids
+  -> [epoch >= schedule[0]] score U-Net -> per-proposal max-pool -> score head, IoU-derived targets
+  -> [epoch >= schedule[1]] NPCS U-Net -> per-point NPCS, symmetry-aware loss
+"""
+import functools
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as GF
+from ..epic_ops.iou import batch_instance_seg_iou
+from ..epic_ops.reduce import segmented_maxpool
+from ..lightning_lite import LightningModule
+from ..misc.info import PART_ID2NAME, get_symmetry_matrix
+from ..spconv import pytorch as spconv
+from ..structure.instances import Instances
+from ..structure.point_cloud import PointCloud, PointCloudBatch
+from ..structure.segmentation import Segmentation
+from .backbone import SparseUNet
+from .grouping_utils import (apply_nms, cluster_proposals, compute_ap, compute_npcs_loss, filter_invalid_proposals,
+                             get_gt_scores, offsets_from_counts, segmented_voxelize)
+from .losses import dice_loss, focal_loss, mean_iou, pixel_accuracy
+
+_SPLITS = ["val", "test_intra", "test_inter"]
+
+
+class GAPartNet(LightningModule):
+    def __init__(
+        self,
+        in_channels: int,
+        num_part_classes: int,
+        backbone_type: str = "SparseUNet",
+        backbone_cfg: Dict = {},
+        learning_rate: float = 1e-3,
+        # semantic segmentation
+        ignore_sem_label: int = -100,
+        use_sem_focal_loss: bool = True,
+        use_sem_dice_loss: bool = True,
+        # instance segmentation
+        instance_seg_cfg: Dict = {},
+        # npcs segmentation
+        symmetry_indices: List = [],
+        # training
+        training_schedule: List = [],
+        # validation
+        val_score_threshold: float = 0.09,
+        val_min_num_points_per_proposal: int = 3,
+        val_nms_iou_threshold: float = 0.3,
+        val_ap_iou_threshold: float = 0.5,
+        # testing
+        visualize_cfg: Dict = {},
+        debug: bool = True,
+        ckpt: str = "",
+        # not in the reference: voxel size used when scenes reach the model un-voxelised (on-device voxelisation)
+        voxel_size: Sequence[float] = (0.01, 0.01, 0.01),
+    ):
+        super().__init__()
+        self.save_hyperparameters()
+        self.validation_step_outputs = []
+
+        self.in_channels = in_channels
+        self.num_part_classes = num_part_classes
+        self.backbone_type = backbone_type
+        self.backbone_cfg = backbone_cfg
+        self.learning_rate = learning_rate
+        self.ignore_sem_label = ignore_sem_label
+        self.use_sem_focal_loss = use_sem_focal_loss
+        self.use_sem_dice_loss = use_sem_dice_loss
+        self.visualize_cfg = visualize_cfg
+        self.start_scorenet, self.start_npcs = training_schedule
+        self.start_clustering = min(self.start_scorenet, self.start_npcs)
+        self.val_nms_iou_threshold = val_nms_iou_threshold
+        self.val_ap_iou_threshold = val_ap_iou_threshold
+        self.val_score_threshold = val_score_threshold
+        self.val_min_num_points_per_proposal = val_min_num_points_per_proposal
+        self.symmetry_indices = torch.as_tensor(symmetry_indices, dtype=torch.int64)
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.revoxelize_jitter = None  # tests inject the two uniform 3-vectors of segmented_voxelize here
+
+        self.ball_query_radius = instance_seg_cfg["ball_query_radius"]
+        self.max_num_points_per_query = instance_seg_cfg["max_num_points_per_query"]
+        self.min_num_points_per_proposal = instance_seg_cfg["min_num_points_per_proposal"]
+        self.max_num_points_per_query_shift = instance_seg_cfg["max_num_points_per_query_shift"]
+        self.score_fullscale = instance_seg_cfg["score_fullscale"]
+        self.score_scale = instance_seg_cfg["score_scale"]
+
+        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+        if self.backbone_type != "SparseUNet":
+            raise NotImplementedError(
+                f"backbone type {self.backbone_type!r}: only the SparseUNet path is on the accelerated hot path "
+                "(the dense PointNet backbone of the reference is out of scope, SURVEY.md §2.1 #9)")
+        channels = self.backbone_cfg["channels"]
+        block_repeat = self.backbone_cfg["block_repeat"]
+        width = channels[0]
+        self.backbone = SparseUNet.build(in_channels, channels, block_repeat, norm_fn)
+        self.sem_seg_head = nn.Linear(width, self.num_part_classes)
+        self.offset_head = nn.Sequential(nn.Linear(width, width), norm_fn(width), nn.ReLU(inplace=True),
+                                         nn.Linear(width, 3))
+        self.score_unet = SparseUNet.build(width, channels[:2], block_repeat, norm_fn, without_stem=True)
+        self.score_head = nn.Linear(width, self.num_part_classes - 1)
+        self.npcs_unet = SparseUNet.build(width, channels[:2], block_repeat, norm_fn, without_stem=True)
+        self.npcs_head = nn.Linear(width, 3 * (self.num_part_classes - 1))
+
+        self.symmetry_matrix_1, self.symmetry_matrix_2, self.symmetry_matrix_3 = get_symmetry_matrix()
+
+        if ckpt != "":
+            print("Loading pretrained model from:", ckpt)
+            state_dict = torch.load(ckpt, map_location="cpu")["state_dict"]
+            missing_keys, unexpected_keys = self.load_state_dict(state_dict, strict=False)
+            if len(missing_keys) > 0:
+                print("missing_keys:", missing_keys)
+            if len(unexpected_keys) > 0:
+                print("unexpected_keys:", unexpected_keys)
+
+    # ------------------------------------------------------------------------------------------ forward pieces
+    def forward_backbone(self, pc_batch: PointCloudBatch) -> torch.Tensor:
+        voxel_features = self.backbone(pc_batch.voxel_tensor)
+        return GF.gather_rows(voxel_features.features, pc_batch.pc_voxel_id, getattr(pc_batch, "pc_voxel_csr", None))
+
+    def forward_sem_seg(self, pc_feature: torch.Tensor) -> torch.Tensor:
+        return self.sem_seg_head(pc_feature)
+
+    def loss_sem_seg(self, sem_logits: torch.Tensor, sem_labels: torch.Tensor) -> torch.Tensor:
+        if self.use_sem_focal_loss:
+            loss = focal_loss(sem_logits, sem_labels, alpha=None, gamma=2.0, ignore_index=self.ignore_sem_label,
+                              reduction="mean")
+        else:
+            loss = F.cross_entropy(sem_logits, sem_labels, weight=None, ignore_index=self.ignore_sem_label,
+                                   reduction="mean")
+        if self.use_sem_dice_loss:
+            loss = loss + dice_loss(sem_logits[:, :, None, None], sem_labels[:, None, None])
+        return loss
+
+    def forward_offset(self, pc_feature: torch.Tensor) -> torch.Tensor:
+        return self.offset_head(pc_feature)
+
+    def loss_offset(self, offsets: torch.Tensor, gt_offsets: torch.Tensor, sem_labels: torch.Tensor,
+                    instance_labels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """L1 distance + negative cosine between predicted and true point->instance-centre offsets, on points of
+        labelled part instances (model.py:204-226)."""
+        on_part = (sem_labels > 0) & (instance_labels >= 0)
+        loss_dist = (offsets - gt_offsets).abs().sum(dim=-1)[on_part].mean()
+        gt_dir = gt_offsets / (torch.norm(gt_offsets, p=2, dim=-1)[:, None] + 1e-8)
+        pred_dir = offsets / (torch.norm(offsets, p=2, dim=-1)[:, None] + 1e-8)
+        loss_dir = (-(gt_dir * pred_dir).sum(-1))[on_part].mean()
+        return loss_dist, loss_dir
+
+    def proposal_clustering_and_revoxelize(self, pt_xyz: torch.Tensor, batch_indices: torch.Tensor,
+                                           pt_features: torch.Tensor, sem_preds: torch.Tensor,
+                                           offset_preds: torch.Tensor, instance_labels: Optional[torch.Tensor]):
+        """dual-set clustering and per-proposal re-voxelisation (model.py:228-346).
+        -> (voxel_tensor, pc_voxel_id, proposals) or (None, None, None) when no proposal survives."""
+        device = pt_xyz.device
+        valid_mask = sem_preds > 0
+        if instance_labels is not None:
+            valid_mask = valid_mask & (instance_labels >= 0)
+
+        pt_xyz, batch_indices, pt_features = pt_xyz[valid_mask], batch_indices[valid_mask], pt_features[valid_mask]
+        sem_preds, offset_preds = sem_preds[valid_mask].int(), offset_preds[valid_mask]
+        if instance_labels is not None:
+            instance_labels = instance_labels[valid_mask]
+
+        # CSR over the scenes that still have points
+        _, scene_compact, scene_counts = torch.unique_consecutive(batch_indices, return_inverse=True, return_counts=True)
+        scene_compact = scene_compact.int()
+        scene_offsets = offsets_from_counts(scene_counts)
+
+        # set 1: clusters in xyz; set 2: clusters in xyz shifted by the predicted centre offsets
+        labels_a, order_a = cluster_proposals(pt_xyz, scene_compact, scene_offsets, sem_preds,
+                                              self.ball_query_radius, self.max_num_points_per_query)
+        labels_b, order_b = cluster_proposals(pt_xyz + offset_preds, scene_compact, scene_offsets, sem_preds,
+                                              self.ball_query_radius, self.max_num_points_per_query_shift)
+        labels = torch.cat([labels_a, labels_b + labels_a.shape[0]], dim=0)
+        sorted_indices = torch.cat([order_a, order_b], dim=0)
+
+        _, proposal_indices, sizes = torch.unique_consecutive(labels, return_inverse=True, return_counts=True)
+        keep_point = (sizes >= self.min_num_points_per_proposal)[proposal_indices]
+        sorted_indices = sorted_indices[keep_point]
+        if sorted_indices.shape[0] == 0:
+            return None, None, None
+
+        batch_indices, pt_xyz, pt_features = batch_indices[sorted_indices], pt_xyz[sorted_indices], pt_features[sorted_indices]
+        sem_preds = sem_preds[sorted_indices]
+        if instance_labels is not None:
+            instance_labels = instance_labels[sorted_indices]
+
+        _, proposal_indices, sizes = torch.unique_consecutive(proposal_indices[keep_point], return_inverse=True,
+                                                              return_counts=True)
+        num_proposals = sizes.shape[0]
+        proposal_offsets = offsets_from_counts(sizes)
+
+        voxel_features, voxel_coords, pc_voxel_id = segmented_voxelize(
+            pt_xyz, pt_features, proposal_offsets, proposal_indices, sizes, self.score_fullscale, self.score_scale,
+            jitter=self.revoxelize_jitter)
+        voxel_tensor = spconv.SparseConvTensor(voxel_features, voxel_coords.int(),
+                                               spatial_shape=[self.score_fullscale] * 3, batch_size=num_proposals)
+        if not bool((pc_voxel_id >= 0).all()):
+            raise RuntimeError("re-voxelisation dropped points: a proposal left its score_fullscale^3 grid "
+                               "(the reference stops in pdb here, model.py:328-330)")
+
+        proposals = Instances(valid_mask=valid_mask, sorted_indices=sorted_indices, pt_xyz=pt_xyz,
+                              batch_indices=batch_indices, proposal_offsets=proposal_offsets,
+                              proposal_indices=proposal_indices, num_points_per_proposal=sizes, sem_preds=sem_preds,
+                              instance_labels=instance_labels)
+        return voxel_tensor, pc_voxel_id, proposals
+
+    def forward_proposal_score(self, voxel_tensor: spconv.SparseConvTensor, pc_voxel_id: torch.Tensor,
+                               proposals: Instances) -> torch.Tensor:
+        offsets = proposals.proposal_offsets
+        feats = self.score_unet(voxel_tensor)
+        feats = GF.gather_rows(feats.features, pc_voxel_id)
+        pooled, _ = segmented_maxpool(feats, offsets[:-1], offsets[1:])
+        return self.score_head(pooled)
+
+    def loss_proposal_score(self, score_logits: torch.Tensor, proposals: Instances,
+                            num_points_per_instance: torch.Tensor) -> torch.Tensor:
+        ious = batch_instance_seg_iou(proposals.proposal_offsets, proposals.instance_labels, proposals.batch_indices,
+                                      num_points_per_instance)
+        proposals.ious = ious
+        proposals.num_points_per_instance = num_points_per_instance
+        gt_scores = get_gt_scores(ious.max(-1)[0], 0.75, 0.25)
+        return F.binary_cross_entropy_with_logits(score_logits, gt_scores)
+
+    def forward_proposal_npcs(self, voxel_tensor: spconv.SparseConvTensor, pc_voxel_id: torch.Tensor) -> torch.Tensor:
+        feats = self.npcs_unet(voxel_tensor)
+        return GF.gather_rows(self.npcs_head(feats.features), pc_voxel_id)
+
+    def loss_proposal_npcs(self, npcs_logits: torch.Tensor, gt_npcs: torch.Tensor, proposals: Instances) -> torch.Tensor:
+        """symmetry-aware NPCS loss on points whose predicted part class is right and that carry a non-zero NPCS
+        target (model.py:398-462); the per-class 3-vector is selected by the predicted class."""
+        sem_preds, sem_labels = proposals.sem_preds, proposals.sem_labels
+        valid = (sem_preds == sem_labels) & (gt_npcs != 0).any(dim=-1)
+
+        npcs_logits, gt_npcs = npcs_logits[valid], gt_npcs[valid]
+        sem_preds = sem_preds[valid].long()
+        proposal_indices = proposals.proposal_indices[valid]
+
+        per_class = npcs_logits.reshape(npcs_logits.shape[0], -1, 3)
+        npcs_preds = per_class.gather(1, (sem_preds - 1)[:, None, None].expand(-1, 1, 3)).squeeze(1)
+
+        proposals.npcs_preds = npcs_preds.detach()
+        proposals.gt_npcs = gt_npcs
+        proposals.npcs_valid_mask = valid
+
+        dev = sem_preds.device
+        self.symmetry_indices = self.symmetry_indices.to(dev)
+        self.symmetry_matrix_1 = self.symmetry_matrix_1.to(dev)
+        self.symmetry_matrix_2 = self.symmetry_matrix_2.to(dev)
+        self.symmetry_matrix_3 = self.symmetry_matrix_3.to(dev)
+        sym = self.symmetry_indices[sem_preds]
+
+        loss = 0
+        # (mask of the group, table of its matrices, index offset inside the table)
+        for mask, table, base in ((sym < 3, self.symmetry_matrix_1, 0), (sym == 3, self.symmetry_matrix_2, 3),
+                                  (sym == 4, self.symmetry_matrix_3, 4)):
+            members = sym[mask]
+            if members.shape[0] > 0:
+                loss = loss + compute_npcs_loss(npcs_preds[mask], gt_npcs[mask], proposal_indices[mask],
+                                                table[members - base])
+        return loss
+
+    # ------------------------------------------------------------------------------------------ one step
+    def _collate(self, point_clouds: Union[Sequence[PointCloud], PointCloudBatch]) -> PointCloudBatch:
+        if isinstance(point_clouds, PointCloudBatch):
+            return point_clouds
+        return PointCloud.collate(point_clouds, voxel_size=self.voxel_size)
+
+    def _training_or_validation_step(self, point_clouds, batch_idx: int, running_mode: str):
+        data_batch = self._collate(point_clouds)
+        batch_size = data_batch.batch_size
+        points = data_batch.points
+        sem_labels = data_batch.sem_labels
+        instance_regions = data_batch.instance_regions
+        instance_labels = data_batch.instance_labels
+        num_points_per_instance = data_batch.num_points_per_instance
+        gt_npcs = data_batch.gt_npcs
+        pt_xyz = points[:, :3]
+
+        pc_feature = self.forward_backbone(pc_batch=data_batch)
+
+        # semantic segmentation
+        sem_logits = self.forward_sem_seg(pc_feature)
+        sem_preds = torch.argmax(sem_logits.detach(), dim=-1)
+        loss_sem_seg = self.loss_sem_seg(sem_logits, sem_labels) if sem_labels is not None else 0.0
+        all_accu = (sem_preds == sem_labels).sum().float() / sem_labels.shape[0]
+        if sem_labels is not None:
+            on_part = sem_labels > 0
+            pixel_accu = pixel_accuracy(sem_preds[on_part], sem_labels[on_part])
+        else:
+            pixel_accu = 0.0
+        sem_seg = Segmentation(batch_size=batch_size, sem_preds=sem_preds, sem_labels=sem_labels, all_accu=all_accu,
+                               pixel_accu=pixel_accu)
+
+        # centre offsets
+        offsets_preds = self.forward_offset(pc_feature)
+        if instance_regions is None:
+            raise RuntimeError("batch carries no instance_regions (the reference stops in pdb here, model.py:525)")
+        loss_offset_dist, loss_offset_dir = self.loss_offset(offsets_preds, instance_regions[:, :3] - pt_xyz, sem_labels,
+                                                             instance_labels)
+
+        # proposals
+        voxel_tensor = pc_voxel_id = proposals = None
+        if self.current_epoch >= self.start_clustering:
+            voxel_tensor, pc_voxel_id, proposals = self.proposal_clustering_and_revoxelize(
+                pt_xyz=pt_xyz, batch_indices=data_batch.batch_indices, pt_features=pc_feature, sem_preds=sem_preds,
+                offset_preds=offsets_preds, instance_labels=instance_labels)
+            if proposals is not None:
+                if sem_labels is not None:
+                    proposals.sem_labels = sem_labels[proposals.valid_mask][proposals.sorted_indices]
+                proposals.instance_sem_labels = data_batch.instance_sem_labels
+
+        loss_prop_score = 0.0
+        if self.current_epoch >= self.start_scorenet and voxel_tensor is not None and proposals is not None:
+            score_logits = self.forward_proposal_score(voxel_tensor, pc_voxel_id, proposals)
+            first_point = proposals.proposal_offsets[:-1].long()
+            cls_source = proposals.sem_labels if proposals.sem_labels is not None else proposals.sem_preds
+            proposal_cls = cls_source[first_point].long()
+            score_logits = score_logits.gather(1, proposal_cls[:, None] - 1).squeeze(1)
+            proposals.score_preds = score_logits.detach().sigmoid()
+            if num_points_per_instance is None:
+                raise RuntimeError("batch carries no num_points_per_instance (reference: pdb, model.py:567)")
+            loss_prop_score = self.loss_proposal_score(score_logits, proposals, num_points_per_instance)
+
+        loss_prop_npcs = 0.0
+        if self.current_epoch >= self.start_npcs and voxel_tensor is not None:
+            npcs_logits = self.forward_proposal_npcs(voxel_tensor, pc_voxel_id)
+            if gt_npcs is not None:
+                gt_npcs = gt_npcs[proposals.valid_mask][proposals.sorted_indices]
+                loss_prop_npcs = self.loss_proposal_npcs(npcs_logits, gt_npcs, proposals)
+
+        loss = loss_sem_seg + loss_offset_dist + loss_offset_dir + loss_prop_score + loss_prop_npcs
+
+        prefix = running_mode
+        for key, value in ((f"{prefix}_loss/total_loss", loss), (f"{prefix}_loss/loss_sem_seg", loss_sem_seg),
+                           (f"{prefix}_loss/loss_offset_dist", loss_offset_dist),
+                           (f"{prefix}_loss/loss_offset_dir", loss_offset_dir),
+                           (f"{prefix}_loss/loss_prop_score", loss_prop_score),
+                           (f"{prefix}_loss/loss_prop_npcs", loss_prop_npcs), (f"{prefix}/all_accu", all_accu * 100),
+                           (f"{prefix}/pixel_accu", pixel_accu * 100)):
+            self.log(key, value, batch_size=batch_size, on_epoch=True, prog_bar=False, logger=True, sync_dist=True)
+        return data_batch.pc_ids, sem_seg, proposals, loss
+
+    # ------------------------------------------------------------------------------------------ Lightning hooks
+    def training_step(self, point_clouds, batch_idx: int):
+        return self._training_or_validation_step(point_clouds, batch_idx, "train")[3]
+
+    def _post_process(self, proposals: Instances) -> Instances:
+        proposals = filter_invalid_proposals(proposals, score_threshold=self.val_score_threshold,
+                                             min_num_points_per_proposal=self.val_min_num_points_per_proposal)
+        proposals = apply_nms(proposals, self.val_nms_iou_threshold)
+        proposals.pt_sem_classes = proposals.sem_preds[proposals.proposal_offsets[:-1].long()]
+        return proposals
+
+    def _stash(self, dataloader_idx: int, item) -> None:
+        while dataloader_idx > len(self.validation_step_outputs) - 1:
+            self.validation_step_outputs.append([])
+        self.validation_step_outputs[dataloader_idx].append(item)
+
+    def validation_step(self, point_clouds, batch_idx: int, dataloader_idx: int = 0):
+        pc_ids, sem_seg, proposals, _ = self._training_or_validation_step(point_clouds, batch_idx, _SPLITS[dataloader_idx])
+        kept = None
+        if self.current_epoch >= self.start_scorenet and proposals is not None:
+            p = self._post_process(proposals)
+            kept = Instances(score_preds=p.score_preds, pt_sem_classes=p.pt_sem_classes, batch_indices=p.batch_indices,
+                             instance_sem_labels=p.instance_sem_labels, ious=p.ious,
+                             proposal_offsets=p.proposal_offsets, valid_mask=p.valid_mask)
+        self._stash(dataloader_idx, (pc_ids, sem_seg, kept))
+        return pc_ids, sem_seg, kept
+
+    def test_step(self, point_clouds, batch_idx: int, dataloader_idx: int = 0):
+        pc_ids, sem_seg, proposals, _ = self._training_or_validation_step(
+            point_clouds, batch_idx, ["val", "intra", "inter"][dataloader_idx])
+        kept = None
+        if proposals is not None and proposals.score_preds is not None:  # the reference dereferences None here (model.py:825)
+            p = self._post_process(proposals)
+            kept = Instances(pt_xyz=p.pt_xyz, score_preds=p.score_preds, pt_sem_classes=p.pt_sem_classes,
+                             batch_indices=p.batch_indices, instance_sem_labels=p.instance_sem_labels, ious=p.ious,
+                             proposal_offsets=p.proposal_offsets, proposal_indices=p.proposal_indices,
+                             valid_mask=p.valid_mask, num_points_per_proposal=p.num_points_per_proposal,
+                             num_points_per_instance=p.num_points_per_instance, sorted_indices=p.sorted_indices,
+                             npcs_preds=p.npcs_preds, npcs_valid_mask=p.npcs_valid_mask)
+        self._stash(dataloader_idx, (pc_ids, sem_seg, kept))
+        return pc_ids, sem_seg, kept
+
+    def _epoch_end_metrics(self) -> None:
+        """semantic accuracy / mIoU and instance AP@50 / mAP(0.50:0.05:0.95) per split, plus the monitor_metrics means of
+        the two test splits (model.py:694-805, 859-1046)."""
+        all_accus, pixel_accus, mious, mean_ap50, mAPs = [], [], [], [], []
+        data_size = 0
+        for split, outputs in zip(_SPLITS, self.validation_step_outputs):
+            if len(outputs) == 0:
+                continue
+            data_size = sum(x[1].batch_size for x in outputs)
+            all_accu = sum(x[1].all_accu for x in outputs) / len(outputs)
+            pixel_accu = sum(x[1].pixel_accu for x in outputs) / len(outputs)
+            sem_preds = torch.cat([x[1].sem_preds for x in outputs], dim=0)
+            sem_labels = torch.cat([x[1].sem_labels for x in outputs], dim=0)
+            miou = mean_iou(sem_preds, sem_labels, num_classes=self.num_part_classes)
+            proposals = [x[2] for x in outputs if x[2] is not None]
+            with_instances = self.current_epoch >= self.start_scorenet and len(proposals) > 0
+
+            thresholds = [0.5 + 0.05 * i for i in range(10)]
+            aps = [compute_ap(proposals, self.num_part_classes, t) if with_instances else 0 for t in thresholds]
+            ap50 = aps[0]
+            mAP = float(np.array(aps).mean())
+
+            log = functools.partial(self.log, batch_size=data_size, on_epoch=True, logger=True, sync_dist=True)
+            if with_instances:
+                for class_idx in range(1, self.num_part_classes):
+                    log(f"{split}/AP@50_{PART_ID2NAME[class_idx]}", float(np.mean(ap50[class_idx - 1])) * 100, prog_bar=False)
+            log(f"{split}/AP@50", float(np.mean(ap50)) * 100, prog_bar=True)
+            log(f"{split}/mAP", mAP * 100, prog_bar=True)
+            log(f"{split}/all_accu", all_accu * 100.0, prog_bar=False)
+            log(f"{split}/pixel_accu", pixel_accu * 100.0, prog_bar=False)
+            log(f"{split}/miou", miou * 100.0, prog_bar=True)
+            all_accus.append(all_accu); pixel_accus.append(pixel_accu); mious.append(miou)
+            mean_ap50.append(float(np.mean(ap50))); mAPs.append(mAP)
+
+        if len(all_accus) == 3:  # the monitor is the mean of test_intra / test_inter and needs all three loaders
+            log = functools.partial(self.log, batch_size=data_size, on_epoch=True, logger=True, sync_dist=True)
+            log("monitor_metrics/mean_all_accu", (all_accus[1] + all_accus[2]) / 2 * 100.0, prog_bar=False)
+            log("monitor_metrics/mean_pixel_accu", (pixel_accus[1] + pixel_accus[2]) / 2 * 100.0, prog_bar=False)
+            log("monitor_metrics/mean_imou", (mious[1] + mious[2]) / 2 * 100.0, prog_bar=True)
+            log("monitor_metrics/mean_AP@50", (mean_ap50[1] + mean_ap50[2]) / 2 * 100.0, prog_bar=True)
+            log("monitor_metrics/mean_mAP", (mAPs[1] + mAPs[2]) / 2 * 100.0, prog_bar=True)
+        self.validation_step_outputs.clear()
+
+    def on_validation_epoch_end(self):
+        self._epoch_end_metrics()
+
+    def on_test_epoch_end(self):
+        if self.visualize_cfg.get("visualize", False):
+            print("[gapartnet_amd] visualisation / pose rendering of on_test_epoch_end is outside the accelerated hot "
+                  "path (SURVEY.md §2.1 #10) and is skipped; metrics are computed as in validation")
+        self._epoch_end_metrics()
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=self.learning_rate)

@@ -1,0 +1,66 @@
+"""Smoke test used by ``__graft_entry__.smoke()``: one small full-pipeline train step on the GPU, checked against the
+same step run through the CPU oracle (``oracle.torch_ops``; the oracle is the checker here, never the product path)."""
+import copy
+
+import torch
+
+from . import backend
+
+DEFAULT_CFG = dict(
+    in_channels=6, num_part_classes=10, backbone_type="SparseUNet",
+    backbone_cfg=dict(channels=[16, 32, 48, 64, 80, 96, 112], block_repeat=2),
+    instance_seg_cfg=dict(ball_query_radius=0.04, max_num_points_per_query=50, min_num_points_per_proposal=5,
+                          max_num_points_per_query_shift=300, score_fullscale=28, score_scale=50),
+    learning_rate=1e-3, ignore_sem_label=-100, use_sem_focal_loss=True, use_sem_dice_loss=True,
+    training_schedule=[5, 10], val_nms_iou_threshold=0.3, val_ap_iou_threshold=0.5,
+    symmetry_indices=[0, 1, 3, 3, 2, 0, 3, 2, 4, 1], visualize_cfg=dict(visualize=False), debug=True)
+
+
+def make_model(training_schedule=(0, 0), channels=None, seed: int = 0):
+    from .network.model import GAPartNet
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["training_schedule"] = list(training_schedule)
+    if channels is not None:
+        cfg["backbone_cfg"]["channels"] = list(channels)
+    torch.manual_seed(seed)
+    return GAPartNet(**cfg)
+
+
+def make_batch(n_scenes: int, n_points: int, seed0: int = 1000):
+    from .dataset.gapartnet import SyntheticGAPartNetDataset
+    ds = SyntheticGAPartNetDataset(n_scenes, n_points=n_points, seed0=seed0)
+    return [ds[i] for i in range(n_scenes)]
+
+
+def run_smoke(device: torch.device, n_scenes: int = 2, n_points: int = 4000, tol: float = 2e-3) -> dict:
+    from oracle import torch_ops as oracle_ops  # checker only
+
+    model = make_model((0, 0), channels=[16, 32, 48, 64])
+    jitter = (torch.tensor([0.3, 0.6, 0.1]), torch.tensor([0.5, 0.2, 0.9]))
+    batch = make_batch(n_scenes, n_points)
+
+    ref_model = copy.deepcopy(model)
+    ref_model.revoxelize_jitter = jitter
+    with backend.using(oracle_ops):
+        ref_loss = ref_model.training_step(batch, 0)
+        ref_loss.backward()
+
+    model = model.to(device)
+    model.revoxelize_jitter = tuple(j.to(device) for j in jitter)
+    loss = model.training_step([pc.to(device) for pc in batch], 0)
+    loss.backward()
+    torch.cuda.synchronize(device)
+
+    got, want = float(loss), float(ref_loss)
+    assert abs(got - want) <= tol * max(1.0, abs(want)), f"smoke: loss {got} vs oracle {want}"
+    worst = 0.0
+    for (name, p), (_, q) in zip(model.named_parameters(), ref_model.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        err = float((p.grad.cpu() - q.grad).abs().max())
+        scale = float(q.grad.abs().max()) + 1e-6
+        worst = max(worst, err / scale)
+    assert worst < 5e-2, f"smoke: gradient mismatch vs oracle, worst relative error {worst}"
+    print(f"smoke ok: loss {got:.6f} (oracle {want:.6f}), worst relative grad error {worst:.2e}")
+    return dict(loss=got, oracle_loss=want, worst_grad_rel_err=worst)

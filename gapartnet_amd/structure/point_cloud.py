@@ -1,0 +1,160 @@
+"""Scene containers and the batch collate that builds the SparseConvTensor
+(reference: gapartnet/structure/point_cloud.py:9-189) — same class / field names.
+
+Two ways to reach a batch:
+  * reference contract: every PointCloud already carries ``voxel_features / voxel_coords / voxel_coords_range /
+    pc_voxel_id`` (produced per scene by dataset.apply_voxelization); collate concatenates them.
+  * MI355X path: scenes arrive un-voxelised on the device and ``collate(..., voxel_size=...)`` voxelises the WHOLE
+    batch with one kernel-V call (per-scene ranges, scene id = key segment).  Because voxels are ordered by
+    (scene, x, y, z) the result is identical to voxelising each scene and concatenating.
+"""
+from dataclasses import dataclass, fields
+from typing import Any, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .. import backend
+from ..spconv import pytorch as spconv
+
+
+@dataclass
+class PointCloudBatch:
+    pc_ids: List[str]
+    points: torch.Tensor
+    batch_indices: torch.Tensor
+    batch_size: int
+    device: Any = None
+    # voxels
+    voxel_tensor: Any = None
+    pc_voxel_id: Any = None
+    pc_voxel_csr: Any = None  # (order, starts): points grouped by voxel, for the deterministic gather backward
+    # semantics
+    sem_labels: Optional[torch.Tensor] = None
+    obj_cls_labels: Optional[torch.Tensor] = None
+    # instances
+    instance_labels: Optional[torch.Tensor] = None
+    num_instances: Optional[List[int]] = None
+    instance_regions: Optional[torch.Tensor] = None
+    num_points_per_instance: Optional[torch.Tensor] = None
+    instance_sem_labels: Optional[torch.Tensor] = None
+    # npcs
+    gt_npcs: Optional[torch.Tensor] = None
+
+
+@dataclass
+class PointCloud:
+    pc_id: str
+    points: Union[torch.Tensor, np.ndarray]
+    obj_cat: int = -1
+    sem_labels: Optional[Union[torch.Tensor, np.ndarray]] = None
+    instance_labels: Optional[Union[torch.Tensor, np.ndarray]] = None
+    gt_npcs: Optional[Union[torch.Tensor, np.ndarray]] = None
+    num_instances: Optional[int] = None
+    # per point, for the instance the point belongs to: [0:3] mean xyz, [3:6] min xyz, [6:9] max xyz
+    # (column order as written by dataset.generate_inst_info; only [:, :3] is consumed, model.py:520)
+    instance_regions: Optional[Union[torch.Tensor, np.ndarray]] = None
+    num_points_per_instance: Optional[Union[torch.Tensor, np.ndarray]] = None
+    instance_sem_labels: Optional[Union[torch.Tensor, np.ndarray]] = None
+    voxel_features: Optional[torch.Tensor] = None
+    voxel_coords: Optional[torch.Tensor] = None
+    voxel_coords_range: Optional[List[int]] = None
+    pc_voxel_id: Optional[torch.Tensor] = None
+
+    def to_dict(self) -> Dict[str, Any]:
+        return {f.name: getattr(self, f.name) for f in fields(self)}
+
+    def to_tensor(self) -> "PointCloud":
+        return PointCloud(**{k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v)
+                             for k, v in self.to_dict().items()})
+
+    def to(self, device) -> "PointCloud":
+        return PointCloud(**{k: (v.to(device) if isinstance(v, torch.Tensor) else v)
+                             for k, v in self.to_dict().items()})
+
+    # -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def collate(point_clouds: Sequence["PointCloud"], voxel_size: Optional[Sequence[float]] = None) -> PointCloudBatch:
+        n_scenes = len(point_clouds)
+        first = point_clouds[0]
+        device = first.points.device
+        counts = [int(pc.points.shape[0]) for pc in point_clouds]
+
+        def cat(attr):
+            if getattr(first, attr) is None:
+                return None
+            return torch.cat([getattr(pc, attr) for pc in point_clouds], dim=0)
+
+        points = cat("points")
+        batch_indices = torch.repeat_interleave(
+            torch.arange(n_scenes, dtype=torch.int32, device=device),
+            torch.as_tensor(counts, dtype=torch.int64, device=device))
+
+        num_instances = num_points_per_instance = instance_sem_labels = None
+        if first.num_instances is not None:
+            num_instances = [int(pc.num_instances) for pc in point_clouds]
+            width = max(num_instances)
+            num_points_per_instance = torch.zeros((n_scenes, width), dtype=torch.int32, device=device)
+            instance_sem_labels = torch.full((n_scenes, width), -1, dtype=torch.int32, device=device)
+            for row, pc in enumerate(point_clouds):
+                num_points_per_instance[row, :pc.num_instances] = pc.num_points_per_instance
+                instance_sem_labels[row, :pc.num_instances] = pc.instance_sem_labels
+
+        csr = None
+        if first.voxel_coords is not None:
+            # reference contract: concatenate per-scene voxelisations (structure/point_cloud.py:139-170)
+            n_vox = [int(pc.voxel_coords.shape[0]) for pc in point_clouds]
+            scene_of_voxel = torch.repeat_interleave(
+                torch.arange(n_scenes, dtype=torch.int32, device=device),
+                torch.as_tensor(n_vox, dtype=torch.int64, device=device))
+            coords = torch.cat([pc.voxel_coords for pc in point_clouds], dim=0).to(torch.int32)
+            indices = torch.cat([scene_of_voxel[:, None], coords], dim=1).contiguous()
+            voxel_features = torch.cat([pc.voxel_features for pc in point_clouds], dim=0)
+            spatial_shape = np.max([pc.voxel_coords_range for pc in point_clouds], axis=0).tolist()
+            shifted, start = [], 0
+            for pc, nv in zip(point_clouds, n_vox):
+                ids = pc.pc_voxel_id
+                shifted.append(torch.where(ids >= 0, ids + start, ids))  # out of place (the reference mutates the scene)
+                start += nv
+            pc_voxel_id = torch.cat(shifted, dim=0)
+        else:
+            assert voxel_size is not None, "un-voxelised scenes need voxel_size"
+            indices, voxel_features, spatial_shape, pc_voxel_id, csr = voxelize_scenes(points[:, :3], points, counts, voxel_size)
+
+        voxel_tensor = spconv.SparseConvTensor(voxel_features, indices, spatial_shape, n_scenes)
+        return PointCloudBatch(
+            pc_ids=[pc.pc_id for pc in point_clouds], points=points, batch_indices=batch_indices,
+            batch_size=n_scenes, device=device, voxel_tensor=voxel_tensor, pc_voxel_id=pc_voxel_id,
+            pc_voxel_csr=csr, sem_labels=cat("sem_labels"),
+            obj_cls_labels=torch.tensor([pc.obj_cat for pc in point_clouds]),
+            instance_labels=cat("instance_labels"), num_instances=num_instances,
+            instance_regions=cat("instance_regions"), num_points_per_instance=num_points_per_instance,
+            instance_sem_labels=instance_sem_labels, gt_npcs=cat("gt_npcs"))
+
+
+@torch.no_grad()
+def voxelize_scenes(xyz: torch.Tensor, feats: torch.Tensor, counts: Sequence[int], voxel_size: Sequence[float]):
+    """Batched scene voxelisation with the reference's per-scene conventions (dataset/gapartnet.py:179-205):
+    range = [min - 1e-4, max + 1e-4] per scene, spatial extent per scene = (max coord + 1).clamp(min=128), batch
+    extent = elementwise max over scenes.  One kernel-V launch sequence for the whole batch; one host sync."""
+    device = xyz.device
+    n_scenes = len(counts)
+    offsets = torch.zeros((n_scenes + 1,), dtype=torch.int64)
+    offsets[1:] = torch.as_tensor(counts, dtype=torch.int64).cumsum(0)
+    offsets_dev = offsets.to(device)
+    seg = torch.repeat_interleave(torch.arange(n_scenes, device=device), torch.as_tensor(counts, device=device))
+    big = torch.finfo(torch.float32).max
+    lo = torch.full((n_scenes, 3), big, dtype=torch.float32, device=device).scatter_reduce_(
+        0, seg[:, None].expand(-1, 3), xyz, reduce="amin", include_self=True)
+    hi = torch.full((n_scenes, 3), -big, dtype=torch.float32, device=device).scatter_reduce_(
+        0, seg[:, None].expand(-1, 3), xyz, reduce="amax", include_self=True)
+    rmin, rmax = lo - 1e-4, hi + 1e-4
+    vs = torch.as_tensor(list(voxel_size), dtype=torch.float32, device=device)
+    cells = (torch.floor((rmax - rmin) / vs).max(0)[0].to(torch.int64) + 2).tolist()  # host sync #1 (3 ints)
+    out = backend.raw().voxelize(xyz, feats, offsets_dev, rmin, rmax, [float(v) for v in voxel_size], cells,
+                                 want_csr=True)
+    vf, vc, vseg, pid, order, starts = out
+    indices = torch.cat([vseg[:, None], vc], dim=1).contiguous()
+    # (max coord + 1).clamp(min=128) per scene then max over scenes == max over the batch, clamped
+    spatial_shape = (vc.max(0)[0].to(torch.int64) + 1).clamp(min=128).tolist() if vc.shape[0] > 0 else [128] * 3
+    return indices, vf, spatial_shape, pid, (order, starts)
