@@ -18,7 +18,10 @@ except Exception:  # ModuleNotFoundError and friends
 
 
 class _AttrDict(dict):
-    __getattr__ = dict.get
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return self.get(k)
 
     def __setattr__(self, k, v):
         self[k] = v
