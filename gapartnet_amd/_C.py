@@ -36,6 +36,9 @@ def lib():
             raise GpnError(
                 f"{SO_PATH} is missing: the HIP extension has not been built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+        # torch first: it brings its own libamdhip64; loading ours before it would put two HIP runtimes in the
+        # process (kernel launches then fail with "no ROCm-capable device")
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(SO_PATH)
         _lib.gpn_last_error.restype = ctypes.c_char_p
         _lib.gpn_entry_point_name.restype = ctypes.c_char_p
