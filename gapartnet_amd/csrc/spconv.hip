@@ -49,115 +49,137 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int K, int cin_
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused gather-MFMA-scatter conv.  blockDim = 256 (4 independent waves), wave tile = 32*TM rows.
-template <int NT, int TM>
+// fused gather-MFMA-scatter conv.  blockDim = 256 = 4 independent waves; a wave owns (wave tile of 32*TM dst rows)
+// x (column group of NTW 16-wide output tiles) and streams the tile's flat block list (rulebook.hip): every block is 16
+// (src, local dst) pairs of ONE tap.  The loop is software-pipelined so the two dependent global loads of a block
+// (its pair entries, then the gathered rows) are in flight while the previous block's MFMAs run:
+//   entries of block b+2  and  A rows of the next 64-channel chunk  are requested before block b's contraction.
+template <int NTW, int TM>
 __global__ __launch_bounds__(256) void spconv_fwd_kernel(
-    const float* __restrict__ in, const float* __restrict__ packed, const int32_t* __restrict__ pair_src,
-    const int32_t* __restrict__ pair_dst, const int32_t* __restrict__ tile_off, int K, int64_t n_dst,
-    int64_t n_tiles, int cin, float* __restrict__ out) {
-  constexpr int COUT = NT * 16;
-  constexpr int LDW = COUT + 16;  // +16 floats: rows an odd distance apart land on disjoint bank halves
+    const float* __restrict__ in, const float* __restrict__ packed, const int32_t* __restrict__ blk_src,
+    const int32_t* __restrict__ blk_meta, const int32_t* __restrict__ blk_off, int K, int64_t n_dst, int64_t n_wtiles,
+    int cin, int nt_total, float* __restrict__ out) {
+  constexpr int LDW = NTW * 16 + 16;  // +16 floats: rows an odd distance apart land on disjoint bank halves
   constexpr int ROWS = 32 * TM;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   float* acc_lds = smem + (size_t)wave * ROWS * LDW;
 
-  const int64_t wtile = (int64_t)blockIdx.x * 4 + wave;  // wave-tile index
-  const int64_t t0 = wtile * TM;                         // first 32-row tile
-  if (t0 >= n_tiles) return;
-  const int64_t t1 = (t0 + TM < n_tiles) ? (t0 + TM) : n_tiles;
-  const int64_t row0 = t0 * GPN_TILE_ROWS;
+  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+  if (w >= n_wtiles) return;
+  const int nt0 = blockIdx.y * NTW;
+  const int ntw = (nt_total - nt0 < NTW) ? (nt_total - nt0) : NTW;
+  const int64_t row0 = w * ROWS;
+  const int cout = nt_total * 16;
 
-  // zero the accumulator tile
   for (int e = lane * 4; e < ROWS * LDW; e += 64 * 4) *reinterpret_cast<f32x4*>(acc_lds + e) = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int i16 = lane & 15, g = lane >> 4;
   const int CB = cin >> 4;
+  const int NCH = (CB + 3) >> 2;  // 64-channel chunks per block
   const f32x4* __restrict__ pw = reinterpret_cast<const f32x4*>(packed);
+  const int32_t b0 = blk_off[w * K], b1 = blk_off[(w + 1) * K];
 
-  for (int k = 0; k < K; ++k) {
-    const int32_t p_begin = tile_off[(int64_t)k * (n_tiles + 1) + t0];
-    const int32_t p_end = tile_off[(int64_t)k * (n_tiles + 1) + t1];
-    for (int32_t p0 = p_begin; p0 < p_end; p0 += 16) {
-      const int32_t p = p0 + i16;
-      const bool valid = p < p_end;
-      const int32_t src = valid ? pair_src[p] : 0;
-      const int32_t dstl = valid ? (int32_t)(pair_dst[p] - row0) : -1;
-      const float* arow = in + (int64_t)src * cin + 4 * g;
-      f32x4 acc[NT];
+  auto load_entry = [&](int32_t b, int32_t& src, int32_t& meta) {
+    src = -1; meta = -1;
+    if (b < b1) {
+      src = blk_src[(int64_t)b * 16 + i16];
+      meta = blk_meta[(int64_t)b * 16 + i16];
+    }
+  };
+  auto load_a = [&](int32_t src, int ch, f32x4 (&a)[4]) {
+    const float* arow = in + (int64_t)src * cin + ch * 64 + 4 * g;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int cb = 0; cb < CB; ++cb) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (valid) a = *reinterpret_cast<const f32x4*>(arow + cb * 16);
-        const f32x4* wrow = pw + ((int64_t)(k * CB + cb) * NT) * 64 + lane;
+    for (int c = 0; c < 4; ++c) {
+      a[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (src >= 0 && ch * 4 + c < CB) a[c] = *reinterpret_cast<const f32x4*>(arow + c * 16);
+    }
+  };
+
+  int32_t src_cur, meta_cur, src_nxt, meta_nxt;
+  load_entry(b0, src_cur, meta_cur);
+  load_entry(b0 + 1, src_nxt, meta_nxt);
+  f32x4 a_cur[4], a_nxt[4];
+  load_a(src_cur, 0, a_cur);
+
+  for (int32_t b = b0; b < b1; ++b) {
+    int32_t src_nn, meta_nn;
+    load_entry(b + 2, src_nn, meta_nn);
+    const int tap = __builtin_amdgcn_readfirstlane(meta_cur) >> 8;  // entry 0 of a block is always valid
+    f32x4 acc[NTW];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const f32x4 b = wrow[nt * 64];
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nt], 0, 0, 0);
+    for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (ch + 1 < NCH) load_a(src_cur, ch + 1, a_nxt);
+      else load_a(src_nxt, 0, a_nxt);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int cb = ch * 4 + c;
+        if (cb < CB) {
+          const f32x4* wrow = pw + ((int64_t)(tap * CB + cb) * nt_total + nt0) * 64 + lane;
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            if (nt < ntw) {
+              const f32x4 bf = wrow[nt * 64];
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c].x, bf.x, acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c].y, bf.y, acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c].z, bf.z, acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c].w, bf.w, acc[nt], 0, 0, 0);
+            }
+          }
         }
       }
-      // D[row = 4g + r][col = i16] belongs to pair p0 + 4g + r, whose local dst row lane (4g+r) holds
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = __shfl(dstl, 4 * g + r, 64);
-        if (row >= 0) {
-          float* dstp = acc_lds + row * LDW + i16;
+      for (int c = 0; c < 4; ++c) a_cur[c] = a_nxt[c];
+    }
+    // D[row = 4g + r][col = i16] belongs to pair 4g + r of the block, whose local dst row lane (4g + r) holds
+    const int dstl = meta_cur >= 0 ? (meta_cur & 0xff) : -1;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) dstp[nt * 16] += acc[nt][r];
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int row = __shfl(dstl, 4 * g + r, 64);
+      if (row >= 0) {
+        float* dstp = acc_lds + row * LDW + i16;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+          if (nt < ntw) dstp[nt * 16] += acc[nt][r];
       }
     }
+    src_cur = src_nxt; meta_cur = meta_nxt;
+    src_nxt = src_nn; meta_nxt = meta_nn;
   }
 
-  // write the tile: COUT/4 float4 per row
+  // write this wave's columns of the tile: ntw*4 float4 per row
   const int64_t rows_here = (n_dst - row0 < ROWS) ? (n_dst - row0) : ROWS;
-  constexpr int V4 = COUT / 4;
-  for (int e = lane; e < (int)rows_here * V4; e += 64) {
-    const int r = e / V4, c4 = e - r * V4;
-    *reinterpret_cast<f32x4*>(out + (row0 + r) * COUT + c4 * 4) =
+  const int v4 = ntw * 4;
+  for (int e = lane; e < (int)rows_here * v4; e += 64) {
+    const int r = e / v4, c4 = e - r * v4;
+    *reinterpret_cast<f32x4*>(out + (row0 + r) * cout + nt0 * 16 + c4 * 4) =
         *reinterpret_cast<const f32x4*>(acc_lds + r * LDW + c4 * 4);
   }
 }
 
-template <int NT, int TM>
-int launch_fwd(const float* in, const float* packed, const int32_t* pair_src, const int32_t* pair_dst,
-               const int32_t* tile_off, int K, int64_t n_dst, int cin, float* out, hipStream_t stream) {
+template <int NTW, int TM>
+int launch_fwd(const float* in, const float* packed, const int32_t* blk_src, const int32_t* blk_meta,
+               const int32_t* blk_off, int K, int64_t n_dst, int cin, int nt_total, float* out, hipStream_t stream) {
   const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
   const int64_t n_wtiles = gpn::cdiv(n_tiles, TM);
-  const int grid = (int)gpn::cdiv(n_wtiles, 4);
-  const size_t lds = (size_t)4 * 32 * TM * (NT * 16 + 16) * sizeof(float);
-  auto kfn = spconv_fwd_kernel<NT, TM>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    GPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, in, packed, pair_src, pair_dst, tile_off, K,
-                     n_dst, n_tiles, cin, out);
+  const dim3 grid((unsigned)gpn::cdiv(n_wtiles, 4), (unsigned)gpn::cdiv(nt_total, NTW));
+  const size_t lds = (size_t)4 * 32 * TM * (NTW * 16 + 16) * sizeof(float);
+  hipLaunchKernelGGL((spconv_fwd_kernel<NTW, TM>), grid, dim3(256), lds, stream, in, packed, blk_src, blk_meta,
+                     blk_off, K, n_dst, n_wtiles, cin, nt_total, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
-template <int TM>
-int dispatch_fwd_nt(int nt, const float* in, const float* packed, const int32_t* pair_src,
-                    const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin, float* out,
-                    hipStream_t stream) {
-  switch (nt) {
-#define GPN_CASE(N) \
-  case N: return launch_fwd<N, TM>(in, packed, pair_src, pair_dst, tile_off, K, n_dst, cin, out, stream);
-    GPN_CASE(1) GPN_CASE(2) GPN_CASE(3) GPN_CASE(4) GPN_CASE(5) GPN_CASE(6) GPN_CASE(7) GPN_CASE(8)
-    GPN_CASE(9) GPN_CASE(10) GPN_CASE(11) GPN_CASE(12) GPN_CASE(13) GPN_CASE(14)
-#undef GPN_CASE
-    default:
-      gpn::set_error("gpn_spconv_fwd: cout=%d not supported (must be a multiple of 16, <= 224)", nt * 16);
-      return GPN_ERR_ARG;
+// column tiles per wave: as many as possible (gathered rows are re-read once per column group) while keeping
+// roughly >= 1024 waves in flight (256 CUs x 4 SIMDs)
+int pick_ntw(int nt_total, int64_t n_wtiles) {
+  for (int ntw = 4; ntw > 1; --ntw) {
+    if (ntw > nt_total) continue;
+    if (n_wtiles * gpn::cdiv(nt_total, ntw) >= 1024) return ntw;
   }
+  return 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -341,21 +363,24 @@ extern "C" int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cou
   return GPN_OK;
 }
 
-extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* pair_src,
-                              const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
+extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* blk_src,
+                              const int32_t* blk_meta, const int32_t* blk_off, int K, int64_t n_dst, int tm, int cin,
                               int cout, float* out, gpn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  GPN_CHECK_ARG(K >= 1 && n_dst >= 0);
+  GPN_CHECK_ARG(K >= 1 && n_dst >= 0 && (tm == 1 || tm == 2));
   GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
   if (n_dst == 0) return GPN_OK;
-  GPN_CHECK_ARG(in && packed_w && pair_src && pair_dst && tile_off && out);
+  GPN_CHECK_ARG(in && packed_w && blk_src && blk_meta && blk_off && out);
   const int nt = cout / 16;
-  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
-  // 64-row wave tiles once there are enough of them to fill the chip (256 CUs x 2 workgroups x 4 waves)
-  const bool big = n_tiles >= 2 * 2048 && nt <= 8;
+  const int64_t n_wtiles = gpn::cdiv(gpn::cdiv(n_dst, GPN_TILE_ROWS), tm);
+  const int ntw = pick_ntw(nt, n_wtiles);
   gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
-  if (big) return dispatch_fwd_nt<2>(nt, in, packed_w, pair_src, pair_dst, tile_off, K, n_dst, cin, out, stream);
-  return dispatch_fwd_nt<1>(nt, in, packed_w, pair_src, pair_dst, tile_off, K, n_dst, cin, out, stream);
+#define GPN_FWD(NTW, TM) return launch_fwd<NTW, TM>(in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, out, stream)
+  if (tm == 2) {
+    switch (ntw) { case 1: GPN_FWD(1, 2); case 2: GPN_FWD(2, 2); case 3: GPN_FWD(3, 2); default: GPN_FWD(4, 2); }
+  }
+  switch (ntw) { case 1: GPN_FWD(1, 1); case 2: GPN_FWD(2, 1); case 3: GPN_FWD(3, 1); default: GPN_FWD(4, 1); }
+#undef GPN_FWD
 }
 
 extern "C" size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst) {

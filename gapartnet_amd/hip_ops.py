@@ -60,9 +60,35 @@ class Rulebook:
     n_src: int
     n_dst: int
     num_pairs: torch.Tensor  # 0-dim int64 on device (no host sync)
+    # block-list view streamed by the fused conv kernel (built lazily by hip_ops.ensure_blocks)
+    tm: int = 0
+    blk_src: Optional[torch.Tensor] = None
+    blk_meta: Optional[torch.Tensor] = None
+    blk_off: Optional[torch.Tensor] = None
 
     def pairs_host(self) -> int:
         return int(self.num_pairs.item())
+
+
+def ensure_blocks(rb: "Rulebook") -> "Rulebook":
+    """build (once per rulebook) the padded 16-pair block list the fused conv kernel streams; no host sync."""
+    if rb.blk_off is not None:
+        return rb
+    dev = rb.pair_src.device
+    tm = 2 if rb.n_dst >= 65536 else 1
+    L = _C.lib()
+    L.gpn_rulebook_blocks_capacity.restype = _C.ctypes.c_int64
+    cap = max(int(L.gpn_rulebook_blocks_capacity(i32(rb.K), i64(rb.n_dst), i32(tm))), 1)
+    n_wtiles = (n_tiles(rb.n_dst) + tm - 1) // tm
+    rb.blk_src = torch.empty((cap * 16,), dtype=torch.int32, device=dev)
+    rb.blk_meta = torch.empty((cap * 16,), dtype=torch.int32, device=dev)
+    rb.blk_off = torch.zeros((n_wtiles * rb.K + 1,), dtype=torch.int32, device=dev)
+    ws = _ws(L.gpn_rulebook_blocks_ws_bytes(i32(rb.K), i64(rb.n_dst), i32(tm)), dev)
+    check(L.gpn_rulebook_blocks(ptr(rb.pair_src), ptr(rb.pair_dst), ptr(rb.tile_off), i32(rb.K), i64(rb.n_dst), i32(tm),
+                                ptr(rb.blk_src), ptr(rb.blk_meta), ptr(rb.blk_off), ptr(ws), szt(ws.numel()), _stream()),
+          "gpn_rulebook_blocks")
+    rb.tm = tm
+    return rb
 
 
 # ---------------------------------------------------------------------------------------------------- V
@@ -161,8 +187,9 @@ def _conv_packed(features, packed, rb: Rulebook, cin, cout):
     features = _c(features, torch.float32)
     assert features.shape[0] == rb.n_src and features.shape[1] == cin, (features.shape, rb.n_src, cin)
     out = torch.empty((rb.n_dst, cout), dtype=torch.float32, device=dev)
-    check(_C.lib().gpn_spconv_fwd(ptr(features), ptr(packed), ptr(rb.pair_src), ptr(rb.pair_dst), ptr(rb.tile_off),
-                                  i32(rb.K), i64(rb.n_dst), i32(cin), i32(cout), ptr(out), _stream()),
+    ensure_blocks(rb)
+    check(_C.lib().gpn_spconv_fwd(ptr(features), ptr(packed), ptr(rb.blk_src), ptr(rb.blk_meta), ptr(rb.blk_off),
+                                  i32(rb.K), i64(rb.n_dst), i32(rb.tm), i32(cin), i32(cout), ptr(out), _stream()),
           "gpn_spconv_fwd")
     return out
 

@@ -120,6 +120,16 @@ int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, i
                             int32_t* bwd_src, int32_t* bwd_dst, int32_t* bwd_tile_off, /* dst = fine, cap N */
                             int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream);
 
+/* Block-list view of a rulebook, streamed by gpn_spconv_fwd: the pairs of each (wave tile of 32*tm dst rows, tap)
+ * group padded to a multiple of 16 ("blocks"), ordered wave-tile-major, tap-minor.
+ *   blk_src [16*B] i32 = src row or -1; blk_meta [16*B] i32 = (tap << 8) | (dst row - tile base) or -1;
+ *   blk_off [n_wtiles*K + 1] i32 = first block of group w*K + k.   B <= gpn_rulebook_blocks_capacity(K, n_dst, tm). */
+int64_t gpn_rulebook_blocks_capacity(int K, int64_t n_dst, int tm);
+size_t gpn_rulebook_blocks_ws_bytes(int K, int64_t n_dst, int tm);
+int gpn_rulebook_blocks(const int32_t* pair_src, const int32_t* pair_dst, const int32_t* tile_off, int K,
+                        int64_t n_dst, int tm, int32_t* blk_src, int32_t* blk_meta, int32_t* blk_off, void* ws,
+                        size_t ws_bytes, gpn_stream_t stream);
+
 /* ================================================================================================
  * C — sparse convolution.  replaces the conv forward/backward inside spconv (network/backbone.py).
  * weights: canonical layout W [K, Cin, Cout] row-major fp32 (tap-major).
@@ -128,17 +138,18 @@ int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, i
  *   a SubM conv uses both, dgrad of down/inverse convs uses transpose only.
  *   cin/cout here are the dims of the *packed* operator (after the optional transpose); both must be
  *   multiples of 16.  packed size = K*cin*cout floats.
- * gpn_spconv_fwd: out[dst] = sum_k W_k^T-applied in[src]  (out is fully overwritten; rows with no
- *   pair get zeros).  in [n_src, cin], out [n_dst, cout].
+ * gpn_spconv_fwd: out[dst] = sum_k in[src] @ W_k over the block-list view of a rulebook (out is fully
+ *   overwritten; rows with no pair get zeros).  in [n_src, cin], out [n_dst, cout]; tm as given to
+ *   gpn_rulebook_blocks.
  * gpn_spconv_wgrad: dW[k] = sum_{pairs of k} in[src]^T (x) dout[dst]  -> dW [K, cin, cout] canonical.
  * ================================================================================================ */
 #define GPN_PACK_TRANSPOSE 1
 #define GPN_PACK_REVERSE 2
 int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cout_w, int flags, float* packed,
                             gpn_stream_t stream);
-int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* pair_src,
-                   const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
-                   int cout, float* out, gpn_stream_t stream);
+int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* blk_src, const int32_t* blk_meta,
+                   const int32_t* blk_off, int K, int64_t n_dst, int tm, int cin, int cout, float* out,
+                   gpn_stream_t stream);
 size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst);
 int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
