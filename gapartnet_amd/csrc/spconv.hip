@@ -2,11 +2,11 @@
 // Replaces the gather-GEMM-scatter conv inside spconv (network/backbone.py:19-36,74-90,149-152).
 //
 // Design (MI355X / CDNA4, wave64):
-//  * ONE fused kernel per conv, output-stationary: a wave owns a tile of 32*TM destination rows and
-//    keeps that tile's fp32 accumulators in its private slice of LDS.  For each tap k it walks the
-//    tile's slice of pair list k (rulebook tile_off), 16 pairs per step: the 16 gathered source rows
-//    are the MFMA A operand, the tap's weight slab the B operand, v_mfma_f32_16x16x4_f32 does the
-//    per-rule dense contraction (exact fp32, == an fmaf chain), and the 16x(16*NT) result is added
+//  * ONE fused kernel per conv (spconv_fwd.hip), output-stationary: a wave owns a tile of 32 destination
+//    rows and keeps that tile's fp32 accumulators in its private slice of LDS.  For each tap k it walks
+//    the tile's 16-pair blocks: the 16 gathered source rows are the MFMA A operand, the tap's weight
+//    slab (shared by the workgroup through LDS) the B operand, v_mfma_f32_16x16x4_f32 does the
+//    per-rule dense contraction (exact fp32, == an fmaf chain), and the 16x(16*NTW) result is added
 //    to the owning rows of the LDS tile.  Each output row is written to HBM exactly once — no global
 //    atomics, no separate gather/scatter kernels, deterministic summation order (tap-major).
 //  * A operand straight from global memory with one 16-byte load per lane: lane (i = l&15, g = l>>4)
@@ -46,140 +46,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int K, int cin_
   if (flags & GPN_PACK_TRANSPOSE) v = W[((int64_t)kk * cin_w + co) * cout_w + ci];
   else v = W[((int64_t)kk * cin_w + ci) * cout_w + co];
   packed[t] = v;
-}
-
-// ------------------------------------------------------------------------------------------------
-// fused gather-MFMA-scatter conv.  blockDim = 256 = 4 independent waves; a wave owns (wave tile of 32*TM dst rows)
-// x (column group of NTW 16-wide output tiles) and streams the tile's flat block list (rulebook.hip): every block is 16
-// (src, local dst) pairs of ONE tap.  The loop is software-pipelined so the two dependent global loads of a block
-// (its pair entries, then the gathered rows) are in flight while the previous block's MFMAs run:
-//   entries of block b+2  and  A rows of the next 64-channel chunk  are requested before block b's contraction.
-template <int NTW, int TM>
-__global__ __launch_bounds__(256) void spconv_fwd_kernel(
-    const float* __restrict__ in, const float* __restrict__ packed, const int32_t* __restrict__ blk_src,
-    const int32_t* __restrict__ blk_meta, const int32_t* __restrict__ blk_off, int K, int64_t n_dst, int64_t n_wtiles,
-    int cin, int nt_total, float* __restrict__ out) {
-  constexpr int LDW = NTW * 16 + 16;  // +16 floats: rows an odd distance apart land on disjoint bank halves
-  constexpr int ROWS = 32 * TM;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  float* acc_lds = smem + (size_t)wave * ROWS * LDW;
-
-  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-  if (w >= n_wtiles) return;
-  const int nt0 = blockIdx.y * NTW;
-  const int ntw = (nt_total - nt0 < NTW) ? (nt_total - nt0) : NTW;
-  const int64_t row0 = w * ROWS;
-  const int cout = nt_total * 16;
-
-  for (int e = lane * 4; e < ROWS * LDW; e += 64 * 4) *reinterpret_cast<f32x4*>(acc_lds + e) = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int i16 = lane & 15, g = lane >> 4;
-  const int CB = cin >> 4;
-  const int NCH = (CB + 3) >> 2;  // 64-channel chunks per block
-  const f32x4* __restrict__ pw = reinterpret_cast<const f32x4*>(packed);
-  const int32_t b0 = blk_off[w * K], b1 = blk_off[(w + 1) * K];
-
-  auto load_entry = [&](int32_t b, int32_t& src, int32_t& meta) {
-    src = -1; meta = -1;
-    if (b < b1) {
-      src = blk_src[(int64_t)b * 16 + i16];
-      meta = blk_meta[(int64_t)b * 16 + i16];
-    }
-  };
-  auto load_a = [&](int32_t src, int ch, f32x4 (&a)[4]) {
-    const float* arow = in + (int64_t)src * cin + ch * 64 + 4 * g;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      a[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (src >= 0 && ch * 4 + c < CB) a[c] = *reinterpret_cast<const f32x4*>(arow + c * 16);
-    }
-  };
-
-  int32_t src_cur, meta_cur, src_nxt, meta_nxt;
-  load_entry(b0, src_cur, meta_cur);
-  load_entry(b0 + 1, src_nxt, meta_nxt);
-  f32x4 a_cur[4], a_nxt[4];
-  load_a(src_cur, 0, a_cur);
-
-  for (int32_t b = b0; b < b1; ++b) {
-    int32_t src_nn, meta_nn;
-    load_entry(b + 2, src_nn, meta_nn);
-    const int tap = __builtin_amdgcn_readfirstlane(meta_cur) >> 8;  // entry 0 of a block is always valid
-    f32x4 acc[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < NCH; ++ch) {
-      if (ch + 1 < NCH) load_a(src_cur, ch + 1, a_nxt);
-      else load_a(src_nxt, 0, a_nxt);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int cb = ch * 4 + c;
-        if (cb < CB) {
-          const f32x4* wrow = pw + ((int64_t)(tap * CB + cb) * nt_total + nt0) * 64 + lane;
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            if (nt < ntw) {
-              const f32x4 bf = wrow[nt * 64];
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c].x, bf.x, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c].y, bf.y, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c].z, bf.z, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[c].w, bf.w, acc[nt], 0, 0, 0);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) a_cur[c] = a_nxt[c];
-    }
-    // D[row = 4g + r][col = i16] belongs to pair 4g + r of the block, whose local dst row lane (4g + r) holds
-    const int dstl = meta_cur >= 0 ? (meta_cur & 0xff) : -1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = __shfl(dstl, 4 * g + r, 64);
-      if (row >= 0) {
-        float* dstp = acc_lds + row * LDW + i16;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-          if (nt < ntw) dstp[nt * 16] += acc[nt][r];
-      }
-    }
-    src_cur = src_nxt; meta_cur = meta_nxt;
-    src_nxt = src_nn; meta_nxt = meta_nn;
-  }
-
-  // write this wave's columns of the tile: ntw*4 float4 per row
-  const int64_t rows_here = (n_dst - row0 < ROWS) ? (n_dst - row0) : ROWS;
-  const int v4 = ntw * 4;
-  for (int e = lane; e < (int)rows_here * v4; e += 64) {
-    const int r = e / v4, c4 = e - r * v4;
-    *reinterpret_cast<f32x4*>(out + (row0 + r) * cout + nt0 * 16 + c4 * 4) =
-        *reinterpret_cast<const f32x4*>(acc_lds + r * LDW + c4 * 4);
-  }
-}
-
-template <int NTW, int TM>
-int launch_fwd(const float* in, const float* packed, const int32_t* blk_src, const int32_t* blk_meta,
-               const int32_t* blk_off, int K, int64_t n_dst, int cin, int nt_total, float* out, hipStream_t stream) {
-  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
-  const int64_t n_wtiles = gpn::cdiv(n_tiles, TM);
-  const dim3 grid((unsigned)gpn::cdiv(n_wtiles, 4), (unsigned)gpn::cdiv(nt_total, NTW));
-  const size_t lds = (size_t)4 * 32 * TM * (NTW * 16 + 16) * sizeof(float);
-  hipLaunchKernelGGL((spconv_fwd_kernel<NTW, TM>), grid, dim3(256), lds, stream, in, packed, blk_src, blk_meta,
-                     blk_off, K, n_dst, n_wtiles, cin, nt_total, out);
-  GPN_CHECK_LAUNCH();
-  return GPN_OK;
-}
-
-// column tiles per wave: as many as possible (gathered rows are re-read once per column group) while keeping
-// roughly >= 1024 waves in flight (256 CUs x 4 SIMDs)
-int pick_ntw(int nt_total, int64_t n_wtiles) {
-  for (int ntw = 4; ntw > 1; --ntw) {
-    if (ntw > nt_total) continue;
-    if (n_wtiles * gpn::cdiv(nt_total, ntw) >= 1024) return ntw;
-  }
-  return 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -361,26 +227,6 @@ extern "C" int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cou
                      cout_w, flags, packed);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
-}
-
-extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* blk_src,
-                              const int32_t* blk_meta, const int32_t* blk_off, int K, int64_t n_dst, int tm, int cin,
-                              int cout, float* out, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  GPN_CHECK_ARG(K >= 1 && n_dst >= 0 && (tm == 1 || tm == 2));
-  GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
-  if (n_dst == 0) return GPN_OK;
-  GPN_CHECK_ARG(in && packed_w && blk_src && blk_meta && blk_off && out);
-  const int nt = cout / 16;
-  const int64_t n_wtiles = gpn::cdiv(gpn::cdiv(n_dst, GPN_TILE_ROWS), tm);
-  const int ntw = pick_ntw(nt, n_wtiles);
-  gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
-#define GPN_FWD(NTW, TM) return launch_fwd<NTW, TM>(in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, out, stream)
-  if (tm == 2) {
-    switch (ntw) { case 1: GPN_FWD(1, 2); case 2: GPN_FWD(2, 2); case 3: GPN_FWD(3, 2); default: GPN_FWD(4, 2); }
-  }
-  switch (ntw) { case 1: GPN_FWD(1, 1); case 2: GPN_FWD(2, 1); case 3: GPN_FWD(3, 1); default: GPN_FWD(4, 1); }
-#undef GPN_FWD
 }
 
 extern "C" size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst) {

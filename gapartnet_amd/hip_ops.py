@@ -75,7 +75,7 @@ def ensure_blocks(rb: "Rulebook") -> "Rulebook":
     if rb.blk_off is not None:
         return rb
     dev = rb.pair_src.device
-    tm = 2 if rb.n_dst >= 65536 else 1
+    tm = 1  # 32-row wave tiles (the fused kernel keeps <= 2 blocks per (tile, tap) in registers)
     L = _C.lib()
     L.gpn_rulebook_blocks_capacity.restype = _C.ctypes.c_int64
     cap = max(int(L.gpn_rulebook_blocks_capacity(i32(rb.K), i64(rb.n_dst), i32(tm))), 1)
