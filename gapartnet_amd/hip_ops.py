@@ -188,9 +188,12 @@ def _conv_packed(features, packed, rb: Rulebook, cin, cout):
     assert features.shape[0] == rb.n_src and features.shape[1] == cin, (features.shape, rb.n_src, cin)
     out = torch.empty((rb.n_dst, cout), dtype=torch.float32, device=dev)
     ensure_blocks(rb)
-    check(_C.lib().gpn_spconv_fwd(ptr(features), ptr(packed), ptr(rb.blk_src), ptr(rb.blk_meta), ptr(rb.blk_off),
-                                  i32(rb.K), i64(rb.n_dst), i32(rb.tm), i32(cin), i32(cout), ptr(out), _stream()),
-          "gpn_spconv_fwd")
+    L = _C.lib()
+    ws_bytes = L.gpn_spconv_fwd_ws_bytes(i32(rb.K), i64(rb.n_dst), i32(cin), i32(cout))
+    ws = _ws(ws_bytes, dev) if ws_bytes else None
+    check(L.gpn_spconv_fwd(ptr(features), ptr(packed), ptr(rb.blk_src), ptr(rb.blk_meta), ptr(rb.blk_off),
+                           i32(rb.K), i64(rb.n_dst), i32(rb.tm), i32(cin), i32(cout), ptr(out), ptr(ws),
+                           szt(ws.numel() if ws is not None else 0), _stream()), "gpn_spconv_fwd")
     return out
 
 

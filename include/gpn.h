@@ -147,9 +147,10 @@ int gpn_rulebook_blocks(const int32_t* pair_src, const int32_t* pair_dst, const 
 #define GPN_PACK_REVERSE 2
 int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cout_w, int flags, float* packed,
                             gpn_stream_t stream);
+size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout);
 int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* blk_src, const int32_t* blk_meta,
-                   const int32_t* blk_off, int K, int64_t n_dst, int tm, int cin, int cout, float* out,
-                   gpn_stream_t stream);
+                   const int32_t* blk_off, int K, int64_t n_dst, int tm, int cin, int cout, float* out, void* ws,
+                   size_t ws_bytes, gpn_stream_t stream);
 size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst);
 int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
