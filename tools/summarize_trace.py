@@ -11,7 +11,7 @@ with open(path) as fh:
         name = r["Kernel_Name"]
         if "spconv" not in name and "wgrad" not in name:
             continue
-        short = name.split("(")[0].replace("void (anonymous namespace)::", "")
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         key = (short, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""),
                r.get("LDS_Block_Size", ""), r.get("VGPR_Count", ""))
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
