@@ -5,62 +5,49 @@
 // Its fp32 accumulators live in a private LDS tile; the output is written once (or, when taps are split across
 // workgroups for small layers, once per split into a partial buffer that a fixed-order reduction sums).
 //
-// The layers of this network are small, so what limits them is dependent-load latency, not flops.  The kernel is
-// therefore organised around keeping gathers in flight:
-//   * taps are processed in stages of as many whole taps as fit a 16 KiB LDS weight slab (shared by the 4 waves;
-//     B operands are conflict-free ds_read_b128 of pre-packed 1 KiB wave fragments);
-//   * per stage a wave copies its block entries (source row, local destination row, tap) into LDS with coalesced
-//     loads, so a gathered row's address never waits on a global load inside the pipeline;
-//   * gathered rows (MFMA A operands) are streamed global -> LDS with the CDNA LDS-DMA (global_load_lds_dwordx4,
-//     per-lane source address = a whole 64-byte piece of a gathered row per 4 lanes) into a PD-deep ring, PD steps
-//     ahead of their use; the ring is drained with COUNTED s_waitcnt vmcnt((PD-1)*CW), so PD-1 steps of gathers
-//     stay in flight under every MFMA group (the compiler cannot count loads it placed behind lane-divergent
-//     branches and falls back to vmcnt(0) — measured: 2 us per step — hence the explicit DMA + explicit counts);
-//   * v_mfma_f32_16x16x4_f32 does the per-rule dense contraction (exact fp32 == an fmaf chain); summation order is
-//     fixed (tap-major), so results are deterministic.
+// The 4 waves walk stages (tap k, chunk of CW 16-channel blocks) in lock-step, so a stage's weight slab
+// (CW x NTW pre-packed 1 KiB MFMA-B fragments) is fetched from L2 once per workgroup and shared through a
+// double-buffered LDS slab (conflict-free ds_read_b128), one barrier per stage.  Everything a stage needs from global
+// memory is requested one or more stages earlier and lands in registers while the previous stage's MFMAs run:
+//     next stage's slab (global -> regs -> LDS after this stage's compute),
+//     next stage's gathered rows = MFMA A operands: lane (i = l&15, g = l>>4) loads channels [16cb+4g, 16cb+4g+4) of
+//         pair i's source row with one 16-byte load, i.e. whole contiguous 64-byte pieces of each gathered row,
+//     the block entries (source row, local destination row) of the tap three taps ahead.
+// All of those loads are unconditional and branch-free (indices are clamped, padding lanes gather row 0 and their MFMA
+// output rows are simply never accumulated): the compiler can then count them and emits partial s_waitcnt vmcnt(N)
+// instead of vmcnt(0) — with lane-divergent guards around the loads every stage exposed a full memory latency.
+// v_mfma_f32_16x16x4_f32 does the per-rule dense contraction (exact fp32 == an fmaf chain); summation order is fixed
+// (tap-major), so results are deterministic.
 #include "gpn_common.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kSlabBytes = 16 * 1024;
-constexpr int kMaxTapsPerSlab = 16;
-constexpr int kMaxBlocks = 2 * kMaxTapsPerSlab;  // <= 2 blocks per (32-row tile, tap)
-
-#define GPN_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | ((((N) >> 4) & 0x3) << 14) | (0x7 << 4) | (0xF << 8))
-
-template <int NTW, int CW, int PD>
-struct FwdLds {
-  static constexpr int LDW = NTW * 16 + 16;  // +16 floats: rows an odd distance apart land on disjoint bank halves
-  static constexpr size_t slab = 0;
-  static constexpr size_t acc = slab + kSlabBytes;
-  static constexpr size_t ring = acc + (size_t)4 * 32 * LDW * 4;
-  static constexpr size_t ent_src = ring + (size_t)4 * PD * CW * 1024;
-  static constexpr size_t ent_dst = ent_src + (size_t)4 * kMaxBlocks * 16 * 4;
-  static constexpr size_t ent_tap = ent_dst + (size_t)4 * kMaxBlocks * 16;
-  static constexpr size_t total = ent_tap + (size_t)4 * kMaxBlocks;
+template <int NTW, int CW>
+struct FwdCfg {
+  static constexpr int LDW = NTW * 16 + 16;       // +16 floats: rows an odd distance apart land on disjoint bank halves
+  static constexpr int SLAB_V4 = CW * NTW * 64;   // float4 per slab buffer: [CW][NTW][64 lanes]
+  static constexpr int NS = (SLAB_V4 + 255) / 256;  // slab float4 per thread
+  static constexpr size_t lds_bytes = (size_t)2 * SLAB_V4 * 16 + (size_t)4 * 32 * LDW * 4;
 };
 
-template <int NTW, int CW, int PD>
+template <int NTW, int CW>
 __global__ __launch_bounds__(256) void spconv_fwd_kernel(
     const float* __restrict__ in, const float* __restrict__ packed, const int32_t* __restrict__ blk_src,
     const int32_t* __restrict__ blk_meta, const int32_t* __restrict__ blk_off, int K, int64_t n_dst, int64_t n_wtiles,
-    int cin, int nt_total, int taps_per_split, int taps_per_slab, float* __restrict__ out) {
-  using L = FwdLds<NTW, CW, PD>;
-  constexpr int LDW = L::LDW;
+    int cin, int nt_total, int taps_per_split, int64_t entry_cap, float* __restrict__ out) {
+  using C = FwdCfg<NTW, CW>;
+  constexpr int LDW = C::LDW, SLAB_V4 = C::SLAB_V4, NS = C::NS;
   constexpr int ROWS = 32;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  f32x4* slab = reinterpret_cast<f32x4*>(smem_raw + L::slab);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* slab = reinterpret_cast<f32x4*>(smem);          // [2][SLAB_V4]
+  float* acc_all = smem + 2 * SLAB_V4 * 4;               // [4 waves][ROWS][LDW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  float* acc_lds = reinterpret_cast<float*>(smem_raw + L::acc) + (size_t)wave * ROWS * LDW;
-  f32x4* ring = reinterpret_cast<f32x4*>(smem_raw + L::ring) + (size_t)wave * PD * CW * 64;
-  int32_t* ent_src = reinterpret_cast<int32_t*>(smem_raw + L::ent_src) + wave * kMaxBlocks * 16;
-  uint8_t* ent_dst = reinterpret_cast<uint8_t*>(smem_raw + L::ent_dst) + wave * kMaxBlocks * 16;
-  uint8_t* ent_tap = reinterpret_cast<uint8_t*>(smem_raw + L::ent_tap) + wave * kMaxBlocks;
+  float* acc_lds = acc_all + (size_t)wave * ROWS * LDW;
 
   const int64_t w = (int64_t)blockIdx.x * 4 + wave;
   const bool active = w < n_wtiles;
@@ -72,123 +59,160 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   const int cout = nt_total * 16;
   const int CB = cin >> 4;
   const int NCH = CB / CW;  // CW divides CB (host guarantees)
+  const int n_stages = (k_hi - k_lo) * NCH;
   const f32x4* __restrict__ pw = reinterpret_cast<const f32x4*>(packed);
 
   for (int e = lane * 4; e < ROWS * LDW; e += 64 * 4) *reinterpret_cast<f32x4*>(acc_lds + e) = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  f32x4 acc[NTW];
+  // per-tap block ranges of this wave's tile: lane l holds blk_off[w*K + min(l, K)]  (K <= 63)
+  int32_t boff = 0;
+  if (active) boff = blk_off[w * K + (lane < K ? lane : K)];
+
+  // ---- branch-free loaders ---------------------------------------------------------------------------------------
+  auto load_slab = [&](int stage, f32x4 (&r)[NS]) {
+    int st = stage < n_stages ? stage : n_stages - 1;  // past the end: harmless duplicate
+    const int k = k_lo + st / NCH, ch = st % NCH;
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  for (int ks = k_lo; ks < k_hi; ks += taps_per_slab) {
-    const int ke = (ks + taps_per_slab < k_hi) ? (ks + taps_per_slab) : k_hi;
-    if (ks != k_lo) __syncthreads();  // every wave is done with the previous slab
-
-    // ---- (a) this wave's block entries of taps [ks, ke) -> LDS -------------------------------------------------
-    int32_t b_lo = 0, nblk = 0;
-    if (active) {
-      b_lo = blk_off[w * K + ks];
-      nblk = blk_off[w * K + ke] - b_lo;
+    for (int j = 0; j < NS; ++j) {
+      int q = j * 256 + tid;
+      q = q < SLAB_V4 ? q : SLAB_V4 - 1;
+      const int p = q >> 6;                 // piece = c * NTW + nt
+      const int c = p / NTW;
+      int nt = p - c * NTW;
+      nt = nt < ntw ? nt : 0;
+      r[j] = pw[((int64_t)(k * CB + ch * CW + c) * nt_total + nt0 + nt) * 64 + (q & 63)];
     }
-    for (int e = lane; e < nblk * 16; e += 64) {
-      const int32_t s = blk_src[(int64_t)b_lo * 16 + e];
-      const int32_t m = blk_meta[(int64_t)b_lo * 16 + e];
-      ent_src[e] = s < 0 ? 0 : s;  // padding lanes gather row 0: their D rows are never accumulated
-      ent_dst[e] = m < 0 ? (uint8_t)255 : (uint8_t)(m & 0xff);
-      if ((e & 15) == 0) ent_tap[e >> 4] = (uint8_t)((m >> 8) - ks);  // entry 0 of a block is always valid
+  };
+  auto store_slab = [&](int buf, const f32x4 (&r)[NS]) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int q = j * 256 + tid;
+      if (q < SLAB_V4) slab[buf * SLAB_V4 + q] = r[j];
     }
-
-    // ---- (b) weights of taps [ks, ke) -> LDS slab ([tap][cb][nt][lane] float4), <= 4 float4 per thread ----------
-    {
-      const int limit = (ke - ks) * CB * NTW * 64;  // float4 count
-      f32x4 r[4];
+  };
+  // entries of tap k: 2 blocks x (src, dst) per 16-lane group; src = -1 / dst = 255 where there is no pair
+  auto load_ent = [&](int k, int32_t (&src)[2], int32_t (&dst)[2]) {
+    const int kk = k < K ? k : K;  // k >= K: empty range [boff[K], boff[K])
+    const int32_t b0 = __shfl(boff, kk, 64);
+    const int32_t b1 = __shfl(boff, (kk + 1 < K ? kk + 1 : K), 64);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int q = j * 256 + tid;
-        q = q < limit ? q : limit - 1;
-        const int p = q >> 6;
-        int nt = p % NTW;
-        const int rest = p / NTW;  // (tap - ks) * CB + cb
-        nt = nt < ntw ? nt : 0;
-        r[j] = pw[((int64_t)(ks * CB + rest) * nt_total + nt0 + nt) * 64 + (q & 63)];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int q = j * 256 + tid;
-        if (q < limit) slab[q] = r[j];
-      }
+    for (int j = 0; j < 2; ++j) {
+      int64_t e = (int64_t)(b0 + j) * 16 + i16;
+      e = e < entry_cap ? e : entry_cap - 1;
+      const int32_t s = blk_src[e];
+      const int32_t m = blk_meta[e];
+      const bool ok = (b0 + j < b1) && (m >= 0);
+      src[j] = ok ? s : -1;
+      dst[j] = ok ? (m & 0xff) : 255;
     }
-    __syncthreads();
-
-    const int nsteps = nblk * NCH;
-    if (nsteps > 0) {
-      // ---- (c) prime the gathered-row ring ------------------------------------------------------------------
-      auto issue_a = [&](int t) {
-        const int tt = t < nsteps ? t : nsteps - 1;  // past the end: harmless duplicate, keeps the DMA count uniform
-        const int blk = tt / NCH;
-        const int ch = tt - blk * NCH;
-        const int32_t src = ent_src[blk * 16 + i16];
-        const float* gp = in + (int64_t)src * cin + ch * (CW * 16) + 4 * g;
-        f32x4* slot = ring + (t % PD) * (CW * 64);
+  };
+  auto load_a = [&](const int32_t (&src)[2], int ch, f32x4 (&a)[2][CW]) {
 #pragma unroll
-        for (int c = 0; c < CW; ++c)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + c * 16),
-                                           (__attribute__((address_space(3))) void*)(slot + c * 64), 16, 0, 0);
-      };
-      for (int u = 0; u < PD; ++u) issue_a(u);
-
-      // ---- (d) steps ------------------------------------------------------------------------------------------
-      for (int t = 0; t < nsteps; ++t) {
-        const int blk = t / NCH;
-        const int ch = t - blk * NCH;
-        const int tap = ent_tap[blk];
-        GPN_WAIT_VMCNT((PD - 1) * CW);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4* slot = ring + (t % PD) * (CW * 64) + lane;
-        f32x4 a[CW];
+    for (int j = 0; j < 2; ++j) {
+      const int32_t s = src[j] < 0 ? 0 : src[j];  // padding lanes gather row 0; their output rows are never used
+      const f32x4* arow = reinterpret_cast<const f32x4*>(in + (int64_t)s * cin + ch * (CW * 16) + 4 * g);
 #pragma unroll
-        for (int c = 0; c < CW; ++c) a[c] = slot[c * 64];
-        const f32x4* sb = slab + ((int64_t)(tap * CB + ch * CW) * NTW) * 64 + lane;
+      for (int c = 0; c < CW; ++c) a[j][c] = arow[c * 4];
+    }
+  };
+
+  // ---- prologue ----------------------------------------------------------------------------------------------------
+  f32x4 slab_r[NS];
+  load_slab(0, slab_r);
+  int32_t src_c[2], dst_c[2], src_n[2], dst_n[2], src_nn[2], dst_nn[2];
+  load_ent(k_lo, src_c, dst_c);
+  load_ent(k_lo + 1 < k_hi ? k_lo + 1 : K, src_n, dst_n);
+  load_ent(k_lo + 2 < k_hi ? k_lo + 2 : K, src_nn, dst_nn);
+  f32x4 a_cur[2][CW], a_nxt[2][CW];
+  load_a(src_c, 0, a_cur);
+  store_slab(0, slab_r);
+  __syncthreads();
+
+  f32x4 acc[2][NTW];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- stages ------------------------------------------------------------------------------------------------------
+  int stage = 0;
+  for (int k = k_lo; k < k_hi; ++k) {
+    for (int ch = 0; ch < NCH; ++ch, ++stage) {
+      const bool last_ch = (ch == NCH - 1);
+      // requests for later stages (all unconditional)
+      load_slab(stage + 1, slab_r);
+      if (!last_ch) load_a(src_c, ch + 1, a_nxt);
+      else load_a(src_n, 0, a_nxt);
+      int32_t src_t[2], dst_t[2];
+      load_ent(k + 3 < k_hi ? k + 3 : K, src_t, dst_t);
+
+      // contraction of the current stage (blocks that do not exist are skipped: uniform branches, no memory ops inside)
+      const bool have0 = __builtin_amdgcn_readfirstlane(dst_c[0]) != 255;  // entry 0 of an existing block is valid
+      const bool have1 = __builtin_amdgcn_readfirstlane(dst_c[1]) != 255;
+      if (have0) {
+        const f32x4* sb = slab + (stage & 1) * SLAB_V4 + lane;
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) {
             if (nt < ntw) {
               const f32x4 bf = sb[(c * NTW + nt) * 64];
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].x, bf.x, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].y, bf.y, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].z, bf.z, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].w, bf.w, acc[nt], 0, 0, 0);
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][c].x, bf.x, acc[0][nt], 0, 0, 0);
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][c].y, bf.y, acc[0][nt], 0, 0, 0);
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][c].z, bf.z, acc[0][nt], 0, 0, 0);
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][c].w, bf.w, acc[0][nt], 0, 0, 0);
+              if (have1) {
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][c].x, bf.x, acc[1][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][c].y, bf.y, acc[1][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][c].z, bf.z, acc[1][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][c].w, bf.w, acc[1][nt], 0, 0, 0);
+              }
             }
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(t + PD);  // refill the slot just consumed
-        if (ch == NCH - 1) {
-          // D[row = 4g + r][col = i16] belongs to pair 4g + r of the block; the 4 rows are distinct destinations
-          int row[4];
-          float v[4][NTW];
+        if (last_ch) {
+          // D[row = 4g + r][col = i16] of block j belongs to its pair 4g + r (lane 4g + r holds that pair's local
+          // destination row); the rows of one tap are distinct, so reads can be batched ahead of the writes
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            row[r] = ent_dst[blk * 16 + 4 * g + r];
-            const int rr = row[r] == 255 ? 0 : row[r];
+          for (int j = 0; j < 2; ++j) {
+            if (j == 1 && !have1) break;
+            int row[4];
+            float v[4][NTW];
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) v[r][nt] = acc_lds[rr * LDW + nt * 16 + i16];
-          }
+            for (int r = 0; r < 4; ++r) {
+              row[r] = __shfl(dst_c[j], 4 * g + r, 64);
+              const int rr = row[r] == 255 ? 0 : row[r];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (row[r] != 255) {
-#pragma unroll
-              for (int nt = 0; nt < NTW; ++nt)
-                if (nt < ntw) acc_lds[row[r] * LDW + nt * 16 + i16] = v[r][nt] + acc[nt][r];
+              for (int nt = 0; nt < NTW; ++nt) v[r][nt] = acc_lds[rr * LDW + nt * 16 + i16];
             }
-          }
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) {
+              if (row[r] != 255) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                  if (nt < ntw) acc_lds[row[r] * LDW + nt * 16 + i16] = v[r][nt] + acc[j][nt][r];
+              }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
-      // ---- (e) drain the tail DMAs before the ring / entries are reused --------------------------------------
-      GPN_WAIT_VMCNT(0);
+
+      store_slab((stage + 1) & 1, slab_r);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) a_cur[j][c] = a_nxt[j][c];
+      if (last_ch) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          src_c[j] = src_n[j]; dst_c[j] = dst_n[j];
+          src_n[j] = src_nn[j]; dst_n[j] = dst_nn[j];
+          src_nn[j] = src_t[j]; dst_nn[j] = dst_t[j];
+        }
+      }
     }
   }
 
@@ -215,7 +239,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int sp
 }
 
 struct FwdPlan {
-  int ntw, cw, splits, taps_per_split, taps_per_slab;
+  int ntw, cw, splits, taps_per_split;
 };
 
 FwdPlan plan_fwd(int K, int64_t n_dst, int cin, int cout) {
@@ -223,11 +247,11 @@ FwdPlan plan_fwd(int K, int64_t n_dst, int cin, int cout) {
   const int64_t row_wgs = gpn::cdiv(gpn::cdiv(n_dst, GPN_TILE_ROWS), 4);
   FwdPlan p;
   p.cw = (CB % 4 == 0) ? 4 : (CB % 2 == 0) ? 2 : 1;
-  // column tiles per workgroup: as many as possible (rows are re-gathered once per column group) with >= 512
-  // workgroups in flight; one tap's weights (CB * ntw KiB) must fit the slab
+  // column tiles per workgroup: as many as possible (rows are re-gathered once per column group) while keeping
+  // >= 512 workgroups in flight
   p.ntw = 1;
   for (int ntw = 4; ntw > 1; --ntw) {
-    if (ntw > nt || CB * ntw * 1024 > kSlabBytes) continue;
+    if (ntw > nt) continue;
     if (row_wgs * gpn::cdiv(nt, ntw) >= 512) { p.ntw = ntw; break; }
   }
   const int64_t wgs = row_wgs * gpn::cdiv(nt, p.ntw);
@@ -240,39 +264,36 @@ FwdPlan plan_fwd(int K, int64_t n_dst, int cin, int cout) {
   }
   p.taps_per_split = (int)gpn::cdiv(K, p.splits);
   p.splits = (int)gpn::cdiv(K, p.taps_per_split);
-  int tps = kSlabBytes / (CB * p.ntw * 1024);
-  if (tps < 1) tps = 1;
-  if (tps > kMaxTapsPerSlab) tps = kMaxTapsPerSlab;
-  p.taps_per_slab = tps;
   return p;
 }
 
-template <int NTW, int CW, int PD>
+template <int NTW, int CW>
 int launch_fwd(const FwdPlan& p, const float* in, const float* packed, const int32_t* blk_src, const int32_t* blk_meta,
-               const int32_t* blk_off, int K, int64_t n_dst, int cin, int nt_total, float* out, hipStream_t stream) {
+               const int32_t* blk_off, int K, int64_t n_dst, int cin, int nt_total, int64_t entry_cap, float* out,
+               hipStream_t stream) {
   const int64_t n_wtiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
   const dim3 grid((unsigned)gpn::cdiv(n_wtiles, 4), (unsigned)gpn::cdiv(nt_total, NTW), (unsigned)p.splits);
-  const size_t lds = FwdLds<NTW, CW, PD>::total;
+  const size_t lds = FwdCfg<NTW, CW>::lds_bytes;
   static bool attr_set = false;
-  if (!attr_set) {
-    GPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_fwd_kernel<NTW, CW, PD>),
+  if (!attr_set && lds > 64 * 1024) {
+    GPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_fwd_kernel<NTW, CW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((spconv_fwd_kernel<NTW, CW, PD>), grid, dim3(256), lds, stream, in, packed, blk_src, blk_meta,
-                     blk_off, K, n_dst, n_wtiles, cin, nt_total, p.taps_per_split, p.taps_per_slab, out);
+  hipLaunchKernelGGL((spconv_fwd_kernel<NTW, CW>), grid, dim3(256), lds, stream, in, packed, blk_src, blk_meta, blk_off,
+                     K, n_dst, n_wtiles, cin, nt_total, p.taps_per_split, entry_cap, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
 template <int NTW>
 int dispatch_cw(const FwdPlan& p, const float* in, const float* packed, const int32_t* blk_src, const int32_t* blk_meta,
-                const int32_t* blk_off, int K, int64_t n_dst, int cin, int nt_total, float* out, hipStream_t stream) {
-  // ring depth: 6 / 3 / 2 steps of 1 / 2 / 4 KiB per wave
+                const int32_t* blk_off, int K, int64_t n_dst, int cin, int nt_total, int64_t entry_cap, float* out,
+                hipStream_t stream) {
   switch (p.cw) {
-    case 1: return launch_fwd<NTW, 1, 6>(p, in, packed, blk_src, blk_meta, blk_off, K, n_dst, cin, nt_total, out, stream);
-    case 2: return launch_fwd<NTW, 2, 3>(p, in, packed, blk_src, blk_meta, blk_off, K, n_dst, cin, nt_total, out, stream);
-    default: return launch_fwd<NTW, 4, 2>(p, in, packed, blk_src, blk_meta, blk_off, K, n_dst, cin, nt_total, out, stream);
+    case 1: return launch_fwd<NTW, 1>(p, in, packed, blk_src, blk_meta, blk_off, K, n_dst, cin, nt_total, entry_cap, out, stream);
+    case 2: return launch_fwd<NTW, 2>(p, in, packed, blk_src, blk_meta, blk_off, K, n_dst, cin, nt_total, entry_cap, out, stream);
+    default: return launch_fwd<NTW, 4>(p, in, packed, blk_src, blk_meta, blk_off, K, n_dst, cin, nt_total, entry_cap, out, stream);
   }
 }
 
@@ -288,13 +309,13 @@ extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int3
                               const int32_t* blk_meta, const int32_t* blk_off, int K, int64_t n_dst, int tm, int cin,
                               int cout, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  GPN_CHECK_ARG(K >= 1 && K <= 255 && n_dst >= 0 && tm == 1);
+  GPN_CHECK_ARG(K >= 1 && K <= 63 && n_dst >= 0 && tm == 1);
   GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
   if (n_dst == 0) return GPN_OK;
   GPN_CHECK_ARG(in && packed_w && blk_src && blk_meta && blk_off && out);
   const int nt = cout / 16;
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
-  GPN_CHECK_ARG((cin / 16) * p.ntw * 1024 <= kSlabBytes);
+  const int64_t entry_cap = gpn_rulebook_blocks_capacity(K, n_dst, 1) * 16;
   float* target = out;
   if (p.splits > 1) {
     if (!ws || ws_bytes < (size_t)p.splits * n_dst * cout * sizeof(float)) {
@@ -307,10 +328,10 @@ extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int3
   {
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
     switch (p.ntw) {
-      case 1: rc = dispatch_cw<1>(p, in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, target, stream); break;
-      case 2: rc = dispatch_cw<2>(p, in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, target, stream); break;
-      case 3: rc = dispatch_cw<3>(p, in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, target, stream); break;
-      default: rc = dispatch_cw<4>(p, in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, target, stream); break;
+      case 1: rc = dispatch_cw<1>(p, in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, entry_cap, target, stream); break;
+      case 2: rc = dispatch_cw<2>(p, in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, entry_cap, target, stream); break;
+      case 3: rc = dispatch_cw<3>(p, in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, entry_cap, target, stream); break;
+      default: rc = dispatch_cw<4>(p, in, packed_w, blk_src, blk_meta, blk_off, K, n_dst, cin, nt, entry_cap, target, stream); break;
     }
     if (rc == GPN_OK && p.splits > 1) {
       const int64_t elems4 = n_dst * cout / 4;
