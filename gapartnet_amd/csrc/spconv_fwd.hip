@@ -116,16 +116,28 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
     }
   };
 
-  // ---- prologue ----------------------------------------------------------------------------------------------------
-  f32x4 slab_r[NS];
-  load_slab(0, slab_r);
-  int32_t src_c[2], dst_c[2], src_n[2], dst_n[2], src_nn[2], dst_nn[2];
-  load_ent(k_lo, src_c, dst_c);
-  load_ent(k_lo + 1 < k_hi ? k_lo + 1 : K, src_n, dst_n);
-  load_ent(k_lo + 2 < k_hi ? k_lo + 2 : K, src_nn, dst_nn);
-  f32x4 a_cur[2][CW], a_nxt[2][CW];
-  load_a(src_c, 0, a_cur);
-  store_slab(0, slab_r);
+  // ---- software pipeline: prefetch distance D stages for slabs and gathered rows, 2D stages for entries ----------
+  // (a stage is shorter than a memory round trip, and the 4 waves of a workgroup advance in lock-step, so the only
+  //  way to keep the workgroup from paying one full latency per stage is to have several stages of loads in flight.
+  //  Ring slots are compile-time: the stage loop is unrolled by E = 2D and the stage count padded to a multiple of E
+  //  with empty stages, which keeps every load unconditional.)
+  constexpr int D = (CW == 4) ? 2 : 4;
+  constexpr int E = 2 * D;
+  const int n_pad = (n_stages + E - 1) / E * E;
+  auto tap_of = [&](int st) { return st < n_stages ? k_lo + st / NCH : K; };  // K -> empty entry range
+  auto ch_of = [&](int st) { return st < n_stages ? st % NCH : 0; };
+
+  int32_t esrc[E][2], edst[E][2];
+  f32x4 areg[D][2][CW];
+  f32x4 sreg[D][NS];
+#pragma unroll
+  for (int u = 0; u < E; ++u) load_ent(tap_of(u), esrc[u], edst[u]);
+#pragma unroll
+  for (int u = 0; u < D; ++u) load_slab(u, sreg[u]);
+#pragma unroll
+  for (int u = 0; u < D; ++u) load_a(esrc[u], ch_of(u), areg[u]);
+  store_slab(0, sreg[0]);
+  load_slab(D, sreg[0]);
   __syncthreads();
 
   f32x4 acc[2][NTW];
@@ -134,21 +146,14 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- stages ------------------------------------------------------------------------------------------------------
-  int stage = 0;
-  for (int k = k_lo; k < k_hi; ++k) {
-    for (int ch = 0; ch < NCH; ++ch, ++stage) {
-      const bool last_ch = (ch == NCH - 1);
-      // requests for later stages (all unconditional)
-      load_slab(stage + 1, slab_r);
-      if (!last_ch) load_a(src_c, ch + 1, a_nxt);
-      else load_a(src_n, 0, a_nxt);
-      int32_t src_t[2], dst_t[2];
-      load_ent(k + 3 < k_hi ? k + 3 : K, src_t, dst_t);
-
+  for (int s0 = 0; s0 < n_pad; s0 += E) {
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      const int stage = s0 + u;
+      const bool last_ch = (ch_of(stage) == NCH - 1);
       // contraction of the current stage (blocks that do not exist are skipped: uniform branches, no memory ops inside)
-      const bool have0 = __builtin_amdgcn_readfirstlane(dst_c[0]) != 255;  // entry 0 of an existing block is valid
-      const bool have1 = __builtin_amdgcn_readfirstlane(dst_c[1]) != 255;
+      const bool have0 = __builtin_amdgcn_readfirstlane(edst[u][0]) != 255;  // entry 0 of an existing block is valid
+      const bool have1 = __builtin_amdgcn_readfirstlane(edst[u][1]) != 255;
       if (have0) {
         const f32x4* sb = slab + (stage & 1) * SLAB_V4 + lane;
 #pragma unroll
@@ -157,15 +162,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
           for (int nt = 0; nt < NTW; ++nt) {
             if (nt < ntw) {
               const f32x4 bf = sb[(c * NTW + nt) * 64];
-              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][c].x, bf.x, acc[0][nt], 0, 0, 0);
-              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][c].y, bf.y, acc[0][nt], 0, 0, 0);
-              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][c].z, bf.z, acc[0][nt], 0, 0, 0);
-              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][c].w, bf.w, acc[0][nt], 0, 0, 0);
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[u % D][0][c].x, bf.x, acc[0][nt], 0, 0, 0);
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[u % D][0][c].y, bf.y, acc[0][nt], 0, 0, 0);
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[u % D][0][c].z, bf.z, acc[0][nt], 0, 0, 0);
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[u % D][0][c].w, bf.w, acc[0][nt], 0, 0, 0);
               if (have1) {
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][c].x, bf.x, acc[1][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][c].y, bf.y, acc[1][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][c].z, bf.z, acc[1][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][c].w, bf.w, acc[1][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[u % D][1][c].x, bf.x, acc[1][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[u % D][1][c].y, bf.y, acc[1][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[u % D][1][c].z, bf.z, acc[1][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[u % D][1][c].w, bf.w, acc[1][nt], 0, 0, 0);
               }
             }
           }
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
             float v[4][NTW];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              row[r] = __shfl(dst_c[j], 4 * g + r, 64);
+              row[r] = __shfl(edst[u][j], 4 * g + r, 64);
               const int rr = row[r] == 255 ? 0 : row[r];
 #pragma unroll
               for (int nt = 0; nt < NTW; ++nt) v[r][nt] = acc_lds[rr * LDW + nt * 16 + i16];
@@ -198,21 +203,12 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
           }
         }
       }
-
-      store_slab((stage + 1) & 1, slab_r);
+      // hand the next stage its slab, then refill the ring slots this stage freed (all loads unconditional)
+      store_slab((stage + 1) & 1, sreg[(u + 1) % D]);
+      load_slab(stage + 1 + D, sreg[(u + 1) % D]);
+      load_a(esrc[(u + D) % E], ch_of(stage + D), areg[u % D]);
+      load_ent(tap_of(stage + E), esrc[u], edst[u]);
       __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int c = 0; c < CW; ++c) a_cur[j][c] = a_nxt[j][c];
-      if (last_ch) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          src_c[j] = src_n[j]; dst_c[j] = dst_n[j];
-          src_n[j] = src_nn[j]; dst_n[j] = dst_nn[j];
-          src_nn[j] = src_t[j]; dst_nn[j] = dst_t[j];
-        }
-      }
     }
   }
 
