@@ -201,52 +201,6 @@ __global__ void down_scatter_tables_kernel(const int32_t* __restrict__ fine_to_c
   tb[(int64_t)k * N + i] = o;
 }
 
-// ------------------------------------------------------------------------------------------ block lists
-// The fused conv kernel streams, per wave tile (32*tm dst rows), a flat list of 16-pair blocks ordered by tap; each
-// (wave tile, tap) group is padded to a multiple of 16 so a block never straddles two taps.
-//   blk_src [16*B] = source row or -1,  blk_meta [16*B] = (tap << 8) | local dst row, or -1,
-//   blk_off [n_wtiles*K + 1] = first block of group (wave tile w, tap k) at index w*K + k.
-__global__ void count_blocks_kernel(const int32_t* __restrict__ tile_off, int K, int64_t n_tiles, int64_t n_wtiles,
-                                    int tm, int32_t* __restrict__ nb) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t > n_wtiles * K) return;
-  if (t == n_wtiles * K) { nb[t] = 0; return; }
-  const int64_t w = t / K;
-  const int k = (int)(t - w * K);
-  const int64_t t0 = w * tm, t1 = (t0 + tm < n_tiles) ? (t0 + tm) : n_tiles;
-  const int32_t cnt = tile_off[(int64_t)k * (n_tiles + 1) + t1] - tile_off[(int64_t)k * (n_tiles + 1) + t0];
-  nb[t] = (cnt + 15) >> 4;
-}
-
-__global__ void fill_blocks_kernel(const int32_t* __restrict__ pair_src, const int32_t* __restrict__ pair_dst,
-                                   const int32_t* __restrict__ tile_off, const int32_t* __restrict__ blk_off, int K,
-                                   int64_t n_tiles, int64_t n_wtiles, int tm, int32_t* __restrict__ blk_src,
-                                   int32_t* __restrict__ blk_meta) {
-  // 16 lanes per (wave tile, tap) group
-  const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int l = threadIdx.x & 15;
-  if (g >= n_wtiles * K) return;
-  const int64_t w = g / K;
-  const int k = (int)(g - w * K);
-  const int64_t t0 = w * tm, t1 = (t0 + tm < n_tiles) ? (t0 + tm) : n_tiles;
-  const int32_t p0 = tile_off[(int64_t)k * (n_tiles + 1) + t0], p1 = tile_off[(int64_t)k * (n_tiles + 1) + t1];
-  const int32_t b0 = blk_off[g], b1 = blk_off[g + 1];
-  const int32_t row0 = (int32_t)(t0 * GPN_TILE_ROWS);
-  for (int32_t b = b0; b < b1; ++b) {
-    const int32_t p = p0 + (b - b0) * 16 + l;
-    const bool valid = p < p1;
-    blk_src[(int64_t)b * 16 + l] = valid ? pair_src[p] : -1;
-    blk_meta[(int64_t)b * 16 + l] = valid ? ((k << 8) | (pair_dst[p] - row0)) : -1;
-  }
-}
-
-size_t escan_i32_temp_bytes(int64_t n) {
-  size_t bytes = 0;
-  rocprim::exclusive_scan(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)(n > 0 ? n : 1),
-                          rocprim::plus<int32_t>(), (hipStream_t) nullptr);
-  return bytes;
-}
-
 size_t sort_temp_bytes(int64_t n) {
   size_t bytes = 0;
   rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
@@ -275,7 +229,7 @@ extern "C" size_t gpn_rulebook_subm3_ws_bytes(int64_t N) {
   return w.used;
 }
 
-extern "C" int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32_t* spatial_shape_host,
+extern "C" int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32_t* spatial_shape_host, int32_t* nbr,
                                   int32_t* pair_src, int32_t* pair_dst, int32_t* tile_off,
                                   int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -294,7 +248,8 @@ extern "C" int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32
   const uint64_t cap = hash_capacity(N);
   uint64_t* hkeys = w.take<uint64_t>(cap);
   int32_t* hvals = w.take<int32_t>(cap);
-  int32_t* table = w.take<int32_t>(27 * (size_t)N + 1);
+  int32_t* table_ws = w.take<int32_t>(27 * (size_t)N + 1);
+  int32_t* table = nbr ? nbr : table_ws;  // the tap-major neighbour table is an output when the caller wants it
   int32_t* pos = w.take<int32_t>(27 * (size_t)N + 1);
   size_t prim_bytes = scan_temp_bytes(27 * N + 1);
   void* prim_tmp = w.take<char>(prim_bytes);
@@ -391,8 +346,8 @@ extern "C" size_t gpn_rulebook_down_lists_ws_bytes(int64_t N, int64_t n_out) {
 }
 
 extern "C" int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N,
-                                       int64_t n_out, int32_t* fwd_src, int32_t* fwd_dst,
-                                       int32_t* fwd_tile_off, int32_t* bwd_src, int32_t* bwd_dst,
+                                       int64_t n_out, int32_t* fwd_nbr, int32_t* fwd_src, int32_t* fwd_dst,
+                                       int32_t* fwd_tile_off, int32_t* bwd_nbr, int32_t* bwd_src, int32_t* bwd_dst,
                                        int32_t* bwd_tile_off, int64_t* num_pairs, void* ws, size_t ws_bytes,
                                        gpn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -406,8 +361,10 @@ extern "C" int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int3
   }
   GPN_CHECK_ARG(fine_to_coarse && tap && fwd_src && fwd_dst && bwd_src && bwd_dst);
   gpn::WsCarver w(ws, ws_bytes);
-  int32_t* tf = w.take<int32_t>(8 * (size_t)n_out + 1);
-  int32_t* tb = w.take<int32_t>(8 * (size_t)N + 1);
+  int32_t* tf_ws = w.take<int32_t>(8 * (size_t)n_out + 1);
+  int32_t* tb_ws = w.take<int32_t>(8 * (size_t)N + 1);
+  int32_t* tf = fwd_nbr ? fwd_nbr : tf_ws;
+  int32_t* tb = bwd_nbr ? bwd_nbr : tb_ws;
   int32_t* pos = w.take<int32_t>(8 * (size_t)N + 1);
   size_t prim_bytes = scan_temp_bytes(8 * N + 1);
   void* prim_tmp = w.take<char>(prim_bytes);
@@ -424,49 +381,3 @@ extern "C" int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int3
   return lists_from_table(tb, pos, 8, N, bwd_src, bwd_dst, bwd_tile_off, nullptr, prim_tmp, prim_bytes, stream);
 }
 
-// ================================================================================================ block lists
-extern "C" int64_t gpn_rulebook_blocks_capacity(int K, int64_t n_dst, int tm) {
-  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
-  const int64_t n_wtiles = gpn::cdiv(n_tiles, tm);
-  return (int64_t)K * (n_dst / 16 + 1) + n_wtiles * K;
-}
-
-extern "C" size_t gpn_rulebook_blocks_ws_bytes(int K, int64_t n_dst, int tm) {
-  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
-  const int64_t n_wtiles = gpn::cdiv(n_tiles, tm);
-  gpn::WsCarver w(nullptr, 0);
-  w.take<int32_t>((size_t)(n_wtiles * K + 1));
-  w.take<char>(escan_i32_temp_bytes(n_wtiles * K + 1));
-  return w.used;
-}
-
-extern "C" int gpn_rulebook_blocks(const int32_t* pair_src, const int32_t* pair_dst, const int32_t* tile_off, int K,
-                                   int64_t n_dst, int tm, int32_t* blk_src, int32_t* blk_meta, int32_t* blk_off,
-                                   void* ws, size_t ws_bytes, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  GPN_CHECK_ARG(K >= 1 && n_dst >= 0 && (tm == 1 || tm == 2) && blk_off);
-  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
-  const int64_t n_wtiles = gpn::cdiv(n_tiles, tm);
-  const int64_t groups = n_wtiles * K;
-  if (n_dst == 0) {
-    GPN_CHECK_HIP(hipMemsetAsync(blk_off, 0, sizeof(int32_t), stream));
-    return GPN_OK;
-  }
-  GPN_CHECK_ARG(pair_src && pair_dst && tile_off && blk_src && blk_meta);
-  gpn::WsCarver w(ws, ws_bytes);
-  int32_t* nb = w.take<int32_t>((size_t)(groups + 1));
-  size_t prim_bytes = escan_i32_temp_bytes(groups + 1);
-  void* prim_tmp = w.take<char>(prim_bytes);
-  GPN_CHECK_WS(w);
-  gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 0.0);
-  hipLaunchKernelGGL(count_blocks_kernel, dim3((int)gpn::cdiv(groups + 1, kThreads)), dim3(kThreads), 0, stream,
-                     tile_off, K, n_tiles, n_wtiles, tm, nb);
-  GPN_CHECK_LAUNCH();
-  size_t tmp = prim_bytes;
-  GPN_CHECK_HIP(rocprim::exclusive_scan(prim_tmp, tmp, nb, blk_off, 0, (size_t)(groups + 1), rocprim::plus<int32_t>(),
-                                        stream));
-  hipLaunchKernelGGL(fill_blocks_kernel, dim3((int)gpn::cdiv(groups * 16, kThreads)), dim3(kThreads), 0, stream,
-                     pair_src, pair_dst, tile_off, blk_off, K, n_tiles, n_wtiles, tm, blk_src, blk_meta);
-  GPN_CHECK_LAUNCH();
-  return GPN_OK;
-}

@@ -60,35 +60,10 @@ class Rulebook:
     n_src: int
     n_dst: int
     num_pairs: torch.Tensor  # 0-dim int64 on device (no host sync)
-    # block-list view streamed by the fused conv kernel (built lazily by hip_ops.ensure_blocks)
-    tm: int = 0
-    blk_src: Optional[torch.Tensor] = None
-    blk_meta: Optional[torch.Tensor] = None
-    blk_off: Optional[torch.Tensor] = None
+    nbr: Optional[torch.Tensor] = None  # tap-major neighbour table [K*n_dst + 1] i32 (-1 = none) the fused conv gathers from
 
     def pairs_host(self) -> int:
         return int(self.num_pairs.item())
-
-
-def ensure_blocks(rb: "Rulebook") -> "Rulebook":
-    """build (once per rulebook) the padded 16-pair block list the fused conv kernel streams; no host sync."""
-    if rb.blk_off is not None:
-        return rb
-    dev = rb.pair_src.device
-    tm = 1  # 32-row wave tiles (the fused kernel keeps <= 2 blocks per (tile, tap) in registers)
-    L = _C.lib()
-    L.gpn_rulebook_blocks_capacity.restype = _C.ctypes.c_int64
-    cap = max(int(L.gpn_rulebook_blocks_capacity(i32(rb.K), i64(rb.n_dst), i32(tm))), 1)
-    n_wtiles = (n_tiles(rb.n_dst) + tm - 1) // tm
-    rb.blk_src = torch.empty((cap * 16,), dtype=torch.int32, device=dev)
-    rb.blk_meta = torch.empty((cap * 16,), dtype=torch.int32, device=dev)
-    rb.blk_off = torch.zeros((n_wtiles * rb.K + 1,), dtype=torch.int32, device=dev)
-    ws = _ws(L.gpn_rulebook_blocks_ws_bytes(i32(rb.K), i64(rb.n_dst), i32(tm)), dev)
-    check(L.gpn_rulebook_blocks(ptr(rb.pair_src), ptr(rb.pair_dst), ptr(rb.tile_off), i32(rb.K), i64(rb.n_dst), i32(tm),
-                                ptr(rb.blk_src), ptr(rb.blk_meta), ptr(rb.blk_off), ptr(ws), szt(ws.numel()), _stream()),
-          "gpn_rulebook_blocks")
-    rb.tm = tm
-    return rb
 
 
 # ---------------------------------------------------------------------------------------------------- V
@@ -133,9 +108,10 @@ def rulebook_subm3(indices, spatial_shape) -> Rulebook:
     npairs = torch.zeros((1,), dtype=torch.int64, device=dev)
     L = _C.lib()
     ws = _ws(L.gpn_rulebook_subm3_ws_bytes(i64(N)), dev)
-    check(L.gpn_rulebook_subm3(ptr(indices), i64(N), host_i32x3(spatial_shape), ptr(src), ptr(dst), ptr(toff),
+    nbr = torch.empty((27 * N + 1,), dtype=torch.int32, device=dev)
+    check(L.gpn_rulebook_subm3(ptr(indices), i64(N), host_i32x3(spatial_shape), ptr(nbr), ptr(src), ptr(dst), ptr(toff),
                                ptr(npairs), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_subm3")
-    return Rulebook(src, dst, toff, 27, N, N, npairs[0])
+    return Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr)
 
 
 def rulebook_down(indices, spatial_shape, batch_size):
@@ -162,12 +138,14 @@ def rulebook_down(indices, spatial_shape, batch_size):
     bt = torch.empty((8, n_tiles(N) + 1), dtype=torch.int32, device=dev)
     npairs = torch.zeros((1,), dtype=torch.int64, device=dev)
     ws = _ws(L.gpn_rulebook_down_lists_ws_bytes(i64(N), i64(No)), dev)
-    check(L.gpn_rulebook_down_lists(ptr(f2c), ptr(tap), i64(N), i64(No), ptr(fs), ptr(fd), ptr(ft), ptr(bs),
-                                    ptr(bd), ptr(bt), ptr(npairs), ptr(ws), szt(ws.numel()), _stream()),
+    fn = torch.empty((8 * No + 1,), dtype=torch.int32, device=dev)
+    bn = torch.empty((8 * N + 1,), dtype=torch.int32, device=dev)
+    check(L.gpn_rulebook_down_lists(ptr(f2c), ptr(tap), i64(N), i64(No), ptr(fn), ptr(fs), ptr(fd), ptr(ft), ptr(bn),
+                                    ptr(bs), ptr(bd), ptr(bt), ptr(npairs), ptr(ws), szt(ws.numel()), _stream()),
           "gpn_rulebook_down_lists")
     out_shape = [int(s) // 2 for s in spatial_shape]
-    rb_fwd = Rulebook(fs, fd, ft, 8, N, No, npairs[0])
-    rb_bwd = Rulebook(bs, bd, bt, 8, No, N, npairs[0])
+    rb_fwd = Rulebook(fs, fd, ft, 8, N, No, npairs[0], fn)
+    rb_bwd = Rulebook(bs, bd, bt, 8, No, N, npairs[0], bn)
     return out_idx[:No], out_shape, rb_fwd, rb_bwd
 
 
@@ -187,13 +165,11 @@ def _conv_packed(features, packed, rb: Rulebook, cin, cout):
     features = _c(features, torch.float32)
     assert features.shape[0] == rb.n_src and features.shape[1] == cin, (features.shape, rb.n_src, cin)
     out = torch.empty((rb.n_dst, cout), dtype=torch.float32, device=dev)
-    ensure_blocks(rb)
     L = _C.lib()
     ws_bytes = L.gpn_spconv_fwd_ws_bytes(i32(rb.K), i64(rb.n_dst), i32(cin), i32(cout))
     ws = _ws(ws_bytes, dev) if ws_bytes else None
-    check(L.gpn_spconv_fwd(ptr(features), ptr(packed), ptr(rb.blk_src), ptr(rb.blk_meta), ptr(rb.blk_off),
-                           i32(rb.K), i64(rb.n_dst), i32(rb.tm), i32(cin), i32(cout), ptr(out), ptr(ws),
-                           szt(ws.numel() if ws is not None else 0), _stream()), "gpn_spconv_fwd")
+    check(L.gpn_spconv_fwd(ptr(features), ptr(packed), ptr(rb.nbr), i32(rb.K), i64(rb.n_dst), i32(cin), i32(cout),
+                           ptr(out), ptr(ws), szt(ws.numel() if ws is not None else 0), _stream()), "gpn_spconv_fwd")
     return out
 
 

@@ -97,9 +97,11 @@ int gpn_voxelize_ex(const float* points, const float* feats, const int64_t* seg_
 #define GPN_TILE_ROWS 32
 
 /* SubM k=3 pad=1: indices [N,4] i32 (batch,x,y,z); tap = (dx+1)*9+(dy+1)*3+(dz+1); src = row at
- * coord(dst)+delta.  pair arrays need capacity 27*N.  num_pairs [1] i64. */
+ * coord(dst)+delta.  pair arrays need capacity 27*N.  num_pairs [1] i64.
+ * nbr (optional, capacity 27*N+1): the tap-major neighbour table nbr[k*N + dst] = src row or -1 that the fused
+ * conv kernel (gpn_spconv_fwd) gathers from; the pair lists are its compaction and feed gpn_spconv_wgrad. */
 size_t gpn_rulebook_subm3_ws_bytes(int64_t N);
-int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32_t* spatial_shape_host,
+int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32_t* spatial_shape_host, int32_t* nbr,
                        int32_t* pair_src, int32_t* pair_dst, int32_t* tile_off, int64_t* num_pairs,
                        void* ws, size_t ws_bytes, gpn_stream_t stream);
 
@@ -116,19 +118,11 @@ int gpn_rulebook_down(const int32_t* indices, int64_t N, int64_t batch_size,
 size_t gpn_rulebook_down_lists_ws_bytes(int64_t N, int64_t n_out);
 int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N,
                             int64_t n_out,
-                            int32_t* fwd_src, int32_t* fwd_dst, int32_t* fwd_tile_off, /* dst = coarse, cap N */
-                            int32_t* bwd_src, int32_t* bwd_dst, int32_t* bwd_tile_off, /* dst = fine, cap N */
+                            int32_t* fwd_nbr /* [8*n_out+1] or NULL */, int32_t* fwd_src, int32_t* fwd_dst,
+                            int32_t* fwd_tile_off, /* dst = coarse, cap N */
+                            int32_t* bwd_nbr /* [8*N+1] or NULL */, int32_t* bwd_src, int32_t* bwd_dst,
+                            int32_t* bwd_tile_off, /* dst = fine, cap N */
                             int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream);
-
-/* Block-list view of a rulebook, streamed by gpn_spconv_fwd: the pairs of each (wave tile of 32*tm dst rows, tap)
- * group padded to a multiple of 16 ("blocks"), ordered wave-tile-major, tap-minor.
- *   blk_src [16*B] i32 = src row or -1; blk_meta [16*B] i32 = (tap << 8) | (dst row - tile base) or -1;
- *   blk_off [n_wtiles*K + 1] i32 = first block of group w*K + k.   B <= gpn_rulebook_blocks_capacity(K, n_dst, tm). */
-int64_t gpn_rulebook_blocks_capacity(int K, int64_t n_dst, int tm);
-size_t gpn_rulebook_blocks_ws_bytes(int K, int64_t n_dst, int tm);
-int gpn_rulebook_blocks(const int32_t* pair_src, const int32_t* pair_dst, const int32_t* tile_off, int K,
-                        int64_t n_dst, int tm, int32_t* blk_src, int32_t* blk_meta, int32_t* blk_off, void* ws,
-                        size_t ws_bytes, gpn_stream_t stream);
 
 /* ================================================================================================
  * C — sparse convolution.  replaces the conv forward/backward inside spconv (network/backbone.py).
@@ -138,9 +132,8 @@ int gpn_rulebook_blocks(const int32_t* pair_src, const int32_t* pair_dst, const 
  *   a SubM conv uses both, dgrad of down/inverse convs uses transpose only.
  *   cin/cout here are the dims of the *packed* operator (after the optional transpose); both must be
  *   multiples of 16.  packed size = K*cin*cout floats.
- * gpn_spconv_fwd: out[dst] = sum_k in[src] @ W_k over the block-list view of a rulebook (out is fully
- *   overwritten; rows with no pair get zeros).  in [n_src, cin], out [n_dst, cout]; tm as given to
- *   gpn_rulebook_blocks.
+ * gpn_spconv_fwd: out[dst] = sum_k in[nbr[k][dst]] @ W_k over the tap-major neighbour table of a rulebook
+ *   (nbr [K, n_dst] i32, -1 = no neighbour; out is fully overwritten).  in [n_src, cin], out [n_dst, cout].
  * gpn_spconv_wgrad: dW[k] = sum_{pairs of k} in[src]^T (x) dout[dst]  -> dW [K, cin, cout] canonical.
  * ================================================================================================ */
 #define GPN_PACK_TRANSPOSE 1
@@ -148,9 +141,8 @@ int gpn_rulebook_blocks(const int32_t* pair_src, const int32_t* pair_dst, const 
 int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cout_w, int flags, float* packed,
                             gpn_stream_t stream);
 size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout);
-int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* blk_src, const int32_t* blk_meta,
-                   const int32_t* blk_off, int K, int64_t n_dst, int tm, int cin, int cout, float* out, void* ws,
-                   size_t ws_bytes, gpn_stream_t stream);
+int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* nbr, int K, int64_t n_dst, int cin,
+                   int cout, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream);
 size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst);
 int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
