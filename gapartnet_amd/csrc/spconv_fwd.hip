@@ -92,10 +92,11 @@ __global__ void spconv_fwd_kernel(const float* __restrict__ in, const float* __r
       if (q < SLAB_V4) slab[buf * SLAB_V4 + q] = r[j];
     }
   };
+  // raw table entry; validity (stage inside the range, row inside the tensor) is applied when the value is USED, so
+  // that nothing consumes the load result - and forces a wait - at issue time
   auto load_idx = [&](StageCursor sc) -> int32_t {
     const int k = sc.k < k_hi ? sc.k : k_hi - 1;
-    const int32_t v = nbr[(int64_t)k * n_dst + row_c];
-    return (sc.k < k_hi && row_ok) ? v : -1;
+    return nbr[(int64_t)k * n_dst + row_c];
   };
   auto load_a = [&](int32_t idx, int ch, f32x4 (&a)[CW]) {
     const int32_t s = idx < 0 ? 0 : idx;  // absent neighbours gather row 0 and are zeroed before the MFMA
@@ -128,7 +129,7 @@ __global__ void spconv_fwd_kernel(const float* __restrict__ in, const float* __r
     for (int u = 0; u < E; ++u) {
       const int stage = s0 + u;
       // ---- contraction of the current stage (skipped when no row of the tile has this neighbour) ----
-      const int32_t idx = ireg[u];
+      const int32_t idx = (stage < n_stages && row_ok) ? ireg[u] : -1;
       if (__builtin_amdgcn_ballot_w64(idx >= 0) != 0) {
         const f32x4* sb = slab + (stage & 1) * SLAB_V4 + lane;
 #pragma unroll
