@@ -249,7 +249,7 @@ class GAPartNet(LightningModule):
         sem_preds = sem_preds[valid].long()
         proposal_indices = proposals.proposal_indices[valid]
 
-        per_class = npcs_logits.reshape(npcs_logits.shape[0], -1, 3)
+        per_class = npcs_logits.reshape(npcs_logits.shape[0], npcs_logits.shape[1] // 3, 3)  # valid for 0 rows too
         npcs_preds = per_class.gather(1, (sem_preds - 1)[:, None, None].expand(-1, 1, 3)).squeeze(1)
 
         proposals.npcs_preds = npcs_preds.detach()

@@ -1,0 +1,69 @@
+"""The drop-in boundary: libgpn_hip.so must load (no GPU needed for that) and export every symbol include/gpn.h
+declares; argument checking must work without touching the device; the product path must refuse CPU tensors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gpn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpn_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gapartnet_amd import _C
+    if not os.path.exists(_C.SO_PATH):
+        _C.build()
+    return _C.lib()
+
+
+def test_header_declares_the_hot_path():
+    syms = declared_symbols()
+    for must in ("gpn_voxelize", "gpn_rulebook_subm3", "gpn_rulebook_down", "gpn_spconv_fwd", "gpn_spconv_wgrad",
+                 "gpn_ball_query", "gpn_ccl", "gpn_segmented_reduce", "gpn_segmented_maxpool_fwd", "gpn_instance_iou",
+                 "gpn_nms", "gpn_pn2_furthest_point_sampling", "gpn_pn2_three_nn", "gpn_pn2_ball_query"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(lib):
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_entry_point_registry_matches_header(lib):
+    n = lib.gpn_num_entry_points()
+    names = {lib.gpn_entry_point_name(i).decode() for i in range(n)}
+    declared = set(declared_symbols()) - {"gpn_num_entry_points", "gpn_entry_point_name"}
+    assert declared <= names | {"gpn_voxelize_ex"}, declared - names
+    assert lib.gpn_version() >= 1
+
+
+def test_argument_errors_do_not_touch_the_device(lib):
+    lib.gpn_last_error.restype = ctypes.c_char_p
+    rc = lib.gpn_spconv_fwd(None, None, None, ctypes.c_int(27), ctypes.c_int64(10), ctypes.c_int(15), ctypes.c_int(16), None,
+                            None, ctypes.c_size_t(0), None)
+    assert rc == 1 and b"bad argument" in lib.gpn_last_error()
+    rc = lib.gpn_segmented_reduce(None, None, None, ctypes.c_int64(4), ctypes.c_int(3), ctypes.c_int(7), None, None)
+    assert rc == 1
+    assert lib.gpn_spconv_wgrad_ws_bytes(ctypes.c_int(27), ctypes.c_int(32), ctypes.c_int(32), ctypes.c_int64(100000)) > 0
+
+
+def test_workspace_queries_are_pure(lib):
+    assert lib.gpn_voxelize_ws_bytes(ctypes.c_int64(20000), ctypes.c_int(6)) > 20000 * 8
+    assert lib.gpn_rulebook_subm3_ws_bytes(ctypes.c_int64(1000)) > 27 * 1000 * 4
+    assert lib.gpn_ccl_ws_bytes(ctypes.c_int64(1000)) >= 3 * 4000
+
+
+def test_product_path_has_no_cpu_fallback():
+    from gapartnet_amd import _C, hip_ops
+    with pytest.raises(_C.GpnError):
+        hip_ops.segmented_reduce(torch.zeros(4, 3), torch.zeros(1, dtype=torch.int32), torch.ones(1, dtype=torch.int32), "sum")
+    from gapartnet_amd import backend
+    assert backend.raw() is hip_ops
