@@ -1,0 +1,113 @@
+"""GPU tests above the operator level: the whole pipeline on the HIP path vs the same pipeline over the CPU oracle
+(small sizes), and size-independent properties at BASELINE.json's full sizes (20k-point scenes, batch 8; 50k-point
+scene) where the oracle would be too slow."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from gapartnet_amd import backend
+from gapartnet_amd.smoke import make_batch, make_model, run_smoke
+from gapartnet_amd.structure.point_cloud import PointCloud
+
+pytestmark = pytest.mark.gpu
+
+
+def test_smoke_train_step_matches_oracle(cuda):
+    res = run_smoke(cuda)
+    assert abs(res["loss"] - res["oracle_loss"]) < 2e-3 * max(1.0, abs(res["oracle_loss"]))
+
+
+def test_backbone_features_within_1e4_of_oracle(cuda):
+    """north_star tolerance: fp features within 1e-4 (eval mode, so BatchNorm uses fixed statistics)."""
+    from oracle import torch_ops
+    model = make_model((999, 999), channels=[16, 32, 48, 64]).eval()
+    batch = make_batch(2, 3000)
+    with torch.no_grad():
+        with backend.using(torch_ops):
+            ref_batch = PointCloud.collate(batch, voxel_size=(0.01, 0.01, 0.01))
+            ref = model.forward_backbone(ref_batch)
+        gpu_model = copy.deepcopy(model).to(cuda)
+        gpu_batch = PointCloud.collate([pc.to(cuda) for pc in batch], voxel_size=(0.01, 0.01, 0.01))
+        got = gpu_model.forward_backbone(gpu_batch)
+    assert torch.equal(gpu_batch.voxel_tensor.indices.cpu(), ref_batch.voxel_tensor.indices), "voxel indices: bit-exact"
+    assert torch.equal(gpu_batch.pc_voxel_id.cpu(), ref_batch.pc_voxel_id)
+    assert torch.equal(gpu_batch.voxel_tensor.features.cpu(), ref_batch.voxel_tensor.features), "ordered means: bit-exact"
+    err = (got.cpu() - ref).abs().max().item()
+    assert err < 1e-4, err
+
+
+def test_cluster_labels_bit_exact_vs_oracle(cuda):
+    from gapartnet_amd.network import grouping_utils as G
+    from oracle import torch_ops
+    from tests import synth
+    rng = np.random.default_rng(4)
+    pts, batch = synth.clustered_points(rng, 4, 5000, n_clusters=10)
+    offs = torch.tensor([0, 5000, 10000, 15000, 20000], dtype=torch.int32)
+    sem = torch.from_numpy(rng.integers(1, 4, 20000).astype(np.int32))
+    with backend.using(torch_ops):
+        ref = G.cluster_proposals(torch.from_numpy(pts), torch.from_numpy(batch), offs, sem, 0.04, 50)
+    got = G.cluster_proposals(torch.from_numpy(pts).to(cuda), torch.from_numpy(batch).to(cuda), offs.to(cuda), sem.to(cuda), 0.04, 50)
+    assert torch.equal(got[0].cpu(), ref[0]) and torch.equal(got[1].cpu(), ref[1])
+
+
+@pytest.mark.parametrize("n_scenes,n_points", [(8, 20000), (1, 50000)])
+def test_full_size_properties(cuda, n_scenes, n_points):
+    """BASELINE sizes: voxel/rulebook invariants that need no oracle."""
+    from gapartnet_amd import hip_ops as H
+    batch = [pc.to(cuda) for pc in make_batch(n_scenes, n_points)]
+    data = PointCloud.collate(batch, voxel_size=(0.01, 0.01, 0.01))
+    vt, pid = data.voxel_tensor, data.pc_voxel_id
+    V = vt.indices.shape[0]
+    assert pid.min() >= 0 and int(pid.max()) == V - 1 and torch.unique(pid).numel() == V  # every voxel has a point
+    idx = vt.indices.long()
+    key = ((idx[:, 0] * vt.spatial_shape[0] + idx[:, 1]) * vt.spatial_shape[1] + idx[:, 2]) * vt.spatial_shape[2] + idx[:, 3]
+    assert bool((key[1:] > key[:-1]).all()), "voxels sorted by (scene,x,y,z), unique"
+    # voxel feature = mean of its points: the count-weighted sum of voxel means reproduces the point sum
+    counts = torch.bincount(pid.long(), minlength=V).float()
+    assert torch.allclose((vt.features * counts[:, None]).sum(0), data.points.sum(0), rtol=1e-4, atol=1e-2)
+    # point -> voxel map agrees with the coordinates
+    order, starts = data.pc_voxel_csr
+    assert int(starts[-1]) == data.points.shape[0] and torch.equal(pid[order.long()], torch.repeat_interleave(torch.arange(V, device=cuda), counts.long()).int())
+    # SubM rulebook: centre tap is the identity, pair (i -> o) at tap k implies (o -> i) at tap 26 - k
+    rb = H.rulebook_subm3(vt.indices, vt.spatial_shape)
+    nbr = rb.nbr[:27 * V].reshape(27, V)
+    assert torch.equal(nbr[13], torch.arange(V, device=cuda, dtype=torch.int32))
+    k = 5
+    o = torch.nonzero(nbr[k] >= 0)[:, 0]
+    assert torch.equal(nbr[26 - k][nbr[k][o].long()], o.int())
+    P = int(rb.num_pairs.item())
+    assert P == int((nbr >= 0).sum()) and torch.equal(rb.tile_off[:, -1], torch.cumsum((nbr >= 0).sum(1), 0).int())
+    # linearity of the conv kernel at full size: conv(a x + y) == a conv(x) + conv(y) up to fp32 rounding
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(V, 16, generator=g).to(cuda)
+    y = torch.randn(V, 16, generator=g).to(cuda)
+    W = (torch.randn(27, 16, 32, generator=g) / 20).to(cuda)
+    lhs = H.conv_fwd(2.5 * x + y, W, rb)
+    rhs = 2.5 * H.conv_fwd(x, W, rb) + H.conv_fwd(y, W, rb)
+    assert torch.allclose(lhs, rhs, atol=1e-4, rtol=1e-4)
+    # dgrad is the adjoint of fwd: <conv(x), g> == <x, dgrad(g)>
+    gg = torch.randn(V, 32, generator=g).to(cuda)
+    a = (H.conv_fwd(x, W, rb) * gg).sum().item()
+    b = (x * H.conv_dgrad(gg, W, rb, rb, True)).sum().item()
+    assert abs(a - b) <= 1e-3 * max(1.0, abs(a))
+    # down conv: every fine voxel maps to exactly one coarse voxel; inverse restores the fine set
+    out_idx, out_shape, rb_f, rb_b = H.rulebook_down(vt.indices, vt.spatial_shape, n_scenes)
+    assert int(rb_f.num_pairs.item()) == V and out_shape == [s // 2 for s in vt.spatial_shape]
+    assert torch.equal(torch.sort(rb_b.pair_dst[:V])[0], torch.arange(V, device=cuda, dtype=torch.int32))
+
+
+def test_full_size_train_step_runs_and_is_deterministic(cuda):
+    batch = [pc.to(cuda) for pc in make_batch(4, 20000)]
+    jitter = (torch.tensor([0.3, 0.6, 0.1], device=cuda), torch.tensor([0.5, 0.2, 0.9], device=cuda))
+    losses, grads = [], []
+    for _ in range(2):
+        model = make_model((0, 0)).to(cuda)
+        model.revoxelize_jitter = jitter
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        losses.append(float(loss))
+        grads.append(model.backbone.stem[0].weight.grad.clone())
+    assert np.isfinite(losses[0]) and losses[0] == losses[1], losses
+    assert torch.equal(grads[0], grads[1]), "conv fwd / dgrad / wgrad are fixed-order: bitwise reproducible"
