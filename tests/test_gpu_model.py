@@ -94,8 +94,12 @@ def test_full_size_properties(cuda, n_scenes, n_points):
     assert abs(a - b) <= 1e-3 * max(1.0, abs(a))
     # down conv: every fine voxel maps to exactly one coarse voxel; inverse restores the fine set
     out_idx, out_shape, rb_f, rb_b = H.rulebook_down(vt.indices, vt.spatial_shape, n_scenes)
-    assert int(rb_f.num_pairs.item()) == V and out_shape == [s // 2 for s in vt.spatial_shape]
-    assert torch.equal(torch.sort(rb_b.pair_dst[:V])[0], torch.arange(V, device=cuda, dtype=torch.int32))
+    assert out_shape == [s // 2 for s in vt.spatial_shape]
+    kept = ((idx[:, 1:] // 2) < torch.tensor(out_shape, device=cuda)).all(1)  # an odd extent drops its last plane
+    Pd = int(rb_f.num_pairs.item())
+    assert Pd == int(kept.sum()) and V - Pd < 0.01 * V
+    assert torch.equal(torch.sort(rb_b.pair_dst[:Pd])[0], torch.nonzero(kept)[:, 0].int())
+    assert int(torch.unique(rb_f.pair_dst[:Pd]).numel()) == out_idx.shape[0]
 
 
 def test_full_size_train_step_runs_and_is_deterministic(cuda):
