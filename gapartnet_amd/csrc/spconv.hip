@@ -80,27 +80,52 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int32_t p0 = a + 4 * wave; p0 < b; p0 += 16) {
-    const int32_t p = p0 + g;
-    const bool valid = p < b;
-    const int32_t src = valid ? pair_src[p] : 0;
-    const int32_t dst = valid ? pair_dst[p] : 0;
-    float av[CT], bv[NT];
+  // branch-free 2-deep software pipeline (pair indices two trips ahead, gathered values one trip ahead): addresses
+  // are clamped instead of guarded so the compiler can count the loads (partial s_waitcnt vmcnt) - lane-divergent
+  // guards made every trip pay two full dependent memory latencies.  Out-of-range lanes are zeroed at use.
+  int32_t p0 = a + 4 * wave;
+  if (p0 < b) {
+    const int32_t last = b - 1;
+    auto ld_idx = [&](int32_t q0, int32_t& s_, int32_t& d_) {
+      int32_t q = q0 + g;
+      q = q < last ? q : last;
+      s_ = pair_src[q];
+      d_ = pair_dst[q];
+    };
+    auto ld_rows = [&](int32_t s_, int32_t d_, float (&av)[CT], float (&bv)[NT]) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      av[ct] = 0.f;
-      if (valid && ct0 + ct < ct_tiles) av[ct] = in[(int64_t)src * cin + (ct0 + ct) * 16 + i16];
+      for (int ct = 0; ct < CT; ++ct) {
+        const int t = (ct0 + ct < ct_tiles) ? (ct0 + ct) : (ct_tiles - 1);
+        av[ct] = in[(int64_t)s_ * cin + t * 16 + i16];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt] = dout[(int64_t)d_ * COUT + nt * 16 + i16];
+    };
+    int32_t s0, d0, s1, d1;
+    float av0[CT], bv0[NT];
+    ld_idx(p0, s0, d0);
+    ld_idx(p0 + 16, s1, d1);
+    ld_rows(s0, d0, av0, bv0);
+    for (; p0 < b; p0 += 16) {
+      int32_t s2, d2;
+      ld_idx(p0 + 32, s2, d2);
+      float av1[CT], bv1[NT];
+      ld_rows(s1, d1, av1, bv1);
+      const bool valid = p0 + g < b;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const float a_ = (valid && ct0 + ct < ct_tiles) ? av0[ct] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bv0[nt], acc[ct][nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) av0[ct] = av1[ct];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv0[nt] = bv1[nt];
+      s1 = s2;
+      d1 = d2;
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      bv[nt] = 0.f;
-      if (valid) bv[nt] = dout[(int64_t)dst * COUT + nt * 16 + i16];
-    }
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct], bv[nt], acc[ct][nt], 0, 0, 0);
   }
 
   // fixed-order reduction over the 4 waves through LDS (element (ct,nt,r,lane) -> red[((ct*NT+nt)*4+r)*64+lane])
@@ -140,15 +165,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, in
   dW[t] = acc;
 }
 
-int wgrad_splits(int K, int cin, int64_t n_dst) {
+int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
   const int ct_tiles = cin / 16;
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int cig = (ct_tiles + CT - 1) / CT;
-  int64_t S = 1024 / ((int64_t)K * cig);
-  int64_t cap = n_dst / 256;
+  // enough pair slices for ~4096 workgroups (each slice is a latency-bound gather loop), at least ~128 dst rows
+  // per slice, and at most 64 MB of partials
+  int64_t S = 4096 / ((int64_t)K * cig);
+  const int64_t cap = n_dst / 128;
   if (S > cap) S = cap;
+  const int64_t mem_cap = ((int64_t)64 << 20) / ((int64_t)K * cin * cout * 4);
+  if (S > mem_cap) S = mem_cap;
   if (S < 1) S = 1;
-  if (S > 256) S = 256;
+  if (S > 512) S = 512;
   return (int)S;
 }
 
@@ -230,7 +259,7 @@ extern "C" int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cou
 }
 
 extern "C" size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst) {
-  const int S = wgrad_splits(K, cin, n_dst);
+  const int S = wgrad_splits(K, cin, cout, n_dst);
   return gpn::align_up((size_t)S * K * cin * cout * sizeof(float));
 }
 
@@ -246,7 +275,7 @@ extern "C" int gpn_spconv_wgrad(const float* in, const float* dout, const int32_
     return GPN_OK;
   }
   GPN_CHECK_ARG(in && dout && pair_src && pair_dst && tile_off);
-  const int S = wgrad_splits(K, cin, n_dst);
+  const int S = wgrad_splits(K, cin, cout, n_dst);
   if (ws_bytes < (size_t)S * elems * sizeof(float) || !ws) {
     gpn::set_error("gpn_spconv_wgrad: workspace too small");
     return GPN_ERR_WS;
