@@ -1,0 +1,240 @@
+// bn.hip — BatchNorm1d over sparse-tensor feature matrices [N, C], fused with the residual add and ReLU that follow
+// it in every block of the reference network (network/backbone.py:40-49: relu(bn(conv(x)) [+ shortcut])).
+//
+// HBM-streaming kernels: [N, C] row-major with C in 16..224, read as float4.  Training forward = statistics pass
+// (per-workgroup partial sums, combined in double for a cancellation-safe variance) + tiny finalize (mean, 1/std,
+// running-stat update) + one apply pass that also adds the residual and applies ReLU.  Backward = one reduction pass
+// (sum g, sum g*xhat with the ReLU mask folded in) + finalize + one apply pass producing dx (and the residual's
+// gradient).  Compared with separate BatchNorm / add / ReLU kernels this removes three full read+write passes per
+// layer in forward and two in backward.  All reductions are fixed-order (deterministic).
+#include "gpn_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 512;
+
+// thread layout for column-wise reductions: c4 = tid % C4 (float4 column), r = tid / C4 (row lane), R = 256 / C4 rows
+template <bool BWD>
+__global__ __launch_bounds__(kThreads) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int64_t N, int C4, int relu,
+                                                             double* __restrict__ partial /* [blocks][2][C] */) {
+  __shared__ double red[2][kThreads][4];
+  const int R = kThreads / C4;
+  const int r = threadIdx.x / C4, c4 = threadIdx.x - r * C4;
+  const bool lane_ok = r < R;
+  const int C = C4 * 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+  if (BWD && lane_ok) {
+    mu = reinterpret_cast<const f32x4*>(mean)[c4];
+    is = reinterpret_cast<const f32x4*>(invstd)[c4];
+  }
+  // rows are dealt to workgroups in contiguous chunks (fixed assignment => fixed summation order)
+  const int64_t rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t row_end = row_begin + rows_per_block < N ? row_begin + rows_per_block : N;
+  if (lane_ok) {
+    for (int64_t row = row_begin + r; row < row_end; row += R) {
+      const f32x4 xv = reinterpret_cast<const f32x4*>(x)[row * C4 + c4];
+      if (!BWD) {
+        s0 += xv;
+        s1 += xv * xv;
+      } else {
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[row * C4 + c4];
+        if (relu) {
+          const f32x4 yv = reinterpret_cast<const f32x4*>(y)[row * C4 + c4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+        }
+        s0 += g;
+        s1 += g * ((xv - mu) * is);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[0][threadIdx.x][j] = (double)s0[j];
+    red[1][threadIdx.x][j] = (double)s1[j];
+  }
+  __syncthreads();
+  // one thread per (quantity, channel): ordered sum over the R row lanes
+  for (int e = threadIdx.x; e < 2 * C; e += kThreads) {
+    const int q = e / C, c = e - q * C;
+    const int cc4 = c >> 2, j = c & 3;
+    double acc = 0.0;
+    for (int rr = 0; rr < R; ++rr) acc += red[q][rr * C4 + cc4][j];
+    partial[((int64_t)blockIdx.x * 2 + q) * C + c] = acc;
+  }
+}
+
+// forward finalize: mean / invstd, running statistics (momentum; unbiased variance as torch.nn.BatchNorm1d)
+__global__ void bn_finalize_fwd_kernel(const double* __restrict__ partial, int blocks, int64_t N, int C, float eps,
+                                       float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    s += partial[((int64_t)b * 2 + 0) * C + c];
+    ss += partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  const double m = s / (double)N;
+  double var = ss / (double)N - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = N > 1 ? var * ((double)N / (double)(N - 1)) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+// y = relu?( (x - mean) * invstd * w + b [+ res] )
+__global__ void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ weight, const float* __restrict__ bias, int64_t total4,
+                                    int C4, int relu, float* __restrict__ y) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(t % C4);
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+    const f32x4 w = reinterpret_cast<const f32x4*>(weight)[c4], b = reinterpret_cast<const f32x4*>(bias)[c4];
+    f32x4 v = (reinterpret_cast<const f32x4*>(x)[t] - mu) * is * w + b;
+    if (res) v += reinterpret_cast<const f32x4*>(res)[t];
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(y)[t] = v;
+  }
+}
+
+// backward finalize: dweight = sum g*xhat, dbias = sum g
+__global__ void bn_finalize_bwd_kernel(const double* __restrict__ partial, int blocks, int C, float* __restrict__ dweight,
+                                       float* __restrict__ dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    s += partial[((int64_t)b * 2 + 0) * C + c];
+    ss += partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  dbias[c] = (float)s;
+  dweight[c] = (float)ss;
+}
+
+// dx = invstd * w * (g - dbias/N - xhat * dweight/N)   (training)   |   dx = invstd * w * g   (eval);  dres = g
+__global__ void bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ weight, const float* __restrict__ dweight,
+                                    const float* __restrict__ dbias, int64_t total4, int C4, float inv_n, int relu,
+                                    int training, float* __restrict__ dx, float* __restrict__ dres) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(t % C4);
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+    const f32x4 w = reinterpret_cast<const f32x4*>(weight)[c4];
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[t];
+    if (relu) {
+      const f32x4 yv = reinterpret_cast<const f32x4*>(y)[t];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+    }
+    if (dres) reinterpret_cast<f32x4*>(dres)[t] = g;
+    f32x4 v = g;
+    if (training) {
+      const f32x4 dw = reinterpret_cast<const f32x4*>(dweight)[c4], db = reinterpret_cast<const f32x4*>(dbias)[c4];
+      const f32x4 xhat = (reinterpret_cast<const f32x4*>(x)[t] - mu) * is;
+      v = g - db * inv_n - xhat * (dw * inv_n);
+    }
+    reinterpret_cast<f32x4*>(dx)[t] = v * is * w;
+  }
+}
+
+int reduce_blocks(int64_t N, int C4) {
+  const int R = kThreads / C4;
+  int64_t b = gpn::cdiv(N, (int64_t)R * 8);
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int apply_grid(int64_t total4) {
+  int64_t g = gpn::cdiv(total4, kThreads);
+  if (g > 4096) g = 4096;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" size_t gpn_bn_ws_bytes(int64_t N, int C) {
+  (void)N;
+  return gpn::align_up((size_t)kMaxBlocks * 2 * C * sizeof(double));
+}
+
+// training forward: batch statistics (saved in mean / invstd for backward), optional running-stat update
+extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* weight, const float* bias, int64_t N,
+                                int C, float eps, float momentum, int relu, float* y, float* mean, float* invstd,
+                                float* running_mean, float* running_var, void* ws, size_t ws_bytes,
+                                gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024);
+  GPN_CHECK_ARG(x && weight && bias && y && mean && invstd && ws);
+  GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
+  GPN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  const int C4 = C / 4;
+  const int blocks = reduce_blocks(N, C4);
+  double* partial = static_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(blocks), dim3(kThreads), 0, stream, x, nullptr, nullptr, nullptr,
+                     nullptr, N, C4, 0, partial);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)gpn::cdiv(C, 64)), dim3(64), 0, stream, partial, blocks, N, C,
+                     eps, momentum, mean, invstd, running_mean, running_var);
+  GPN_CHECK_LAUNCH();
+  const int64_t total4 = N * C4;
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, res, mean, invstd,
+                     weight, bias, total4, C4, relu, y);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+// eval forward: y = act((x - mean) * invstd * w + b [+ res]) with caller-provided mean / invstd
+extern "C" int gpn_bn_fwd_eval(const float* x, const float* res, const float* weight, const float* bias,
+                               const float* mean, const float* invstd, int64_t N, int C, int relu, float* y,
+                               gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(N >= 0 && C >= 4 && C % 4 == 0);
+  if (N == 0) return GPN_OK;
+  GPN_CHECK_ARG(x && weight && bias && mean && invstd && y);
+  const int64_t total4 = N * (C / 4);
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, res, mean, invstd,
+                     weight, bias, total4, C / 4, relu, y);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+// backward of both modes.  y is the forward output (needed for the ReLU mask when relu != 0); dres may be NULL.
+extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* mean,
+                          const float* invstd, int64_t N, int C, int relu, int training, float* dx, float* dres,
+                          float* dweight, float* dbias, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024);
+  GPN_CHECK_ARG(x && dy && weight && mean && invstd && dx && dweight && dbias && ws && (y || !relu));
+  GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
+  const int C4 = C / 4;
+  const int blocks = reduce_blocks(N, C4);
+  double* partial = static_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(blocks), dim3(kThreads), 0, stream, x, y, dy, mean, invstd, N, C4, relu,
+                     partial);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)gpn::cdiv(C, 64)), dim3(64), 0, stream, partial, blocks, C,
+                     dweight, dbias);
+  GPN_CHECK_LAUNCH();
+  const int64_t total4 = N * C4;
+  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, y, dy, mean, invstd,
+                     weight, dweight, dbias, total4, C4, 1.0f / (float)N, relu, training, dx, dres);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}

@@ -112,3 +112,40 @@ class _SegmentedMaxpoolFn(torch.autograd.Function):
 
 def segmented_maxpool(values, begin, end):
     return _SegmentedMaxpoolFn.apply(values, begin, end)
+
+
+class _BnActFn(torch.autograd.Function):
+    """y = act(batch_norm(x) [+ residual]) as one op (kernel family BN)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        ops = backend.raw()
+        y, mean, invstd = ops.bn_fwd(x.contiguous(), None if residual is None else residual.contiguous(), weight, bias,
+                                     running_mean, running_var, training, momentum, eps, relu)
+        ctx.save_for_backward(x, y, weight, mean, invstd)
+        ctx.relu, ctx.training, ctx.has_res = relu, training, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = backend.raw()
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        dx, dres, dw, db = ops.bn_bwd(x, y, dy.contiguous(), weight, mean, invstd, ctx.relu, ctx.training, ctx.has_res)
+        return dx, dres, dw, db, None, None, None, None, None, None
+
+
+def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``relu(bn(x) + residual)`` (any of the two optional) with the parameters / running statistics of the given
+    ``nn.BatchNorm1d`` module, in its current train/eval mode.  Falls back to the module itself for shapes the fused
+    kernels do not cover (C % 4 != 0, empty input, no affine / running stats)."""
+    C = x.shape[1]
+    if x.shape[0] == 0 or C % 4 != 0 or not bn.affine or not bn.track_running_stats or bn.momentum is None:
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BnActFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, float(bn.momentum),
+                          float(bn.eps), bool(relu))

@@ -199,6 +199,47 @@ def conv_wgrad(features, dout, rb: Rulebook):
     return dW
 
 
+# ---------------------------------------------------------------------------------------------------- BN
+def bn_fwd(x, res, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    """fused BatchNorm1d(+residual)(+ReLU) forward -> (y, mean, invstd); running stats updated in place when training."""
+    dev = _dev(x, res, weight, bias)
+    x = _c(x, torch.float32)
+    res = _c(res, torch.float32)
+    N, C = x.shape
+    y = torch.empty_like(x)
+    L = _C.lib()
+    if training:
+        mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        ws = _ws(L.gpn_bn_ws_bytes(i64(N), i32(C)), dev)
+        check(L.gpn_bn_fwd_train(ptr(x), ptr(res), ptr(weight), ptr(bias), i64(N), i32(C), f32(eps), f32(momentum),
+                                 i32(1 if relu else 0), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
+                                 ptr(running_var), ptr(ws), szt(ws.numel()), _stream()), "gpn_bn_fwd_train")
+    else:
+        mean = running_mean
+        invstd = torch.rsqrt(running_var + eps)
+        check(L.gpn_bn_fwd_eval(ptr(x), ptr(res), ptr(weight), ptr(bias), ptr(mean), ptr(invstd), i64(N), i32(C),
+                                i32(1 if relu else 0), ptr(y), _stream()), "gpn_bn_fwd_eval")
+    return y, mean, invstd
+
+
+def bn_bwd(x, y, dy, weight, mean, invstd, relu, training, has_res):
+    """-> (dx, dres or None, dweight, dbias)"""
+    dev = _dev(x, dy)
+    x, dy = _c(x, torch.float32), _c(dy, torch.float32)
+    N, C = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if has_res else None
+    dw = torch.empty((C,), dtype=torch.float32, device=dev)
+    db = torch.empty((C,), dtype=torch.float32, device=dev)
+    L = _C.lib()
+    ws = _ws(L.gpn_bn_ws_bytes(i64(N), i32(C)), dev)
+    check(L.gpn_bn_bwd(ptr(x), ptr(y), ptr(dy), ptr(weight), ptr(mean), ptr(invstd), i64(N), i32(C), i32(1 if relu else 0),
+                       i32(1 if training else 0), ptr(dx), ptr(dres), ptr(dw), ptr(db), ptr(ws), szt(ws.numel()),
+                       _stream()), "gpn_bn_bwd")
+    return dx, dres, dw, db
+
+
 # ---------------------------------------------------------------------------------------------------- G
 def gather_rows(table, idx):
     dev = _dev(table, idx)

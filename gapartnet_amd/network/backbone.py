@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import functional as GF
 from ..spconv import pytorch as spconv
 
 NormFn = Callable[[int], nn.Module]
@@ -43,10 +44,12 @@ class ResBlock(spconv.SparseModule):
 
     def forward(self, x: spconv.SparseConvTensor) -> spconv.SparseConvTensor:
         skip = self.shortcut(x)
-        y = self.conv1(x)
-        y = y.replace_feature(F.relu(y.features))
-        y = self.conv2(y)
-        return y.replace_feature(F.relu(y.features + skip.features))
+        # conv -> BatchNorm -> ReLU, then conv -> BatchNorm -> (+ skip) -> ReLU: BN, residual add and ReLU run as one
+        # fused op per layer (gapartnet_amd.functional.bn_act) on the parameters of the BatchNorm1d sub-modules
+        y = self.conv1[0](x)
+        y = y.replace_feature(GF.bn_act(y.features, self.conv1[1], relu=True))
+        y = self.conv2[0](y)
+        return y.replace_feature(GF.bn_act(y.features, self.conv2[1], relu=True, residual=skip.features))
 
 
 class UBlock(nn.Module):

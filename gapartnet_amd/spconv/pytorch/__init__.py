@@ -100,14 +100,24 @@ class SparseSequential(SparseModule):
         return list(self._modules.values())[idx]
 
     def forward(self, x):
-        for module in self._modules.values():
+        modules = list(self._modules.values())
+        i = 0
+        while i < len(modules):
+            module = modules[i]
             if _is_sparse(module):
                 x = module(x)
             elif isinstance(x, SparseConvTensor):
                 if x.features.shape[0] > 0:
-                    x = x.replace_feature(module(x.features))
+                    if isinstance(module, nn.BatchNorm1d):
+                        # BatchNorm1d [+ ReLU] on a feature matrix: one fused kernel family (csrc/bn.hip)
+                        fuse_relu = i + 1 < len(modules) and isinstance(modules[i + 1], nn.ReLU)
+                        x = x.replace_feature(GF.bn_act(x.features, module, relu=fuse_relu))
+                        i += 1 if fuse_relu else 0
+                    else:
+                        x = x.replace_feature(module(x.features))
             else:
                 x = module(x)
+            i += 1
         return x
 
 

@@ -148,6 +148,23 @@ int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src
                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
                      int cout, float* dW, void* ws, size_t ws_bytes, gpn_stream_t stream);
 
+/* BN — BatchNorm1d over a feature matrix [N, C] fused with the residual add and ReLU that follow it in every block of
+ * the reference network (network/backbone.py:40-49 relu(bn(conv(x)) [+ shortcut]); norm_fn = BatchNorm1d(eps=1e-4,
+ * momentum=0.1), network/model.py:86).  C % 4 == 0.  res may be NULL; relu = 0/1.
+ * train: batch statistics (biased variance) -> mean / invstd [C] outputs (saved for backward); running_mean/var (may be
+ *   NULL) are updated in place with `momentum` and the unbiased variance, as torch.nn.BatchNorm1d does.
+ * eval: caller passes mean = running_mean and invstd = 1/sqrt(running_var + eps).
+ * bwd: y = forward output (ReLU mask), dy = its gradient -> dx, dres (NULL if no residual), dweight, dbias. */
+size_t gpn_bn_ws_bytes(int64_t N, int C);
+int gpn_bn_fwd_train(const float* x, const float* res, const float* weight, const float* bias, int64_t N, int C,
+                     float eps, float momentum, int relu, float* y, float* mean, float* invstd, float* running_mean,
+                     float* running_var, void* ws, size_t ws_bytes, gpn_stream_t stream);
+int gpn_bn_fwd_eval(const float* x, const float* res, const float* weight, const float* bias, const float* mean,
+                    const float* invstd, int64_t N, int C, int relu, float* y, gpn_stream_t stream);
+int gpn_bn_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* mean,
+               const float* invstd, int64_t N, int C, int relu, int training, float* dx, float* dres, float* dweight,
+               float* dbias, void* ws, size_t ws_bytes, gpn_stream_t stream);
+
 /* G — row gather voxels->points and its deterministic transpose (model.py:153,359,394).
  * out[i] = idx[i] >= 0 ? table[idx[i]] : 0.   bwd: dtable[r] = sum_{i: idx[i]==r} dout[i] using the
  * CSR (order,starts) of points grouped by row (ascending point order inside a row). */

@@ -66,6 +66,41 @@ def conv_wgrad(features, dout, rb):
     return _t(O.spconv_wgrad(_np(features), _np(dout), _lists(rb), rb.n_dst, rb.K))
 
 
+def bn_fwd(x, res, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    """plain-torch restatement of BatchNorm1d (+ residual) (+ ReLU), network/backbone.py:40-49 / model.py:86"""
+    if training:
+        mean = x.double().mean(0)
+        var = x.double().var(0, unbiased=False)
+        invstd = (1.0 / torch.sqrt(var + eps)).float()
+        if running_mean is not None:
+            n = x.shape[0]
+            unbiased = var * (n / (n - 1)) if n > 1 else var
+            running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+            running_var.mul_(1 - momentum).add_(momentum * unbiased.float())
+        mean = mean.float()
+    else:
+        mean, invstd = running_mean, torch.rsqrt(running_var + eps)
+    y = (x - mean) * invstd * weight + bias
+    if res is not None:
+        y = y + res
+    if relu:
+        y = torch.relu(y)
+    return y, mean, invstd
+
+
+def bn_bwd(x, y, dy, weight, mean, invstd, relu, training, has_res):
+    g = torch.where(y > 0, dy, torch.zeros_like(dy)) if relu else dy
+    xhat = (x - mean) * invstd
+    db = g.double().sum(0).float()
+    dw = (g.double() * xhat.double()).sum(0).float()
+    if training:
+        n = x.shape[0]
+        dx = (g - db / n - xhat * (dw / n)) * invstd * weight
+    else:
+        dx = g * invstd * weight
+    return dx, (g if has_res else None), dw, db
+
+
 def gather_rows(table, idx):
     return _t(O.gather_rows(_np(table), _np(idx)))
 

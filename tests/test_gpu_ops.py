@@ -291,3 +291,39 @@ def test_fps_tie_break_small_cloud(H, cuda):
     # regular grid -> many exact distance ties; n = 1000 -> reference block size 512
     g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(10), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
     assert np.array_equal(host(H.pn2_furthest_point_sampling(dev(g, cuda), 64)), O.pn2_furthest_point_sampling(g, 64))
+
+
+# ------------------------------------------------------------------------------------------------ BN
+@pytest.mark.parametrize("N,C,relu,with_res,training", [(20000, 16, True, True, True), (777, 48, True, False, True),
+                                                          (136, 112, False, False, True), (5000, 32, True, True, False),
+                                                          (3, 16, True, False, True)])
+def test_fused_batchnorm_matches_torch(H, cuda, N, C, relu, with_res, training):
+    """fp32 torch.nn.functional.batch_norm (+ add + relu) is the reference for this floating-point kernel family;
+    tolerance 1e-4 (north_star) on outputs, 1e-3 relative on the reduced parameter gradients."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(N + C)
+    x = (torch.randn(N, C, generator=g) * 2 + 0.5).to(cuda).requires_grad_(True)
+    res = torch.randn(N, C, generator=g).to(cuda).requires_grad_(True) if with_res else None
+    w = (torch.rand(C, generator=g) + 0.5).to(cuda).requires_grad_(True)
+    b = torch.randn(C, generator=g).to(cuda).requires_grad_(True)
+    rm0, rv0 = torch.randn(C, generator=g).to(cuda) * 0.1, (torch.rand(C, generator=g) + 0.5).to(cuda)
+    rm, rv = rm0.clone(), rv0.clone()
+    ref = F.batch_norm(x, rm, rv, w, b, training=training, momentum=0.1, eps=1e-4)
+    if with_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    dy = torch.randn(N, C, generator=g).to(cuda)
+    grads_ref = torch.autograd.grad(ref, [x, w, b] + ([res] if with_res else []), dy)
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    y, mean, invstd = H.bn_fwd(x.detach(), None if res is None else res.detach(), w.detach(), b.detach(), rm2, rv2,
+                               training, 0.1, 1e-4, relu)
+    assert torch.allclose(y, ref.detach(), atol=1e-4, rtol=1e-4)
+    if training and N > 1:
+        assert torch.allclose(rm2, rm, atol=1e-5) and torch.allclose(rv2, rv, atol=1e-4, rtol=1e-4)
+    dx, dres, dw, db = H.bn_bwd(x.detach(), y, dy, w.detach(), mean, invstd, relu, training, with_res)
+    assert torch.allclose(dx, grads_ref[0], atol=2e-4, rtol=1e-3)
+    assert torch.allclose(dw, grads_ref[1], atol=1e-3 * max(1.0, float(grads_ref[1].abs().max())), rtol=1e-3)
+    assert torch.allclose(db, grads_ref[2], atol=1e-3 * max(1.0, float(grads_ref[2].abs().max())), rtol=1e-3)
+    if with_res:
+        assert torch.allclose(dres, grads_ref[3], atol=1e-6)

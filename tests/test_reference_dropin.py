@@ -61,7 +61,8 @@ def test_reference_backbone_runs_on_the_mirrors_and_matches(reference_modules):
     for net in (mine, theirs):
         x = spconv.SparseConvTensor(feats, torch.from_numpy(idx), [40, 40, 40], 2)
         outs.append(net(x).features)
-    assert torch.equal(outs[0], outs[1])
+    # same module tree and weights; this repo fuses BatchNorm + residual + ReLU into one op, so equality is to rounding
+    assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-5)
 
 
 def test_reference_grouping_glue_matches(reference_modules):
