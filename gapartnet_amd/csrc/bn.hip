@@ -70,17 +70,32 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_kernel(const float* __rest
   }
 }
 
-// forward finalize: mean / invstd, running statistics (momentum; unbiased variance as torch.nn.BatchNorm1d)
-__global__ void bn_finalize_fwd_kernel(const double* __restrict__ partial, int blocks, int64_t N, int C, float eps,
-                                       float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < blocks; ++b) {
+// one 64-thread workgroup per channel sums the per-workgroup partials: strided per-lane sums, then a fixed-order
+// shuffle tree (deterministic); a serial loop over up to 512 partials per channel cost 25 us per layer
+__device__ __forceinline__ void sum_partials(const double* __restrict__ partial, int blocks, int C, int c, double& s,
+                                             double& ss) {
+  s = 0.0;
+  ss = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 64) {
     s += partial[((int64_t)b * 2 + 0) * C + c];
     ss += partial[((int64_t)b * 2 + 1) * C + c];
   }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    ss += __shfl_down(ss, off, 64);
+  }
+}
+
+// forward finalize: mean / invstd, running statistics (momentum; unbiased variance as torch.nn.BatchNorm1d)
+__global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(const double* __restrict__ partial, int blocks, int64_t N,
+                                                             int C, float eps, float momentum, float* __restrict__ mean,
+                                                             float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var) {
+  const int c = blockIdx.x;
+  double s, ss;
+  sum_partials(partial, blocks, C, c, s, ss);
+  if (threadIdx.x != 0) return;
   const double m = s / (double)N;
   double var = ss / (double)N - m * m;
   if (var < 0.0) var = 0.0;
@@ -113,15 +128,12 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __
 }
 
 // backward finalize: dweight = sum g*xhat, dbias = sum g
-__global__ void bn_finalize_bwd_kernel(const double* __restrict__ partial, int blocks, int C, float* __restrict__ dweight,
-                                       float* __restrict__ dbias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < blocks; ++b) {
-    s += partial[((int64_t)b * 2 + 0) * C + c];
-    ss += partial[((int64_t)b * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(const double* __restrict__ partial, int blocks, int C,
+                                                             float* __restrict__ dweight, float* __restrict__ dbias) {
+  const int c = blockIdx.x;
+  double s, ss;
+  sum_partials(partial, blocks, C, c, s, ss);
+  if (threadIdx.x != 0) return;
   dbias[c] = (float)s;
   dweight[c] = (float)ss;
 }
@@ -190,7 +202,7 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
   hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(blocks), dim3(kThreads), 0, stream, x, nullptr, nullptr, nullptr,
                      nullptr, N, C4, 0, partial);
   GPN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)gpn::cdiv(C, 64)), dim3(64), 0, stream, partial, blocks, N, C,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, stream, partial, blocks, N, C,
                      eps, momentum, mean, invstd, running_mean, running_var);
   GPN_CHECK_LAUNCH();
   const int64_t total4 = N * C4;
@@ -229,7 +241,7 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
   hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(blocks), dim3(kThreads), 0, stream, x, y, dy, mean, invstd, N, C4, relu,
                      partial);
   GPN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)gpn::cdiv(C, 64)), dim3(64), 0, stream, partial, blocks, C,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, stream, partial, blocks, C,
                      dweight, dbias);
   GPN_CHECK_LAUNCH();
   const int64_t total4 = N * C4;

@@ -156,13 +156,17 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t elems,
-                                    float* __restrict__ dW) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= elems) return;
+// dW[e] = sum_s partial[s][e]: 16 lanes per element stride over the slices, then a fixed-order shuffle tree
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t elems,
+                                                           float* __restrict__ dW) {
+  const int part = threadIdx.x & 15;
+  const int64_t e = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += partial[(int64_t)s * elems + t];
-  dW[t] = acc;
+  if (e < elems)
+    for (int s = part; s < S; s += 16) acc += partial[(int64_t)s * elems + e];
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 16);
+  if (part == 0 && e < elems) dW[e] = acc;
 }
 
 int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
@@ -295,7 +299,7 @@ extern "C" int gpn_spconv_wgrad(const float* in, const float* dout, const int32_
     }
   }
   if (rc != GPN_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)gpn::cdiv(elems, 256)), dim3(256), 0, stream, partial, S,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gpn::cdiv(elems, 16)), dim3(256), 0, stream, partial, S,
                      elems, dW);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
