@@ -42,9 +42,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int K, int cin_
   const int ci = cb * 16 + 4 * (lane >> 4) + s;
   const int co = nt * 16 + (lane & 15);
   const int kk = (flags & GPN_PACK_REVERSE) ? (K - 1 - k) : k;
+  // element (tap kk, input channel wi, output channel wo) of the stored weight
+  const int wi = (flags & GPN_PACK_TRANSPOSE) ? co : ci;
+  const int wo = (flags & GPN_PACK_TRANSPOSE) ? ci : co;
   float v;
-  if (flags & GPN_PACK_TRANSPOSE) v = W[((int64_t)kk * cin_w + co) * cout_w + ci];
-  else v = W[((int64_t)kk * cin_w + ci) * cout_w + co];
+  if (flags & GPN_LAYOUT_OKI) v = W[((int64_t)wo * K + kk) * cin_w + wi];   // spconv-2.x parameter [Cout][K][Cin]
+  else v = W[((int64_t)kk * cin_w + wi) * cout_w + wo];                     // canonical [K][Cin][Cout]
   packed[t] = v;
 }
 
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
 
 // dW[e] = sum_s partial[s][e]: 16 lanes per element stride over the slices, then a fixed-order shuffle tree
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t elems,
+                                                           int K, int cin, int cout, int oki,
                                                            float* __restrict__ dW) {
   const int part = threadIdx.x & 15;
   const int64_t e = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -166,7 +170,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int s = part; s < S; s += 16) acc += partial[(int64_t)s * elems + e];
 #pragma unroll
   for (int off = 8; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 16);
-  if (part == 0 && e < elems) dW[e] = acc;
+  if (part == 0 && e < elems) {
+    int64_t o = e;  // e = (k * cin + ci) * cout + co
+    if (oki) {
+      const int co = (int)(e % cout);
+      const int64_t r = e / cout;
+      const int ci = (int)(r % cin), k = (int)(r / cin);
+      o = ((int64_t)co * K + k) * cin + ci;  // gradient in the parameter's own [Cout][K][Cin] layout
+    }
+    dW[o] = acc;
+  }
 }
 
 int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
@@ -269,7 +282,7 @@ extern "C" size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_
 
 extern "C" int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
                                 const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
-                                int cout, float* dW, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+                                int cout, int flags, float* dW, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GPN_CHECK_ARG(K >= 1 && n_dst >= 0 && dW);
   GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
@@ -300,7 +313,7 @@ extern "C" int gpn_spconv_wgrad(const float* in, const float* dout, const int32_
   }
   if (rc != GPN_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gpn::cdiv(elems, 16)), dim3(256), 0, stream, partial, S,
-                     elems, dW);
+                     elems, K, cin, cout, (flags & GPN_LAYOUT_OKI) ? 1 : 0, dW);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

@@ -29,29 +29,38 @@ class _SparseConvFn(torch.autograd.Function):
     dgrad (for SubM convs rb_t is rb and the taps are reversed)."""
 
     @staticmethod
-    def forward(ctx, features, weight, rb, rb_t, reverse_taps):
+    def forward(ctx, features, weight, rb, rb_t, reverse_taps, layout):
         ops = backend.raw()
         features = features.contiguous()
         weight = weight.contiguous()
-        out = ops.conv_fwd(features, weight, rb)
-        _log(rb, weight.shape[1], weight.shape[2], "fwd")
+        cin, cout = (weight.shape[2], weight.shape[0]) if layout == "oki" else (weight.shape[1], weight.shape[2])
+        out = ops.conv_fwd(features, weight, rb, layout)
+        _log(rb, cin, cout, "fwd")
         ctx.save_for_backward(features, weight)
-        ctx.rb, ctx.rb_t, ctx.reverse_taps = rb, rb_t, reverse_taps
+        ctx.rb, ctx.rb_t, ctx.reverse_taps, ctx.layout, ctx.dims = rb, rb_t, reverse_taps, layout, (cin, cout)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         ops = backend.raw()
         features, weight = ctx.saved_tensors
+        cin, cout = ctx.dims
         dout = dout.contiguous()
         din = dW = None
         if ctx.needs_input_grad[0]:
-            din = ops.conv_dgrad(dout, weight, ctx.rb, ctx.rb_t, ctx.reverse_taps)
-            _log(ctx.rb_t, weight.shape[2], weight.shape[1], "dgrad")
+            din = ops.conv_dgrad(dout, weight, ctx.rb, ctx.rb_t, ctx.reverse_taps, ctx.layout)
+            _log(ctx.rb_t, cout, cin, "dgrad")
         if ctx.needs_input_grad[1]:
-            dW = ops.conv_wgrad(features, dout, ctx.rb)
-            _log(ctx.rb, weight.shape[1], weight.shape[2], "wgrad")
-        return din, dW, None, None, None
+            dW = ops.conv_wgrad(features, dout, ctx.rb, ctx.layout)
+            _log(ctx.rb, cin, cout, "wgrad")
+        return din, dW, None, None, None, None
+
+
+def sparse_conv_param(features: torch.Tensor, weight_oki: torch.Tensor, rb, rb_t, reverse_taps: bool) -> torch.Tensor:
+    """same op on the conv parameter in its own layout [Cout, K, Cin] (a free view of the spconv-2.x parameter):
+    packing reads it and wgrad writes its gradient directly in that layout, so no permute/copy kernels run.
+    Channel counts must be multiples of 16 (otherwise use sparse_conv on the canonical view)."""
+    return _SparseConvFn.apply(features, weight_oki, rb, rb_t, reverse_taps, "oki")
 
 
 def sparse_conv(features: torch.Tensor, weight: torch.Tensor, rb, rb_t, reverse_taps: bool) -> torch.Tensor:
@@ -65,7 +74,7 @@ def sparse_conv(features: torch.Tensor, weight: torch.Tensor, rb, rb_t, reverse_
         features = F.pad(features, (0, cin_p - cin))
     if cin_p != cin or cout_p != cout:
         weight = F.pad(weight, (0, cout_p - cout, 0, cin_p - cin))
-    out = _SparseConvFn.apply(features, weight, rb, rb_t, reverse_taps)
+    out = _SparseConvFn.apply(features, weight, rb, rb_t, reverse_taps, "kio")
     if cout_p != cout:
         out = out[:, :cout]
     return out

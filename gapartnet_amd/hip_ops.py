@@ -19,7 +19,8 @@ name = "hip"
 
 
 def _stream():
-    return _C.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw current-stream handle (the C call behind torch.cuda.current_stream(), ~20x cheaper than building the wrapper)
+    return _C.ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _dev(*tensors):
@@ -42,8 +43,19 @@ def _c(t, dtype):
     return t.contiguous()
 
 
+_WS_CACHE = {}
+
+
 def _ws(nbytes, device):
-    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+    """scratch workspace for one kernel call.  One grow-only buffer per (device, stream) is reused by every call:
+    kernels on a stream run in order, so a later call can only overwrite scratch an earlier one is done with."""
+    nbytes = max(int(nbytes), 256)
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device()))
+    buf = _WS_CACHE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((max(nbytes * 2, 64 << 20),), dtype=torch.uint8, device=device)
+        _WS_CACHE[key] = buf
+    return buf
 
 
 def n_tiles(n):
@@ -150,11 +162,23 @@ def rulebook_down(indices, spatial_shape, batch_size):
 
 
 # ---------------------------------------------------------------------------------------------------- C
-def pack_weights(W, flags):
+LAYOUT_OKI = 4
+
+
+def _wdims(W, layout):
+    """(K, cin, cout) of a weight given as canonical [K, Cin, Cout] ("kio") or parameter layout [Cout, K, Cin] ("oki")"""
+    if layout == "oki":
+        return W.shape[1], W.shape[2], W.shape[0]
+    return W.shape[0], W.shape[1], W.shape[2]
+
+
+def pack_weights(W, flags, layout="kio"):
     dev = _dev(W)
     W = _c(W, torch.float32)
-    K, cin, cout = W.shape
+    K, cin, cout = _wdims(W, layout)
     packed = torch.empty((K * cin * cout,), dtype=torch.float32, device=dev)
+    if layout == "oki":
+        flags |= LAYOUT_OKI
     check(_C.lib().gpn_spconv_pack_weights(ptr(W), i32(K), i32(cin), i32(cout), i32(flags), ptr(packed), _stream()),
           "gpn_spconv_pack_weights")
     return packed
@@ -173,29 +197,31 @@ def _conv_packed(features, packed, rb: Rulebook, cin, cout):
     return out
 
 
-def conv_fwd(features, W, rb: Rulebook):
-    """out[dst] = sum_k in[src] @ W[k];  W canonical [K, cin, cout] (both multiples of 16)."""
-    K, cin, cout = W.shape
-    return _conv_packed(features, pack_weights(W, 0), rb, cin, cout)
+def conv_fwd(features, W, rb: Rulebook, layout="kio"):
+    """out[dst] = sum_k in[src] @ W[k];  channel counts multiples of 16."""
+    K, cin, cout = _wdims(W, layout)
+    return _conv_packed(features, pack_weights(W, 0, layout), rb, cin, cout)
 
 
-def conv_dgrad(dout, W, rb: Rulebook, rb_t: Rulebook, reverse_taps: bool):
+def conv_dgrad(dout, W, rb: Rulebook, rb_t: Rulebook, reverse_taps: bool, layout="kio"):
     """din[src] = sum_k dout[dst] @ W[k]^T, computed as a forward conv over the transposed rulebook rb_t."""
-    K, cin, cout = W.shape
+    K, cin, cout = _wdims(W, layout)
     flags = PACK_TRANSPOSE | (PACK_REVERSE if reverse_taps else 0)
-    return _conv_packed(dout, pack_weights(W, flags), rb_t, cout, cin)
+    return _conv_packed(dout, pack_weights(W, flags, layout), rb_t, cout, cin)
 
 
-def conv_wgrad(features, dout, rb: Rulebook):
+def conv_wgrad(features, dout, rb: Rulebook, layout="kio"):
+    """weight gradient in the same layout as the weight was given ("kio": [K,Cin,Cout]; "oki": [Cout,K,Cin])"""
     dev = _dev(features, dout)
     features, dout = _c(features, torch.float32), _c(dout, torch.float32)
     cin, cout = features.shape[1], dout.shape[1]
-    dW = torch.empty((rb.K, cin, cout), dtype=torch.float32, device=dev)
+    shape = (cout, rb.K, cin) if layout == "oki" else (rb.K, cin, cout)
+    dW = torch.empty(shape, dtype=torch.float32, device=dev)
     L = _C.lib()
     ws = _ws(L.gpn_spconv_wgrad_ws_bytes(i32(rb.K), i32(cin), i32(cout), i64(rb.n_dst)), dev)
     check(L.gpn_spconv_wgrad(ptr(features), ptr(dout), ptr(rb.pair_src), ptr(rb.pair_dst), ptr(rb.tile_off),
-                             i32(rb.K), i64(rb.n_dst), i32(cin), i32(cout), ptr(dW), ptr(ws), szt(ws.numel()),
-                             _stream()), "gpn_spconv_wgrad")
+                             i32(rb.K), i64(rb.n_dst), i32(cin), i32(cout), i32(LAYOUT_OKI if layout == "oki" else 0),
+                             ptr(dW), ptr(ws), szt(ws.numel()), _stream()), "gpn_spconv_wgrad")
     return dW
 
 
@@ -209,8 +235,8 @@ def bn_fwd(x, res, weight, bias, running_mean, running_var, training, momentum, 
     y = torch.empty_like(x)
     L = _C.lib()
     if training:
-        mean = torch.empty((C,), dtype=torch.float32, device=dev)
-        invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        stats = torch.empty((2, C), dtype=torch.float32, device=dev)
+        mean, invstd = stats[0], stats[1]
         ws = _ws(L.gpn_bn_ws_bytes(i64(N), i32(C)), dev)
         check(L.gpn_bn_fwd_train(ptr(x), ptr(res), ptr(weight), ptr(bias), i64(N), i32(C), f32(eps), f32(momentum),
                                  i32(1 if relu else 0), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
@@ -230,8 +256,8 @@ def bn_bwd(x, y, dy, weight, mean, invstd, relu, training, has_res):
     N, C = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if has_res else None
-    dw = torch.empty((C,), dtype=torch.float32, device=dev)
-    db = torch.empty((C,), dtype=torch.float32, device=dev)
+    dwb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    dw, db = dwb[0], dwb[1]
     L = _C.lib()
     ws = _ws(L.gpn_bn_ws_bytes(i64(N), i32(C)), dev)
     check(L.gpn_bn_bwd(ptr(x), ptr(y), ptr(dy), ptr(weight), ptr(mean), ptr(invstd), i64(N), i32(C), i32(1 if relu else 0),

@@ -164,6 +164,14 @@ class _SparseConvBase(SparseModule):
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         return self.weight.permute(1, 2, 3, 4, 0).reshape(K, self.in_channels, self.out_channels)
 
+    def _conv(self, features, rb, rb_t, reverse_taps):
+        """the fused sparse conv on this module's parameter"""
+        if self.in_channels % 16 == 0 and self.out_channels % 16 == 0:
+            K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+            w = self.weight.view(self.out_channels, K, self.in_channels)  # parameter layout, no copy
+            return GF.sparse_conv_param(features, w, rb, rb_t, reverse_taps)
+        return GF.sparse_conv(features, self.canonical_weight(), rb, rb_t, reverse_taps)
+
     def _finish(self, out):
         return out if self.bias is None else out + self.bias
 
@@ -194,7 +202,7 @@ class SubMConv3d(_SparseConvBase):
             if rb is None:
                 rb = _identity_rulebook(x.features.shape[0], x.features.device)
                 x.indice_dict[ident_key] = rb
-            out = GF.sparse_conv(x.features, self.canonical_weight(), rb, rb, False)
+            out = self._conv(x.features, rb, rb, False)
             return x.replace_feature(self._finish(out))
         assert k == [3, 3, 3] and self.padding == [1, 1, 1] and self.stride == [1, 1, 1], \
             "GAPartNet uses SubMConv3d with kernel 3 / padding 1 or kernel 1 only"
@@ -203,7 +211,7 @@ class SubMConv3d(_SparseConvBase):
             rb = backend.raw().rulebook_subm3(x.indices, x.spatial_shape)
             if self.indice_key is not None:
                 x.indice_dict[self.indice_key] = rb
-        out = GF.sparse_conv(x.features, self.canonical_weight(), rb, rb, True)
+        out = self._conv(x.features, rb, rb, True)
         return x.replace_feature(self._finish(out))
 
 
@@ -219,7 +227,7 @@ class SparseConv3d(_SparseConvBase):
             rec = _DownRecord(x.indices, list(x.spatial_shape), out_idx, out_shape, rb_fwd, rb_bwd)
             if self.indice_key is not None:
                 x.indice_dict[self.indice_key] = rec
-        out = GF.sparse_conv(x.features, self.canonical_weight(), rec.rb_fwd, rec.rb_bwd, False)
+        out = self._conv(x.features, rec.rb_fwd, rec.rb_bwd, False)
         return SparseConvTensor(self._finish(out), rec.out_indices, rec.out_shape, x.batch_size, x.indice_dict)
 
 
@@ -233,5 +241,5 @@ class SparseInverseConv3d(_SparseConvBase):
         rec = x.find_indice_pair(self.indice_key)
         assert isinstance(rec, _DownRecord), f"SparseInverseConv3d: no SparseConv3d registered '{self.indice_key}'"
         assert x.features.shape[0] == rec.out_indices.shape[0]
-        out = GF.sparse_conv(x.features, self.canonical_weight(), rec.rb_bwd, rec.rb_fwd, False)
+        out = self._conv(x.features, rec.rb_bwd, rec.rb_fwd, False)
         return SparseConvTensor(self._finish(out), rec.in_indices, rec.in_shape, x.batch_size, x.indice_dict)

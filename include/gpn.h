@@ -138,6 +138,7 @@ int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, i
  * ================================================================================================ */
 #define GPN_PACK_TRANSPOSE 1
 #define GPN_PACK_REVERSE 2
+#define GPN_LAYOUT_OKI 4 /* weights stored as the spconv-2.x parameter [Cout][K][Cin] instead of canonical [K][Cin][Cout] */
 int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cout_w, int flags, float* packed,
                             gpn_stream_t stream);
 size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout);
@@ -146,7 +147,8 @@ int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* nbr, i
 size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst);
 int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
-                     int cout, float* dW, void* ws, size_t ws_bytes, gpn_stream_t stream);
+                     int cout, int flags /* GPN_LAYOUT_OKI: write dW as [Cout][K][Cin] */, float* dW, void* ws,
+                     size_t ws_bytes, gpn_stream_t stream);
 
 /* BN — BatchNorm1d over a feature matrix [N, C] fused with the residual add and ReLU that follow it in every block of
  * the reference network (network/backbone.py:40-49 relu(bn(conv(x)) [+ shortcut]); norm_fn = BatchNorm1d(eps=1e-4,

@@ -54,16 +54,22 @@ def _lists(rb):
     return _np(rb.pair_src), _np(rb.pair_dst), _np(rb.tile_off)
 
 
-def conv_fwd(features, W, rb):
-    return _t(O.spconv_fwd(_np(features), _np(W), _lists(rb), rb.n_dst))
+def _canon(W, layout):
+    """canonical [K, Cin, Cout] view of a weight given in parameter layout [Cout, K, Cin] ("oki")"""
+    return W.permute(1, 2, 0).contiguous() if layout == "oki" else W
 
 
-def conv_dgrad(dout, W, rb, rb_t, reverse_taps):
-    return _t(O.spconv_dgrad(_np(dout), _np(W), _lists(rb), rb.n_dst, rb.n_src))
+def conv_fwd(features, W, rb, layout="kio"):
+    return _t(O.spconv_fwd(_np(features), _np(_canon(W, layout)), _lists(rb), rb.n_dst))
 
 
-def conv_wgrad(features, dout, rb):
-    return _t(O.spconv_wgrad(_np(features), _np(dout), _lists(rb), rb.n_dst, rb.K))
+def conv_dgrad(dout, W, rb, rb_t, reverse_taps, layout="kio"):
+    return _t(O.spconv_dgrad(_np(dout), _np(_canon(W, layout)), _lists(rb), rb.n_dst, rb.n_src))
+
+
+def conv_wgrad(features, dout, rb, layout="kio"):
+    dW = _t(O.spconv_wgrad(_np(features), _np(dout), _lists(rb), rb.n_dst, rb.K))
+    return dW.permute(2, 0, 1).contiguous() if layout == "oki" else dW
 
 
 def bn_fwd(x, res, weight, bias, running_mean, running_var, training, momentum, eps, relu):

@@ -327,3 +327,19 @@ def test_fused_batchnorm_matches_torch(H, cuda, N, C, relu, with_res, training):
     assert torch.allclose(db, grads_ref[2], atol=1e-3 * max(1.0, float(grads_ref[2].abs().max())), rtol=1e-3)
     if with_res:
         assert torch.allclose(dres, grads_ref[3], atol=1e-6)
+
+
+def test_conv_parameter_layout_matches_canonical(H, cuda):
+    """weights given in the spconv-2.x parameter layout [Cout, K, Cin] (no permute/copy) == canonical [K, Cin, Cout]"""
+    rng = np.random.default_rng(21)
+    shape = [40, 40, 40]
+    idx = synth.surface_indices(rng, 2, shape, 1500)
+    N = idx.shape[0]
+    f = dev(rng.normal(size=(N, 32)).astype(np.float32), cuda)
+    g = dev(rng.normal(size=(N, 48)).astype(np.float32), cuda)
+    W = dev((rng.normal(size=(27, 32, 48)) / 30).astype(np.float32), cuda)
+    Wp = W.permute(2, 0, 1).contiguous()
+    rb = H.rulebook_subm3(dev(idx, cuda), shape)
+    assert torch.equal(H.conv_fwd(f, W, rb), H.conv_fwd(f, Wp, rb, "oki"))
+    assert torch.equal(H.conv_dgrad(g, W, rb, rb, True), H.conv_dgrad(g, Wp, rb, rb, True, "oki"))
+    assert torch.equal(H.conv_wgrad(f, g, rb).permute(2, 0, 1), H.conv_wgrad(f, g, rb, "oki"))
