@@ -15,7 +15,7 @@ _lib = None
 
 _SIZE_T_FUNCS = (
     "gpn_voxelize_ws_bytes", "gpn_rulebook_subm3_ws_bytes", "gpn_rulebook_down_ws_bytes",
-    "gpn_rulebook_down_lists_ws_bytes", "gpn_spconv_fwd_ws_bytes", "gpn_bn_ws_bytes", "gpn_spconv_wgrad_ws_bytes", "gpn_ccl_ws_bytes", "gpn_nms_ws_bytes",
+    "gpn_rulebook_down_lists_ws_bytes", "gpn_spconv_fwd_ws_bytes", "gpn_spconv_fwd_w_ws_bytes", "gpn_bn_ws_bytes", "gpn_spconv_wgrad_ws_bytes", "gpn_ccl_ws_bytes", "gpn_nms_ws_bytes",
 )
 
 
@@ -44,6 +44,16 @@ def lib():
         _lib.gpn_entry_point_name.restype = ctypes.c_char_p
         for name in _SIZE_T_FUNCS:
             getattr(_lib, name).restype = ctypes.c_size_t
+        # prototypes of the per-layer hot calls: with argtypes set, plain Python ints (data_ptr()) and floats are
+        # converted by ctypes itself, which is several times cheaper than building c_void_p / c_int64 objects per call
+        vp, i64t, i32t, f32t, st = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+        _lib.gpn_spconv_fwd_w.argtypes = [vp, vp, i32t, i32t, i32t, i32t, vp, i64t, vp, vp, st, vp]
+        _lib.gpn_spconv_wgrad.argtypes = [vp, vp, vp, vp, vp, i32t, i64t, i32t, i32t, i32t, vp, vp, st, vp]
+        _lib.gpn_bn_fwd_train.argtypes = [vp, vp, vp, vp, i64t, i32t, f32t, f32t, i32t, vp, vp, vp, vp, vp, vp, st, vp]
+        _lib.gpn_bn_fwd_eval.argtypes = [vp, vp, vp, vp, vp, vp, i64t, i32t, i32t, vp, vp]
+        _lib.gpn_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64t, i32t, i32t, i32t, vp, vp, vp, vp, vp, st, vp]
+        _lib.gpn_gather_rows.argtypes = [vp, vp, i64t, i32t, vp, vp]
+        _lib.gpn_scatter_rows_csr.argtypes = [vp, vp, vp, i64t, i32t, vp, vp]
     return _lib
 
 

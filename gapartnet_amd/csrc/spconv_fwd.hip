@@ -296,3 +296,28 @@ extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int3
   }
   return rc;
 }
+
+// One-call form used by the host wrapper: packs the weight (canonical or parameter layout, optional transpose /
+// tap reversal: see gpn_spconv_pack_weights) into the head of the workspace and runs the conv.  Halves the number of
+// host->library calls per layer; the packed copy never needs its own allocation.
+extern "C" size_t gpn_spconv_fwd_w_ws_bytes(int K, int64_t n_dst, int cin, int cout) {
+  return gpn::align_up((size_t)K * cin * cout * sizeof(float)) + gpn_spconv_fwd_ws_bytes(K, n_dst, cin, cout);
+}
+
+extern "C" int gpn_spconv_fwd_w(const float* in, const float* W, int K, int cin_w, int cout_w, int pack_flags,
+                                const int32_t* nbr, int64_t n_dst, float* out, void* ws, size_t ws_bytes,
+                                gpn_stream_t stream) {
+  GPN_CHECK_ARG(W && K >= 1 && cin_w >= 16 && cout_w >= 16);
+  const int cin = (pack_flags & GPN_PACK_TRANSPOSE) ? cout_w : cin_w;
+  const int cout = (pack_flags & GPN_PACK_TRANSPOSE) ? cin_w : cout_w;
+  const size_t packed_bytes = gpn::align_up((size_t)K * cin * cout * sizeof(float));
+  if (!ws || ws_bytes < packed_bytes + gpn_spconv_fwd_ws_bytes(K, n_dst, cin, cout)) {
+    gpn::set_error("gpn_spconv_fwd_w: workspace too small");
+    return GPN_ERR_WS;
+  }
+  float* packed = static_cast<float*>(ws);
+  int rc = gpn_spconv_pack_weights(W, K, cin_w, cout_w, pack_flags, packed, stream);
+  if (rc != GPN_OK) return rc;
+  return gpn_spconv_fwd(in, packed, nbr, K, n_dst, cin, cout, out, static_cast<char*>(ws) + packed_bytes,
+                        ws_bytes - packed_bytes, stream);
+}

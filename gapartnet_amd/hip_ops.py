@@ -197,72 +197,129 @@ def _conv_packed(features, packed, rb: Rulebook, cin, cout):
     return out
 
 
+_FAST_WS = {}
+
+
+def _fast_ws(device, need=0):
+    """(pointer, bytes) of the shared per-(device, stream) scratch buffer, grown on demand (see _ws)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch._C._cuda_getCurrentRawStream(idx)
+    key = (idx, stream)
+    ent = _FAST_WS.get(key)
+    if ent is None or ent[1] < need:
+        size = max(int(need) * 2, 256 << 20)
+        buf = torch.empty((size,), dtype=torch.uint8, device=device)
+        ent = (buf.data_ptr(), size, buf)
+        _FAST_WS[key] = ent
+    return ent[0], ent[1], stream
+
+
+def _raise(what):
+    raise _C.GpnError(f"{what} failed: {_C.lib().gpn_last_error().decode('utf-8', 'replace')}")
+
+
+def _conv_w(features, W, layout, flags, rb: Rulebook, cin_op, cout_op):
+    """pack + fused conv in one library call; features must be contiguous fp32 on the GPU (autograd wrappers ensure it)"""
+    if not features.is_cuda:
+        _dev(features)
+    K, cin_w, cout_w = _wdims(W, layout)
+    assert features.shape[0] == rb.n_src and features.shape[1] == cin_op, (features.shape, rb.n_src, cin_op)
+    L = _C.lib()
+    out = torch.empty((rb.n_dst, cout_op), dtype=torch.float32, device=features.device)
+    if layout == "oki":
+        flags |= LAYOUT_OKI
+    ws_ptr, ws_size, stream = _fast_ws(features.device)
+    rc = L.gpn_spconv_fwd_w(features.data_ptr(), W.data_ptr(), K, cin_w, cout_w, flags, rb.nbr.data_ptr(), rb.n_dst,
+                            out.data_ptr(), ws_ptr, ws_size, stream)
+    if rc == 2:  # workspace too small: grow once and retry
+        ws_ptr, ws_size, stream = _fast_ws(features.device, L.gpn_spconv_fwd_w_ws_bytes(K, rb.n_dst, cin_op, cout_op))
+        rc = L.gpn_spconv_fwd_w(features.data_ptr(), W.data_ptr(), K, cin_w, cout_w, flags, rb.nbr.data_ptr(), rb.n_dst,
+                                out.data_ptr(), ws_ptr, ws_size, stream)
+    if rc:
+        _raise("gpn_spconv_fwd_w")
+    return out
+
+
 def conv_fwd(features, W, rb: Rulebook, layout="kio"):
     """out[dst] = sum_k in[src] @ W[k];  channel counts multiples of 16."""
     K, cin, cout = _wdims(W, layout)
-    return _conv_packed(features, pack_weights(W, 0, layout), rb, cin, cout)
+    return _conv_w(features, W, layout, 0, rb, cin, cout)
 
 
 def conv_dgrad(dout, W, rb: Rulebook, rb_t: Rulebook, reverse_taps: bool, layout="kio"):
     """din[src] = sum_k dout[dst] @ W[k]^T, computed as a forward conv over the transposed rulebook rb_t."""
     K, cin, cout = _wdims(W, layout)
-    flags = PACK_TRANSPOSE | (PACK_REVERSE if reverse_taps else 0)
-    return _conv_packed(dout, pack_weights(W, flags, layout), rb_t, cout, cin)
+    return _conv_w(dout, W, layout, PACK_TRANSPOSE | (PACK_REVERSE if reverse_taps else 0), rb_t, cout, cin)
 
 
 def conv_wgrad(features, dout, rb: Rulebook, layout="kio"):
     """weight gradient in the same layout as the weight was given ("kio": [K,Cin,Cout]; "oki": [Cout,K,Cin])"""
-    dev = _dev(features, dout)
-    features, dout = _c(features, torch.float32), _c(dout, torch.float32)
+    if not (features.is_cuda and dout.is_cuda):
+        _dev(features, dout)
     cin, cout = features.shape[1], dout.shape[1]
     shape = (cout, rb.K, cin) if layout == "oki" else (rb.K, cin, cout)
-    dW = torch.empty(shape, dtype=torch.float32, device=dev)
+    dW = torch.empty(shape, dtype=torch.float32, device=features.device)
     L = _C.lib()
-    ws = _ws(L.gpn_spconv_wgrad_ws_bytes(i32(rb.K), i32(cin), i32(cout), i64(rb.n_dst)), dev)
-    check(L.gpn_spconv_wgrad(ptr(features), ptr(dout), ptr(rb.pair_src), ptr(rb.pair_dst), ptr(rb.tile_off),
-                             i32(rb.K), i64(rb.n_dst), i32(cin), i32(cout), i32(LAYOUT_OKI if layout == "oki" else 0),
-                             ptr(dW), ptr(ws), szt(ws.numel()), _stream()), "gpn_spconv_wgrad")
+    ws_ptr, ws_size, stream = _fast_ws(features.device, 0)
+    args = (features.data_ptr(), dout.data_ptr(), rb.pair_src.data_ptr(), rb.pair_dst.data_ptr(), rb.tile_off.data_ptr(),
+            rb.K, rb.n_dst, cin, cout, LAYOUT_OKI if layout == "oki" else 0, dW.data_ptr())
+    rc = L.gpn_spconv_wgrad(*args, ws_ptr, ws_size, stream)
+    if rc == 2:
+        ws_ptr, ws_size, stream = _fast_ws(features.device, L.gpn_spconv_wgrad_ws_bytes(i32(rb.K), i32(cin), i32(cout), i64(rb.n_dst)))
+        rc = L.gpn_spconv_wgrad(*args, ws_ptr, ws_size, stream)
+    if rc:
+        _raise("gpn_spconv_wgrad")
     return dW
 
 
 # ---------------------------------------------------------------------------------------------------- BN
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
 def bn_fwd(x, res, weight, bias, running_mean, running_var, training, momentum, eps, relu):
-    """fused BatchNorm1d(+residual)(+ReLU) forward -> (y, mean, invstd); running stats updated in place when training."""
-    dev = _dev(x, res, weight, bias)
-    x = _c(x, torch.float32)
-    res = _c(res, torch.float32)
+    """fused BatchNorm1d(+residual)(+ReLU) forward -> (y, mean, invstd); running stats updated in place when training.
+    x / res must be contiguous fp32 (the autograd wrapper ensures it)."""
+    if not x.is_cuda:
+        _dev(x)
     N, C = x.shape
     y = torch.empty_like(x)
     L = _C.lib()
     if training:
-        stats = torch.empty((2, C), dtype=torch.float32, device=dev)
+        stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
         mean, invstd = stats[0], stats[1]
-        ws = _ws(L.gpn_bn_ws_bytes(i64(N), i32(C)), dev)
-        check(L.gpn_bn_fwd_train(ptr(x), ptr(res), ptr(weight), ptr(bias), i64(N), i32(C), f32(eps), f32(momentum),
-                                 i32(1 if relu else 0), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
-                                 ptr(running_var), ptr(ws), szt(ws.numel()), _stream()), "gpn_bn_fwd_train")
+        ws_ptr, ws_size, stream = _fast_ws(x.device, 0)
+        rc = L.gpn_bn_fwd_train(x.data_ptr(), _p(res), weight.data_ptr(), bias.data_ptr(), N, C, eps, momentum,
+                                1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _p(running_mean),
+                                _p(running_var), ws_ptr, ws_size, stream)
+        if rc:
+            _raise("gpn_bn_fwd_train")
     else:
         mean = running_mean
         invstd = torch.rsqrt(running_var + eps)
-        check(L.gpn_bn_fwd_eval(ptr(x), ptr(res), ptr(weight), ptr(bias), ptr(mean), ptr(invstd), i64(N), i32(C),
-                                i32(1 if relu else 0), ptr(y), _stream()), "gpn_bn_fwd_eval")
+        rc = L.gpn_bn_fwd_eval(x.data_ptr(), _p(res), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(),
+                               invstd.data_ptr(), N, C, 1 if relu else 0, y.data_ptr(),
+                               torch._C._cuda_getCurrentRawStream(x.device.index))
+        if rc:
+            _raise("gpn_bn_fwd_eval")
     return y, mean, invstd
 
 
 def bn_bwd(x, y, dy, weight, mean, invstd, relu, training, has_res):
     """-> (dx, dres or None, dweight, dbias)"""
-    dev = _dev(x, dy)
-    x, dy = _c(x, torch.float32), _c(dy, torch.float32)
+    if not x.is_cuda:
+        _dev(x)
     N, C = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if has_res else None
-    dwb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    dwb = torch.empty((2, C), dtype=torch.float32, device=x.device)
     dw, db = dwb[0], dwb[1]
-    L = _C.lib()
-    ws = _ws(L.gpn_bn_ws_bytes(i64(N), i32(C)), dev)
-    check(L.gpn_bn_bwd(ptr(x), ptr(y), ptr(dy), ptr(weight), ptr(mean), ptr(invstd), i64(N), i32(C), i32(1 if relu else 0),
-                       i32(1 if training else 0), ptr(dx), ptr(dres), ptr(dw), ptr(db), ptr(ws), szt(ws.numel()),
-                       _stream()), "gpn_bn_bwd")
+    ws_ptr, ws_size, stream = _fast_ws(x.device, 0)
+    rc = _C.lib().gpn_bn_bwd(x.data_ptr(), y.data_ptr(), dy.data_ptr(), weight.data_ptr(), mean.data_ptr(),
+                             invstd.data_ptr(), N, C, 1 if relu else 0, 1 if training else 0, dx.data_ptr(), _p(dres),
+                             dw.data_ptr(), db.data_ptr(), ws_ptr, ws_size, stream)
+    if rc:
+        _raise("gpn_bn_bwd")
     return dx, dres, dw, db
 
 

@@ -144,6 +144,10 @@ int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cout_w, int fl
 size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout);
 int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* nbr, int K, int64_t n_dst, int cin,
                    int cout, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream);
+/* pack + conv in one call (packed copy lives in the head of ws); cin_w/cout_w are the STORED weight's dims */
+size_t gpn_spconv_fwd_w_ws_bytes(int K, int64_t n_dst, int cin, int cout);
+int gpn_spconv_fwd_w(const float* in, const float* W, int K, int cin_w, int cout_w, int pack_flags, const int32_t* nbr,
+                     int64_t n_dst, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream);
 size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst);
 int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
