@@ -1,0 +1,328 @@
+// net.hip — kernel family U: layer-program executor for the sparse residual U-Net (include/gpn.h section U).
+//
+// Reference behaviour: network/backbone.py:40-49 (ResBlock.forward), :126-141 (UBlock.forward), :150-155
+// (SparseUNet.forward) — a Python walk over ~200 spconv / BatchNorm1d modules per forward, and autograd's walk back.
+// Here the host describes that walk once as a flat list of CONV / BN / CONCAT ops over numbered activation slots and
+// this file issues every launch of the forward (or of the backward, in reverse program order) from one native loop.
+// The arithmetic is exactly that of the per-layer entry points (gpn_spconv_fwd_w, gpn_spconv_wgrad, gpn_bn_*), which
+// this file calls; the only kernels of its own are the column concat / split and the gradient accumulation.
+#include <algorithm>
+
+#include "gpn_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// dst[r, 0:ca] = a[r, :], dst[r, ca:ca+cb] = b[r, :]   (float4 granularity; channel counts are multiples of 4)
+__global__ __launch_bounds__(kThreads) void concat_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                          int64_t rows, int ca4, int cb4, float4* __restrict__ dst) {
+  const int c4 = ca4 + cb4;
+  const int64_t total = rows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t r = i / c4;
+    const int c = (int)(i - r * c4);
+    dst[i] = c < ca4 ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
+  }
+}
+
+// the transpose: da (+)= dsrc[:, 0:ca], db (+)= dsrc[:, ca:]; acc_a / acc_b select overwrite (0) or accumulate (1)
+__global__ __launch_bounds__(kThreads) void split_kernel(const float4* __restrict__ dsrc, int64_t rows, int ca4, int cb4,
+                                                         float4* __restrict__ da, int acc_a, float4* __restrict__ db,
+                                                         int acc_b) {
+  const int c4 = ca4 + cb4;
+  const int64_t total = rows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t r = i / c4;
+    const int c = (int)(i - r * c4);
+    const float4 g = dsrc[i];
+    float4* p = c < ca4 ? da + (r * ca4 + c) : db + (r * cb4 + (c - ca4));
+    if (c < ca4 ? acc_a : acc_b) {
+      float4 o = *p;
+      o.x += g.x, o.y += g.y, o.z += g.z, o.w += g.w;
+      *p = o;
+    } else {
+      *p = g;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void accumulate_kernel(float4* __restrict__ dst, const float4* __restrict__ src,
+                                                              int64_t total4) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kThreads) {
+    float4 o = dst[i];
+    const float4 g = src[i];
+    o.x += g.x, o.y += g.y, o.z += g.z, o.w += g.w;
+    dst[i] = o;
+  }
+}
+
+__global__ void invstd_kernel(const float* __restrict__ var, float eps, int C, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
+}
+
+inline int grid_for(int64_t total) {
+  int64_t g = gpn::cdiv(total, kThreads);
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+inline size_t slot_bytes(const gpn_net_slot_t& s) { return (size_t)s.rows * s.channels * sizeof(float); }
+
+struct Need {
+  size_t tmp = 0;  // gradient staging buffer (largest slot that can receive a second gradient)
+  size_t op = 0;   // largest per-op workspace
+};
+
+Need workspace_need(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, const gpn_net_rulebook_t* rbs,
+                    const gpn_net_conv_t* convs) {
+  Need n;
+  for (int i = 0; i < n_ops; ++i) {
+    const gpn_net_op_t& op = ops[i];
+    const gpn_net_slot_t& s0 = slots[op.src0];
+    if (op.kind == GPN_NET_CONV) {
+      const gpn_net_rulebook_t& rb = rbs[op.rulebook];
+      const gpn_net_conv_t& cv = convs[op.param];
+      size_t w = gpn_spconv_fwd_w_ws_bytes(rb.K, rb.n_dst, cv.cin, cv.cout);
+      size_t wt = gpn_spconv_fwd_w_ws_bytes(rb.K, rb.n_src, cv.cout, cv.cin);
+      size_t wg = gpn_spconv_wgrad_ws_bytes(rb.K, cv.cin, cv.cout, rb.n_dst);
+      n.op = std::max(n.op, std::max(w, std::max(wt, wg)));
+      n.tmp = std::max(n.tmp, slot_bytes(s0));
+    } else if (op.kind == GPN_NET_BN) {
+      n.op = std::max(n.op, gpn_bn_ws_bytes(s0.rows, s0.channels));
+      if (op.src1 >= 0) n.tmp = std::max(n.tmp, slot_bytes(slots[op.src1]));
+    }
+  }
+  n.tmp = gpn::align_up(n.tmp);
+  n.op = gpn::align_up(n.op);
+  return n;
+}
+
+int check_program(const char* who, const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, int n_slots,
+                  const gpn_net_rulebook_t* rbs, int n_rbs, const gpn_net_conv_t* convs, int n_convs,
+                  const gpn_net_bn_t* bns, int n_bns) {
+  if (!ops || !slots || n_ops < 0 || n_slots < 1 || (n_rbs && !rbs) || (n_convs && !convs) || (n_bns && !bns)) {
+    gpn::set_error("%s: null table", who);
+    return GPN_ERR_ARG;
+  }
+  for (int i = 0; i < n_ops; ++i) {
+    const gpn_net_op_t& op = ops[i];
+    auto bad = [&](const char* what) {
+      gpn::set_error("%s: op %d (kind %d): %s", who, i, op.kind, what);
+      return GPN_ERR_ARG;
+    };
+    if (op.src0 < 0 || op.src0 >= n_slots || op.dst < 0 || op.dst >= n_slots || op.src1 >= n_slots) return bad("slot index out of range");
+    const gpn_net_slot_t &s0 = slots[op.src0], &d = slots[op.dst];
+    if (s0.rows < 1 || d.rows < 1) return bad("empty slot");
+    if (op.kind == GPN_NET_CONV) {
+      if (op.rulebook < 0 || op.rulebook >= n_rbs || op.param < 0 || op.param >= n_convs) return bad("table index out of range");
+      const gpn_net_rulebook_t& rb = rbs[op.rulebook];
+      const gpn_net_conv_t& cv = convs[op.param];
+      if (rb.n_src != s0.rows || rb.n_dst != d.rows || cv.cin != s0.channels || cv.cout != d.channels)
+        return bad("slot shape does not match rulebook / weight");
+      if (!rb.nbr || !cv.W) return bad("null rulebook / weight pointer");
+    } else if (op.kind == GPN_NET_BN) {
+      if (op.param < 0 || op.param >= n_bns) return bad("table index out of range");
+      if (bns[op.param].C != s0.channels || d.channels != s0.channels || d.rows != s0.rows) return bad("slot shape does not match BatchNorm");
+      if (op.src1 >= 0 && (slots[op.src1].rows != s0.rows || slots[op.src1].channels != s0.channels)) return bad("residual shape");
+    } else if (op.kind == GPN_NET_CONCAT) {
+      if (op.src1 < 0) return bad("concat needs two inputs");
+      const gpn_net_slot_t& s1 = slots[op.src1];
+      if (s1.rows != s0.rows || d.rows != s0.rows || d.channels != s0.channels + s1.channels || s0.channels % 4 || s1.channels % 4)
+        return bad("concat shapes");
+    } else {
+      return bad("unknown op kind");
+    }
+  }
+  return GPN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gpn_net_ws_bytes(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, int n_slots,
+                                   const gpn_net_rulebook_t* rulebooks, const gpn_net_conv_t* convs) {
+  (void)n_slots;
+  if (!ops || !slots) return 0;
+  const Need n = workspace_need(ops, n_ops, slots, rulebooks, convs);
+  return n.tmp + n.op;
+}
+
+extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
+                               const gpn_net_rulebook_t* rbs, int n_rbs, const gpn_net_conv_t* convs, int n_convs,
+                               const gpn_net_bn_t* bns, int n_bns, int training, void* ws, size_t ws_bytes,
+                               gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_program(__func__, ops, n_ops, slots, n_slots, rbs, n_rbs, convs, n_convs, bns, n_bns);
+  if (rc) return rc;
+  const Need need = workspace_need(ops, n_ops, slots, rbs, convs);
+  if (!ws || ws_bytes < need.op) {
+    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, need.op, ws_bytes);
+    return GPN_ERR_WS;
+  }
+  for (int i = 0; i < n_ops; ++i) {
+    const gpn_net_op_t& op = ops[i];
+    const gpn_net_slot_t &s0 = slots[op.src0], &d = slots[op.dst];
+    if (!s0.data || !d.data) {
+      gpn::set_error("%s: op %d: null activation pointer", __func__, i);
+      return GPN_ERR_ARG;
+    }
+    if (op.kind == GPN_NET_CONV) {
+      const gpn_net_rulebook_t& rb = rbs[op.rulebook];
+      const gpn_net_conv_t& cv = convs[op.param];
+      rc = gpn_spconv_fwd_w(s0.data, cv.W, rb.K, cv.cin, cv.cout, GPN_LAYOUT_OKI, rb.nbr, rb.n_dst, d.data, ws, ws_bytes,
+                            stream_);
+    } else if (op.kind == GPN_NET_BN) {
+      const gpn_net_bn_t& bn = bns[op.param];
+      const float* res = op.src1 >= 0 ? slots[op.src1].data : nullptr;
+      const int relu = (op.flags & GPN_NET_RELU) ? 1 : 0;
+      if (training) {
+        rc = gpn_bn_fwd_train(s0.data, res, bn.weight, bn.bias, s0.rows, bn.C, bn.eps, bn.momentum, relu, d.data,
+                              bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, ws, ws_bytes, stream_);
+      } else {
+        if (!bn.running_mean || !bn.running_var || !bn.save_invstd) {
+          gpn::set_error("%s: op %d: eval-mode BatchNorm needs running statistics", __func__, i);
+          return GPN_ERR_ARG;
+        }
+        hipLaunchKernelGGL(invstd_kernel, dim3((bn.C + 63) / 64), dim3(64), 0, stream, bn.running_var, bn.eps, bn.C,
+                           bn.save_invstd);
+        GPN_CHECK_LAUNCH();
+        rc = gpn_bn_fwd_eval(s0.data, res, bn.weight, bn.bias, bn.running_mean, bn.save_invstd, s0.rows, bn.C, relu,
+                             d.data, stream_);
+      }
+    } else {
+      const gpn_net_slot_t& s1 = slots[op.src1];
+      hipLaunchKernelGGL(concat_kernel, dim3(grid_for(d.rows * (d.channels / 4))), dim3(kThreads), 0, stream,
+                         (const float4*)s0.data, (const float4*)s1.data, d.rows, s0.channels / 4, s1.channels / 4,
+                         (float4*)d.data);
+      GPN_CHECK_LAUNCH();
+      rc = GPN_OK;
+    }
+    if (rc) return rc;
+  }
+  return GPN_OK;
+}
+
+namespace {
+
+// hand a gradient buffer to a producer: the slot's own buffer if nothing was written there yet, else the staging buffer
+struct GradTarget {
+  float* ptr;
+  bool staged;
+};
+
+inline GradTarget grad_target(gpn_net_slot_t& s, float* tmp) {
+  return s.grad_state ? GradTarget{tmp, true} : GradTarget{s.grad, false};
+}
+
+int commit(gpn_net_slot_t& s, const GradTarget& t, hipStream_t stream) {
+  if (t.staged) {
+    const int64_t total4 = s.rows * s.channels / 4;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid_for(total4)), dim3(kThreads), 0, stream, (float4*)s.grad,
+                       (const float4*)t.ptr, total4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      gpn::set_error("gpn_net_backward: accumulate launch failed: %s", hipGetErrorString(e));
+      return GPN_ERR_HIP;
+    }
+  }
+  s.grad_state = 1;
+  return GPN_OK;
+}
+
+}  // namespace
+
+extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
+                                const gpn_net_rulebook_t* rbs, int n_rbs, const gpn_net_conv_t* convs, int n_convs,
+                                const gpn_net_bn_t* bns, int n_bns, int training, int need_input_grad, void* ws,
+                                size_t ws_bytes, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_program(__func__, ops, n_ops, slots, n_slots, rbs, n_rbs, convs, n_convs, bns, n_bns);
+  if (rc) return rc;
+  const Need need = workspace_need(ops, n_ops, slots, rbs, convs);
+  if (!ws || ws_bytes < need.tmp + need.op) {
+    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, need.tmp + need.op, ws_bytes);
+    return GPN_ERR_WS;
+  }
+  float* tmp = static_cast<float*>(ws);
+  void* op_ws = static_cast<char*>(ws) + need.tmp;
+  const size_t op_ws_bytes = ws_bytes - need.tmp;
+  for (int i = n_ops - 1; i >= 0; --i) {
+    const gpn_net_op_t& op = ops[i];
+    gpn_net_slot_t &s0 = slots[op.src0], &d = slots[op.dst];
+    if (!d.grad_state) continue;  // nothing flows back through this op (its output does not reach the loss)
+    if (!d.grad || !s0.data || !d.data) {
+      gpn::set_error("%s: op %d: null pointer", __func__, i);
+      return GPN_ERR_ARG;
+    }
+    if (op.kind == GPN_NET_CONV) {
+      const gpn_net_rulebook_t& rb = rbs[op.rulebook];
+      const gpn_net_conv_t& cv = convs[op.param];
+      if (cv.dW) {
+        if (!rb.pair_src || !rb.pair_dst || !rb.tile_off) {
+          gpn::set_error("%s: op %d: rulebook has no pair lists for wgrad", __func__, i);
+          return GPN_ERR_ARG;
+        }
+        rc = gpn_spconv_wgrad(s0.data, d.grad, rb.pair_src, rb.pair_dst, rb.tile_off, rb.K, rb.n_dst, cv.cin, cv.cout,
+                              GPN_LAYOUT_OKI, cv.dW, op_ws, op_ws_bytes, stream_);
+        if (rc) return rc;
+      }
+      if (op.src0 != 0 || need_input_grad) {
+        if (!s0.grad || !rb.nbr_t) {
+          gpn::set_error("%s: op %d: null gradient buffer / transposed table", __func__, i);
+          return GPN_ERR_ARG;
+        }
+        GradTarget t = grad_target(s0, tmp);
+        rc = gpn_spconv_fwd_w(d.grad, cv.W, rb.K, cv.cin, cv.cout,
+                              GPN_LAYOUT_OKI | GPN_PACK_TRANSPOSE | (rb.reverse_taps ? GPN_PACK_REVERSE : 0), rb.nbr_t,
+                              rb.n_src, t.ptr, op_ws, op_ws_bytes, stream_);
+        if (rc) return rc;
+        rc = commit(s0, t, stream);
+        if (rc) return rc;
+      }
+    } else if (op.kind == GPN_NET_BN) {
+      const gpn_net_bn_t& bn = bns[op.param];
+      if (!s0.grad || !bn.dweight || !bn.dbias) {
+        gpn::set_error("%s: op %d: null gradient buffer", __func__, i);
+        return GPN_ERR_ARG;
+      }
+      const float* mean = training ? bn.save_mean : bn.running_mean;
+      GradTarget tx = grad_target(s0, tmp);
+      if (tx.staged) {
+        gpn::set_error("%s: op %d: BatchNorm input consumed twice is not supported", __func__, i);
+        return GPN_ERR_ARG;
+      }
+      float* dres = nullptr;
+      GradTarget tr{nullptr, false};
+      if (op.src1 >= 0 && (op.src1 != 0 || need_input_grad)) {
+        if (!slots[op.src1].grad) {
+          gpn::set_error("%s: op %d: null residual gradient buffer", __func__, i);
+          return GPN_ERR_ARG;
+        }
+        tr = grad_target(slots[op.src1], tmp);
+        dres = tr.ptr;
+      }
+      rc = gpn_bn_bwd(s0.data, d.data, d.grad, bn.weight, mean, bn.save_invstd, s0.rows, bn.C,
+                      (op.flags & GPN_NET_RELU) ? 1 : 0, training ? 1 : 0, tx.ptr, dres, bn.dweight, bn.dbias, op_ws,
+                      op_ws_bytes, stream_);
+      if (rc) return rc;
+      s0.grad_state = 1;
+      if (dres) {
+        rc = commit(slots[op.src1], tr, stream);
+        if (rc) return rc;
+      }
+    } else {
+      gpn_net_slot_t& s1 = slots[op.src1];
+      if (!s0.grad || !s1.grad) {
+        gpn::set_error("%s: op %d: null gradient buffer", __func__, i);
+        return GPN_ERR_ARG;
+      }
+      hipLaunchKernelGGL(split_kernel, dim3(grid_for(d.rows * (d.channels / 4))), dim3(kThreads), 0, stream,
+                         (const float4*)d.grad, d.rows, s0.channels / 4, s1.channels / 4, (float4*)s0.grad,
+                         s0.grad_state, (float4*)s1.grad, s1.grad_state);
+      GPN_CHECK_LAUNCH();
+      s0.grad_state = 1;
+      s1.grad_state = 1;
+    }
+  }
+  return GPN_OK;
+}

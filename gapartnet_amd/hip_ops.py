@@ -296,7 +296,7 @@ def bn_fwd(x, res, weight, bias, running_mean, running_var, training, momentum, 
             _raise("gpn_bn_fwd_train")
     else:
         mean = running_mean
-        invstd = torch.rsqrt(running_var + eps)
+        invstd = 1.0 / torch.sqrt(running_var + eps)
         rc = L.gpn_bn_fwd_eval(x.data_ptr(), _p(res), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(),
                                invstd.data_ptr(), N, C, 1 if relu else 0, y.data_ptr(),
                                torch._C._cuda_getCurrentRawStream(x.device.index))

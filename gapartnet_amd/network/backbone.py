@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import backend
 from .. import functional as GF
 from ..spconv import pytorch as spconv
 
@@ -87,12 +88,21 @@ class UBlock(nn.Module):
 
 
 class SparseUNet(nn.Module):
+    # run forward / backward of the whole network through the native layer-program executor (network/net_exec.py,
+    # csrc/net.hip) instead of module by module; same kernels, same results, one library call per direction
+    use_native_executor = True
+
     def __init__(self, stem: Optional[nn.Module], ublock: UBlock):
         super().__init__()
         self.stem = stem
         self.ublock = ublock
 
     def forward(self, x: spconv.SparseConvTensor) -> spconv.SparseConvTensor:
+        if self.use_native_executor and backend.raw().name == "hip":
+            from . import net_exec
+            out = net_exec.run(self, x)
+            if out is not None:
+                return out
         if self.stem is not None:
             x = self.stem(x)
         return self.ublock(x)

@@ -153,10 +153,14 @@ class GAPartNet(LightningModule):
         """L1 distance + negative cosine between predicted and true point->instance-centre offsets, on points of
         labelled part instances (model.py:204-226)."""
         on_part = (sem_labels > 0) & (instance_labels >= 0)
-        loss_dist = (offsets - gt_offsets).abs().sum(dim=-1)[on_part].mean()
+        # masked means written as sum / count: the reference's boolean-mask selection (x[on_part].mean()) costs a
+        # device->host round trip per selection; the value is the same (NaN for an empty selection, as .mean() gives)
+        count = on_part.sum()
+        zero = offsets.new_zeros(())
+        loss_dist = torch.where(on_part, (offsets - gt_offsets).abs().sum(dim=-1), zero).sum() / count
         gt_dir = gt_offsets / (torch.norm(gt_offsets, p=2, dim=-1)[:, None] + 1e-8)
         pred_dir = offsets / (torch.norm(offsets, p=2, dim=-1)[:, None] + 1e-8)
-        loss_dir = (-(gt_dir * pred_dir).sum(-1))[on_part].mean()
+        loss_dir = torch.where(on_part, -(gt_dir * pred_dir).sum(-1), zero).sum() / count
         return loss_dist, loss_dir
 
     def proposal_clustering_and_revoxelize(self, pt_xyz: torch.Tensor, batch_indices: torch.Tensor,
@@ -169,10 +173,12 @@ class GAPartNet(LightningModule):
         if instance_labels is not None:
             valid_mask = valid_mask & (instance_labels >= 0)
 
-        pt_xyz, batch_indices, pt_features = pt_xyz[valid_mask], batch_indices[valid_mask], pt_features[valid_mask]
-        sem_preds, offset_preds = sem_preds[valid_mask].int(), offset_preds[valid_mask]
+        # one compaction index for every per-point array (each boolean-mask selection would be its own host sync)
+        valid_indices = torch.nonzero(valid_mask).squeeze(1)
+        pt_xyz, batch_indices, pt_features = pt_xyz[valid_indices], batch_indices[valid_indices], pt_features[valid_indices]
+        sem_preds, offset_preds = sem_preds[valid_indices].int(), offset_preds[valid_indices]
         if instance_labels is not None:
-            instance_labels = instance_labels[valid_mask]
+            instance_labels = instance_labels[valid_indices]
 
         # CSR over the scenes that still have points
         _, scene_compact, scene_counts = torch.unique_consecutive(batch_indices, return_inverse=True, return_counts=True)
@@ -188,7 +194,7 @@ class GAPartNet(LightningModule):
         sorted_indices = torch.cat([order_a, order_b], dim=0)
 
         _, proposal_indices, sizes = torch.unique_consecutive(labels, return_inverse=True, return_counts=True)
-        keep_point = (sizes >= self.min_num_points_per_proposal)[proposal_indices]
+        keep_point = torch.nonzero((sizes >= self.min_num_points_per_proposal)[proposal_indices]).squeeze(1)
         sorted_indices = sorted_indices[keep_point]
         if sorted_indices.shape[0] == 0:
             return None, None, None
@@ -212,7 +218,7 @@ class GAPartNet(LightningModule):
             raise RuntimeError("re-voxelisation dropped points: a proposal left its score_fullscale^3 grid "
                                "(the reference stops in pdb here, model.py:328-330)")
 
-        proposals = Instances(valid_mask=valid_mask, sorted_indices=sorted_indices, pt_xyz=pt_xyz,
+        proposals = Instances(valid_mask=valid_mask, valid_indices=valid_indices, sorted_indices=sorted_indices, pt_xyz=pt_xyz,
                               batch_indices=batch_indices, proposal_offsets=proposal_offsets,
                               proposal_indices=proposal_indices, num_points_per_proposal=sizes, sem_preds=sem_preds,
                               instance_labels=instance_labels)
@@ -245,9 +251,10 @@ class GAPartNet(LightningModule):
         sem_preds, sem_labels = proposals.sem_preds, proposals.sem_labels
         valid = (sem_preds == sem_labels) & (gt_npcs != 0).any(dim=-1)
 
-        npcs_logits, gt_npcs = npcs_logits[valid], gt_npcs[valid]
-        sem_preds = sem_preds[valid].long()
-        proposal_indices = proposals.proposal_indices[valid]
+        valid_idx = torch.nonzero(valid).squeeze(1)
+        npcs_logits, gt_npcs = npcs_logits[valid_idx], gt_npcs[valid_idx]
+        sem_preds = sem_preds[valid_idx].long()
+        proposal_indices = proposals.proposal_indices[valid_idx]
 
         per_class = npcs_logits.reshape(npcs_logits.shape[0], npcs_logits.shape[1] // 3, 3)  # valid for 0 rows too
         npcs_preds = per_class.gather(1, (sem_preds - 1)[:, None, None].expand(-1, 1, 3)).squeeze(1)
@@ -264,13 +271,20 @@ class GAPartNet(LightningModule):
         sym = self.symmetry_indices[sem_preds]
 
         loss = 0
-        # (mask of the group, table of its matrices, index offset inside the table)
-        for mask, table, base in ((sym < 3, self.symmetry_matrix_1, 0), (sym == 3, self.symmetry_matrix_2, 3),
-                                  (sym == 4, self.symmetry_matrix_3, 4)):
-            members = sym[mask]
-            if members.shape[0] > 0:
-                loss = loss + compute_npcs_loss(npcs_preds[mask], gt_npcs[mask], proposal_indices[mask],
-                                                table[members - base])
+        # the three symmetry groups (sym < 3, == 3, == 4), each with its own table of candidate rotations: points are
+        # bucketed with one stable sort and ONE host read of the three bucket sizes (the reference selects each group
+        # with four boolean masks = twelve host syncs); inside a bucket the points keep their order
+        group = (sym >= 3).long() + (sym >= 4).long()
+        order = torch.sort(group, stable=True)[1]
+        n0, n1, n2 = torch.bincount(group, minlength=3)[:3].tolist()
+        start = 0
+        for size, table, base in ((n0, self.symmetry_matrix_1, 0), (n1, self.symmetry_matrix_2, 3),
+                                  (n2, self.symmetry_matrix_3, 4)):
+            if size > 0:
+                members = order[start:start + size]
+                loss = loss + compute_npcs_loss(npcs_preds[members], gt_npcs[members], proposal_indices[members],
+                                                table[sym[members] - base])
+            start += size
         return loss
 
     # ------------------------------------------------------------------------------------------ one step
@@ -298,8 +312,8 @@ class GAPartNet(LightningModule):
         loss_sem_seg = self.loss_sem_seg(sem_logits, sem_labels) if sem_labels is not None else 0.0
         all_accu = (sem_preds == sem_labels).sum().float() / sem_labels.shape[0]
         if sem_labels is not None:
-            on_part = sem_labels > 0
-            pixel_accu = pixel_accuracy(sem_preds[on_part], sem_labels[on_part])
+            on_part = sem_labels > 0  # pixel_accuracy(sem_preds[on_part], sem_labels[on_part]) without the host syncs
+            pixel_accu = ((sem_preds == sem_labels) & on_part).sum() / on_part.sum()
         else:
             pixel_accu = 0.0
         sem_seg = Segmentation(batch_size=batch_size, sem_preds=sem_preds, sem_labels=sem_labels, all_accu=all_accu,
@@ -320,7 +334,7 @@ class GAPartNet(LightningModule):
                 offset_preds=offsets_preds, instance_labels=instance_labels)
             if proposals is not None:
                 if sem_labels is not None:
-                    proposals.sem_labels = sem_labels[proposals.valid_mask][proposals.sorted_indices]
+                    proposals.sem_labels = sem_labels[proposals.valid_indices[proposals.sorted_indices]]
                 proposals.instance_sem_labels = data_batch.instance_sem_labels
 
         loss_prop_score = 0.0
@@ -339,7 +353,7 @@ class GAPartNet(LightningModule):
         if self.current_epoch >= self.start_npcs and voxel_tensor is not None:
             npcs_logits = self.forward_proposal_npcs(voxel_tensor, pc_voxel_id)
             if gt_npcs is not None:
-                gt_npcs = gt_npcs[proposals.valid_mask][proposals.sorted_indices]
+                gt_npcs = gt_npcs[proposals.valid_indices[proposals.sorted_indices]]
                 loss_prop_npcs = self.loss_proposal_npcs(npcs_logits, gt_npcs, proposals)
 
         loss = loss_sem_seg + loss_offset_dist + loss_offset_dir + loss_prop_score + loss_prop_npcs
@@ -449,4 +463,7 @@ class GAPartNet(LightningModule):
         self._epoch_end_metrics()
 
     def configure_optimizers(self):
-        return torch.optim.Adam(self.parameters(), lr=self.learning_rate)
+        params = list(self.parameters())
+        # same update rule; on the GPU the fused multi-tensor implementation does it in a handful of launches
+        fused = len(params) > 0 and all(p.is_cuda and p.dtype == torch.float32 for p in params)
+        return torch.optim.Adam(params, lr=self.learning_rate, fused=fused)

@@ -1,0 +1,392 @@
+"""Host side of the native layer-program executor (include/gpn.h section U, csrc/net.hip).
+
+The reference runs its sparse U-Net as a Python walk over ~200 spconv / BatchNorm1d modules per forward
+(network/backbone.py:40-49, 126-141, 150-155) and lets autograd walk back.  On MI355X the kernels of one layer take
+20-40 us, i.e. about as long as the interpreter needs to dispatch them, so the walk itself bounds the step.  This
+module flattens the same walk ONCE per network into a program (CONV / BN / CONCAT ops over numbered activation slots)
+and runs each forward / backward with a single library call; it is used by ``SparseUNet.forward`` whenever the raw-op
+backend is the HIP library.  The module tree (and so the state_dict) is untouched: the program only holds references
+to the modules' parameters and buffers.
+
+Results are those of the per-layer path (same kernels, same order); gradients of multiply-consumed activations are
+summed in reverse program order.
+"""
+import ctypes
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _C, backend
+from .. import functional as GF
+from ..spconv import pytorch as spconv
+
+# numpy mirrors of the C structs in include/gpn.h (sizes are checked against the header in tests/test_cabi.py)
+SLOT_DT = np.dtype([("data", "<u8"), ("grad", "<u8"), ("rows", "<i8"), ("channels", "<i4"), ("grad_state", "<i4")])
+RB_DT = np.dtype([("nbr", "<u8"), ("nbr_t", "<u8"), ("pair_src", "<u8"), ("pair_dst", "<u8"), ("tile_off", "<u8"),
+                  ("n_src", "<i8"), ("n_dst", "<i8"), ("K", "<i4"), ("reverse_taps", "<i4")])
+CONV_DT = np.dtype([("W", "<u8"), ("dW", "<u8"), ("cin", "<i4"), ("cout", "<i4")])
+BN_DT = np.dtype([("weight", "<u8"), ("bias", "<u8"), ("running_mean", "<u8"), ("running_var", "<u8"),
+                  ("save_mean", "<u8"), ("save_invstd", "<u8"), ("dweight", "<u8"), ("dbias", "<u8"),
+                  ("eps", "<f4"), ("momentum", "<f4"), ("C", "<i4"), ("reserved", "<i4")])
+OP_DT = np.dtype([("kind", "<i4"), ("src0", "<i4"), ("src1", "<i4"), ("dst", "<i4"), ("rulebook", "<i4"),
+                  ("param", "<i4"), ("flags", "<i4"), ("reserved", "<i4")])
+OP_CONV, OP_BN, OP_CONCAT = 0, 1, 2
+FLAG_RELU = 1
+
+
+class Unsupported(Exception):
+    """the network contains something the program cannot express; the caller falls back to the per-layer path"""
+
+
+def _bn_ok(bn) -> bool:
+    return (isinstance(bn, nn.BatchNorm1d) and bn.affine and bn.track_running_stats and bn.momentum is not None
+            and bn.num_features % 4 == 0)
+
+
+class NetProgram:
+    """static description of one SparseUNet: ops, slots (level, channels), and the modules whose tensors they use."""
+
+    def __init__(self, unet):
+        from .backbone import ResBlock, UBlock  # local: backbone imports this module
+        self._ResBlock, self._UBlock = ResBlock, UBlock
+        self.ops: List[tuple] = []
+        self.slot_level: List[int] = [0]
+        self.slot_channels: List[int] = [-1]  # slot 0 = the input features (channels filled below)
+        self.convs: List[nn.Module] = []
+        self.bns: List[nn.Module] = []
+        self.rb_keys: List[tuple] = []  # ("subm", level) | ("down", level) | ("inv", level) | ("ident", level)
+        self.level_keys = {}  # level -> (subm indice_key, down indice_key)
+        self.python_stem_conv = None
+        cur = 0
+        stem = unet.stem
+        if stem is not None:
+            mods = list(stem._modules.values())
+            if len(mods) == 3 and isinstance(mods[0], spconv.SubMConv3d) and isinstance(mods[2], nn.ReLU):
+                conv = mods[0]
+                if conv.kernel_size != [3, 3, 3] or conv.bias is not None:
+                    raise Unsupported("stem conv")
+                self.level_keys[0] = [conv.indice_key, None]
+                if conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0:
+                    self.slot_channels[0] = conv.in_channels
+                    cur = self._conv(conv, ("subm", 0), cur, 0)
+                else:
+                    self.python_stem_conv = conv  # 6-channel input: padded per-layer path, then the program
+                    self.slot_channels[0] = conv.out_channels
+                cur = self._bn(mods[1], cur, relu=True)
+            elif len(mods) == 2 and isinstance(mods[1], nn.ReLU):
+                self.slot_channels[0] = mods[0].num_features
+                cur = self._bn(mods[0], cur, relu=True)
+            else:
+                raise Unsupported("stem layout")
+        else:
+            self.slot_channels[0] = unet.ublock.channels[0]
+        self.out_slot = self._ublock(unet.ublock, 0, cur)
+        self.n_levels = max(self.slot_level) + 1
+        for lvl in range(self.n_levels):
+            keys = self.level_keys.get(lvl)
+            if keys is None or keys[0] is None or (lvl + 1 < self.n_levels and keys[1] is None):
+                raise Unsupported("indice keys")
+        # static tables
+        self.ops_np = np.zeros(len(self.ops), OP_DT)
+        for i, (kind, s0, s1, dst, rb, param, flags) in enumerate(self.ops):
+            self.ops_np[i] = (kind, s0, s1, dst, rb, param, flags, 0)
+        self.slot_level_np = np.asarray(self.slot_level, np.int64)
+        self.slot_channels_np = np.asarray(self.slot_channels, np.int64)
+        self.bn_C = np.asarray([bn.num_features for bn in self.bns], np.int64)
+        self.bn_off = np.concatenate([[0], np.cumsum(self.bn_C)])  # float offsets into the flat per-BN vectors
+        self.conv_numel = np.asarray([c.weight.numel() for c in self.convs], np.int64)
+        self.conv_off = np.concatenate([[0], np.cumsum(self.conv_numel)])
+        self.conv_ops = [(i, op) for i, op in enumerate(self.ops) if op[0] == OP_CONV]
+        self.signature = self._signature(unet)
+
+    # ------------------------------------------------------------------ program construction
+    def _new_slot(self, level, channels):
+        self.slot_level.append(level)
+        self.slot_channels.append(channels)
+        return len(self.slot_level) - 1
+
+    def _rb(self, key):
+        if key not in self.rb_keys:
+            self.rb_keys.append(key)
+        return self.rb_keys.index(key)
+
+    def _conv(self, conv, rb_key, src, dst_level):
+        if conv.bias is not None or conv.in_channels % 16 or conv.out_channels % 16:
+            raise Unsupported("conv shape / bias")
+        if self.slot_channels[src] != conv.in_channels:
+            raise Unsupported("channel mismatch")
+        dst = self._new_slot(dst_level, conv.out_channels)
+        self.convs.append(conv)
+        self.ops.append((OP_CONV, src, -1, dst, self._rb(rb_key), len(self.convs) - 1, 0))
+        return dst
+
+    def _bn(self, bn, src, relu, res=-1):
+        if not _bn_ok(bn) or bn.num_features != self.slot_channels[src]:
+            raise Unsupported("norm layer")
+        dst = self._new_slot(self.slot_level[src], bn.num_features)
+        self.bns.append(bn)
+        self.ops.append((OP_BN, src, res, dst, -1, len(self.bns) - 1, FLAG_RELU if relu else 0))
+        return dst
+
+    def _conv_norm(self, seq, rb_key, src, relu, res=-1):
+        mods = list(seq._modules.values())
+        if len(mods) != 2 or not isinstance(mods[0], spconv.SubMConv3d):
+            raise Unsupported("conv-norm pair")
+        want = [1, 1, 1] if rb_key[0] == "ident" else [3, 3, 3]
+        if mods[0].kernel_size != want:
+            raise Unsupported("kernel size")
+        return self._bn(mods[1], self._conv(mods[0], rb_key, src, self.slot_level[src]), relu, res)
+
+    def _resblock(self, blk, level, src):
+        if type(blk) is not self._ResBlock:
+            raise Unsupported("block type")
+        keys = self.level_keys.setdefault(level, [None, None])
+        key = blk.conv1[0].indice_key
+        if key is None or blk.conv2[0].indice_key != key or (keys[0] not in (None, key)):
+            raise Unsupported("indice key")
+        keys[0] = key
+        if isinstance(blk.shortcut, nn.Identity):
+            skip = src
+        else:
+            skip = self._conv_norm(blk.shortcut, ("ident", level), src, relu=False)
+        y = self._conv_norm(blk.conv1, ("subm", level), src, relu=True)
+        return self._conv_norm(blk.conv2, ("subm", level), y, relu=True, res=skip)
+
+    def _ublock(self, ub, level, src):
+        if type(ub) is not self._UBlock:
+            raise Unsupported("ublock type")
+        for blk in ub.encoder_blocks._modules.values():
+            src = self._resblock(blk, level, src)
+        if len(ub.channels) == 1:
+            return src
+        skip = src
+        down = list(ub.downsample._modules.values())
+        up = list(ub.upsample._modules.values())
+        if not (len(down) == 3 and isinstance(down[0], spconv.SparseConv3d) and isinstance(down[2], nn.ReLU)
+                and len(up) == 3 and isinstance(up[0], spconv.SparseInverseConv3d) and isinstance(up[2], nn.ReLU)
+                and down[0].indice_key is not None and down[0].indice_key == up[0].indice_key):
+            raise Unsupported("down / up layout")
+        self.level_keys[level][1] = down[0].indice_key
+        d = self._bn(down[1], self._conv(down[0], ("down", level), src, level + 1), relu=True)
+        d = self._ublock(ub.ublock, level + 1, d)
+        u = self._bn(up[1], self._conv(up[0], ("inv", level), d, level), relu=True)
+        cat = self._new_slot(level, self.slot_channels[u] + self.slot_channels[skip])
+        self.ops.append((OP_CONCAT, u, skip, cat, -1, -1, 0))
+        for blk in ub.decoder_blocks._modules.values():
+            cat = self._resblock(blk, level, cat)
+        return cat
+
+    @staticmethod
+    def _signature(unet):
+        """changes when modules are replaced (not when their tensors are updated in place)"""
+        return tuple(id(m) for m in unet.modules())
+
+    # ------------------------------------------------------------------ per-call state
+    def rulebooks(self, x):
+        """fetch / build the rulebook of every level through the tensor's indice_dict (same keys as the modules)"""
+        ops = backend.raw()
+        levels = [(x.indices, list(x.spatial_shape))]
+        subm, down = [], []
+        for lvl in range(self.n_levels):
+            idx, shape = levels[lvl]
+            skey, dkey = self.level_keys[lvl]
+            rb = x.indice_dict.get(skey)
+            if rb is None:
+                rb = ops.rulebook_subm3(idx, shape)
+                x.indice_dict[skey] = rb
+            subm.append(rb)
+            if lvl + 1 < self.n_levels:
+                rec = x.indice_dict.get(dkey)
+                if rec is None:
+                    out_idx, out_shape, rb_fwd, rb_bwd = ops.rulebook_down(idx, shape, x.batch_size)
+                    rec = spconv._DownRecord(idx, shape, out_idx, out_shape, rb_fwd, rb_bwd)
+                    x.indice_dict[dkey] = rec
+                down.append(rec)
+                levels.append((rec.out_indices, rec.out_shape))
+        rows = np.asarray([lv[0].shape[0] for lv in levels], np.int64)
+        table = np.zeros(len(self.rb_keys), RB_DT)
+        objs = []
+        for i, (kind, lvl) in enumerate(self.rb_keys):
+            if kind == "subm":
+                rb, rb_t, rev = subm[lvl], subm[lvl], 1
+            elif kind == "down":
+                rb, rb_t, rev = down[lvl].rb_fwd, down[lvl].rb_bwd, 0
+            elif kind == "inv":
+                rb, rb_t, rev = down[lvl].rb_bwd, down[lvl].rb_fwd, 0
+            else:
+                n = int(rows[lvl])
+                ikey = f"__identity_{n}__"
+                rb = x.indice_dict.get(ikey)
+                if rb is None:
+                    rb = spconv._identity_rulebook(n, x.features.device)
+                    x.indice_dict[ikey] = rb
+                rb_t, rev = rb, 0
+            table[i] = (rb.nbr.data_ptr(), rb_t.nbr.data_ptr(), rb.pair_src.data_ptr(), rb.pair_dst.data_ptr(),
+                        rb.tile_off.data_ptr(), rb.n_src, rb.n_dst, rb.K, rev)
+            objs.append((rb, rb_t))
+        return rows, table, objs, levels
+
+    def params(self):
+        return [c.weight for c in self.convs] + [b.weight for b in self.bns] + [b.bias for b in self.bns]
+
+
+def _vp(a: np.ndarray):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _call(fn_name, prog, slots, rb_table, conv_table, bn_table, extra, device):
+    from ..hip_ops import _fast_ws
+    L = _C.lib()
+    fn = getattr(L, fn_name)
+    ws_ptr, ws_size, stream = _fast_ws(device)
+    args = (_vp(prog.ops_np), len(prog.ops_np), _vp(slots), len(slots), _vp(rb_table), len(rb_table), _vp(conv_table),
+            len(conv_table), _vp(bn_table), len(bn_table)) + extra
+    rc = fn(*args, ctypes.c_void_p(ws_ptr), ctypes.c_size_t(ws_size), ctypes.c_void_p(stream))
+    if rc == 2:  # workspace too small: size it from the library's own estimate and retry
+        need = L.gpn_net_ws_bytes(_vp(prog.ops_np), len(prog.ops_np), _vp(slots), len(slots), _vp(rb_table),
+                                  _vp(conv_table))
+        ws_ptr, ws_size, stream = _fast_ws(device, int(need))
+        rc = fn(*args, ctypes.c_void_p(ws_ptr), ctypes.c_size_t(ws_size), ctypes.c_void_p(stream))
+    if rc:
+        raise _C.GpnError(f"{fn_name} failed: {L.gpn_last_error().decode('utf-8', 'replace')}")
+
+
+class _NetFn(torch.autograd.Function):
+    """the whole program as one differentiable op: inputs = features + every conv weight / BN weight / BN bias"""
+
+    @staticmethod
+    def forward(ctx, features, prog: NetProgram, rt, training, *params):
+        rows, rb_table, rb_objs = rt
+        features = features.contiguous()
+        dev = features.device
+        n_slots = len(prog.slot_level)
+        slot_rows = rows[prog.slot_level_np]
+        sizes = slot_rows * prog.slot_channels_np
+        sizes[0] = 0  # slot 0 is the caller's tensor
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        arena = torch.empty((int(offs[-1]),), dtype=torch.float32, device=dev)
+        base = arena.data_ptr()
+        slots = np.zeros(n_slots, SLOT_DT)
+        slots["data"] = base + offs[:-1] * 4
+        slots["data"][0] = features.data_ptr()
+        slots["rows"] = slot_rows
+        slots["channels"] = prog.slot_channels_np
+        n_conv, n_bn = len(prog.convs), len(prog.bns)
+        total_c = int(prog.bn_off[-1])
+        stats = torch.empty((2, total_c), dtype=torch.float32, device=dev)
+        conv_table = np.zeros(n_conv, CONV_DT)
+        conv_table["W"] = [p.data_ptr() for p in params[:n_conv]]
+        conv_table["cin"] = [c.in_channels for c in prog.convs]
+        conv_table["cout"] = [c.out_channels for c in prog.convs]
+        bn_table = np.zeros(n_bn, BN_DT)
+        bn_table["weight"] = [p.data_ptr() for p in params[n_conv:n_conv + n_bn]]
+        bn_table["bias"] = [p.data_ptr() for p in params[n_conv + n_bn:]]
+        bn_table["running_mean"] = [b.running_mean.data_ptr() for b in prog.bns]
+        bn_table["running_var"] = [b.running_var.data_ptr() for b in prog.bns]
+        bn_table["save_mean"] = stats.data_ptr() + prog.bn_off[:-1] * 4
+        bn_table["save_invstd"] = stats.data_ptr() + (total_c + prog.bn_off[:-1]) * 4
+        bn_table["eps"] = [b.eps for b in prog.bns]
+        bn_table["momentum"] = [b.momentum for b in prog.bns]
+        bn_table["C"] = prog.bn_C
+        _call("gpn_net_forward", prog, slots, rb_table, conv_table, bn_table, (1 if training else 0,), dev)
+        if GF.CONV_LOG is not None:
+            for _, op in prog.conv_ops:
+                conv, (rb, _rb_t) = prog.convs[op[5]], rb_objs[op[4]]
+                GF._log(rb, conv.in_channels, conv.out_channels, "fwd")
+        o = prog.out_slot
+        out = arena[int(offs[o]):int(offs[o + 1])].view(int(slot_rows[o]), int(prog.slot_channels_np[o]))
+        ctx.prog, ctx.rt, ctx.training = prog, rt, training
+        ctx.state = (features, arena, stats, slots, conv_table, bn_table, sizes, params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        prog = ctx.prog
+        rows, rb_table, rb_objs = ctx.rt
+        features, arena, stats, slots, conv_table, bn_table, sizes, params = ctx.state
+        dev = features.device
+        dout = dout.contiguous()
+        gsizes = sizes.copy()
+        gsizes[0] = features.numel()
+        gsizes[prog.out_slot] = 0  # the incoming gradient is used in place
+        goffs = np.concatenate([[0], np.cumsum(gsizes)])
+        garena = torch.empty((int(goffs[-1]),), dtype=torch.float32, device=dev)
+        slots = slots.copy()
+        slots["grad"] = garena.data_ptr() + goffs[:-1] * 4
+        slots["grad_state"] = 0
+        slots["grad"][prog.out_slot] = dout.data_ptr()
+        slots["grad_state"][prog.out_slot] = 1
+        n_conv, n_bn = len(prog.convs), len(prog.bns)
+        total_w, total_c = int(prog.conv_off[-1]), int(prog.bn_off[-1])
+        pgrad = torch.empty((total_w + 2 * total_c,), dtype=torch.float32, device=dev)
+        pbase = pgrad.data_ptr()
+        conv_table = conv_table.copy()
+        conv_table["dW"] = pbase + prog.conv_off[:-1] * 4
+        bn_table = bn_table.copy()
+        bn_table["dweight"] = pbase + (total_w + prog.bn_off[:-1]) * 4
+        bn_table["dbias"] = pbase + (total_w + total_c + prog.bn_off[:-1]) * 4
+        need_in = bool(ctx.needs_input_grad[0])
+        _call("gpn_net_backward", prog, slots, rb_table, conv_table, bn_table,
+              (1 if ctx.training else 0, 1 if need_in else 0), dev)
+        if GF.CONV_LOG is not None:
+            for _, op in prog.conv_ops:
+                conv, (rb, rb_t) = prog.convs[op[5]], rb_objs[op[4]]
+                if op[1] != 0 or need_in:
+                    GF._log(rb_t, conv.out_channels, conv.in_channels, "dgrad")
+                GF._log(rb, conv.in_channels, conv.out_channels, "wgrad")
+        din = garena[:features.numel()].view_as(features) if need_in else None
+        grads = []
+        for i in range(n_conv):
+            grads.append(pgrad[int(prog.conv_off[i]):int(prog.conv_off[i + 1])].view_as(params[i]))
+        for part in range(2):
+            for i in range(n_bn):
+                o = total_w + part * total_c
+                grads.append(pgrad[o + int(prog.bn_off[i]):o + int(prog.bn_off[i + 1])])
+        ctx.state = None
+        return (din, None, None, None, *grads)
+
+
+def program_for(unet) -> Optional[NetProgram]:
+    """the cached program of a SparseUNet (rebuilt if its module tree changed); None if it cannot be expressed"""
+    cached = unet.__dict__.get("_net_program")
+    if cached is not None:
+        if cached is False:
+            return None
+        return cached  # module replacement after the first forward needs invalidate(unet)
+    try:
+        prog = NetProgram(unet)
+    except Unsupported:
+        unet.__dict__["_net_program"] = False
+        return None
+    unet.__dict__["_net_program"] = prog
+    return prog
+
+
+def invalidate(unet):
+    """drop the cached program (call after replacing sub-modules of a SparseUNet that has already run)"""
+    unet.__dict__.pop("_net_program", None)
+
+
+def run(unet, x):
+    """SparseUNet.forward through the native executor; returns None when the per-layer path must be used."""
+    prog = program_for(unet)
+    if prog is None or x.features.shape[0] == 0 or not x.features.is_cuda or x.features.dtype != torch.float32:
+        return None
+    training = prog.bns[0].training
+    for bn in prog.bns:
+        if bn.training != training:
+            return None
+    if prog.python_stem_conv is not None:
+        x = prog.python_stem_conv(x)
+    rows, rb_table, rb_objs, levels = prog.rulebooks(x)
+    if int(rows.min()) < 1 or x.features.shape[1] != prog.slot_channels[0]:
+        return None
+    if training:
+        with torch.no_grad():
+            torch._foreach_add_([bn.num_batches_tracked for bn in prog.bns], 1)
+    out = _NetFn.apply(x.features, prog, (rows, rb_table, rb_objs), training, *prog.params())
+    lvl = prog.slot_level[prog.out_slot]
+    idx, shape = levels[lvl]
+    return spconv.SparseConvTensor(out, idx, shape, x.batch_size, x.indice_dict)

@@ -9,6 +9,7 @@ import torch
 class Instances:
     # selection of the points that entered clustering, and their order inside proposals
     valid_mask: Optional[torch.Tensor] = None
+    valid_indices: Optional[torch.Tensor] = None  # nonzero(valid_mask), computed once (not a reference field)
     sorted_indices: Optional[torch.Tensor] = None
     pt_xyz: Optional[torch.Tensor] = None
     # CSR over proposals

@@ -180,6 +180,84 @@ int gpn_scatter_rows_csr(const float* dout, const int32_t* order, const int32_t*
                          int64_t n_rows, int C, float* dtable, gpn_stream_t stream);
 
 /* ================================================================================================
+ * U — layer-program executor for the sparse residual U-Net (network/backbone.py:8-165: ResBlock.forward 40-49,
+ * UBlock.forward 126-141, SparseUNet.forward 150-155).  The reference walks ~200 spconv / BatchNorm modules per
+ * forward from Python; here the host side describes the same walk once as a flat op list and one call runs every
+ * conv / BN / concat launch of the forward (or of the backward, in reverse, accumulating gradients), so the step is
+ * not bound by per-layer interpreter overhead.  All arrays are host memory; every pointer inside them is device memory.
+ *   slot     : an activation matrix [rows, channels] (data) and, for backward, its gradient buffer (grad)
+ *   rulebook : neighbour table of the map and of its transpose (dgrad), plus the (tap,dst)-ordered pair lists (wgrad)
+ *   conv     : weight in parameter layout [Cout][K][Cin] (GPN_LAYOUT_OKI) and where its gradient goes
+ *   bn       : BatchNorm1d parameters / running stats / saved batch stats / gradients
+ *   op       : CONV dst = conv(src0)        | BN dst = act(bn(src0) [+ src1])   | CONCAT dst = [src0 | src1]
+ * forward: training != 0 uses batch statistics (saved into save_mean / save_invstd, running stats updated);
+ *          training == 0 uses the running statistics (save_invstd receives 1/sqrt(var+eps)).
+ * backward: slots[].grad of the final slot holds d(loss)/d(output); slots[].grad_state must be 0 everywhere except
+ *          slots that already hold a gradient (1).  Gradients of multiply-consumed slots are summed in program order
+ *          (reverse), so results are deterministic.  need_input_grad = 0 skips d/d(slot 0). */
+typedef struct gpn_net_slot {
+  float* data;
+  float* grad;
+  int64_t rows;
+  int32_t channels;
+  int32_t grad_state;
+} gpn_net_slot_t;
+typedef struct gpn_net_rulebook {
+  const int32_t* nbr;   /* [K][n_dst]  forward table */
+  const int32_t* nbr_t; /* [K][n_src]  table of the transposed map */
+  const int32_t* pair_src;
+  const int32_t* pair_dst;
+  const int32_t* tile_off;
+  int64_t n_src;
+  int64_t n_dst;
+  int32_t K;
+  int32_t reverse_taps; /* 1: SubM (transposed map = same table with taps reversed) */
+} gpn_net_rulebook_t;
+typedef struct gpn_net_conv {
+  const float* W;
+  float* dW;
+  int32_t cin;
+  int32_t cout;
+} gpn_net_conv_t;
+typedef struct gpn_net_bn {
+  const float* weight;
+  const float* bias;
+  float* running_mean;
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+  float* dweight;
+  float* dbias;
+  float eps;
+  float momentum;
+  int32_t C;
+  int32_t reserved;
+} gpn_net_bn_t;
+#define GPN_NET_CONV 0
+#define GPN_NET_BN 1
+#define GPN_NET_CONCAT 2
+#define GPN_NET_RELU 1 /* op.flags, BN only */
+typedef struct gpn_net_op {
+  int32_t kind;
+  int32_t src0;
+  int32_t src1; /* BN: residual slot or -1; CONCAT: right-hand input */
+  int32_t dst;
+  int32_t rulebook; /* CONV */
+  int32_t param;    /* CONV: index into convs; BN: index into bns */
+  int32_t flags;
+  int32_t reserved;
+} gpn_net_op_t;
+size_t gpn_net_ws_bytes(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, int n_slots,
+                        const gpn_net_rulebook_t* rulebooks, const gpn_net_conv_t* convs);
+int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
+                    const gpn_net_rulebook_t* rulebooks, int n_rulebooks, const gpn_net_conv_t* convs, int n_convs,
+                    const gpn_net_bn_t* bns, int n_bns, int training, void* ws, size_t ws_bytes, gpn_stream_t stream);
+int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
+                     const gpn_net_rulebook_t* rulebooks, int n_rulebooks, const gpn_net_conv_t* convs, int n_convs,
+                     const gpn_net_bn_t* bns, int n_bns, int training, int need_input_grad, void* ws, size_t ws_bytes,
+                     gpn_stream_t stream);
+
+/* ================================================================================================
  * B — ball query.  replaces epic_ops.ball_query.ball_query (network/grouping_utils.py:119-128).
  * points [Np,3], query [Q,3], batch_indices [Q] i32, batch_offsets [S+1] i32 (CSR over points),
  * point_labels [Np] / query_labels [Q] i32 (both may be NULL = no label filter).

@@ -67,3 +67,34 @@ def test_product_path_has_no_cpu_fallback():
         hip_ops.segmented_reduce(torch.zeros(4, 3), torch.zeros(1, dtype=torch.int32), torch.ones(1, dtype=torch.int32), "sum")
     from gapartnet_amd import backend
     assert backend.raw() is hip_ops
+
+
+def test_executor_struct_layouts_match_the_header(tmp_path):
+    """the numpy mirrors in network/net_exec.py must have exactly the C layout of the gpn_net_* structs"""
+    import subprocess
+    from gapartnet_amd.network import net_exec as NX
+    src = tmp_path / "sizes.c"
+    fields = {
+        "gpn_net_slot_t": (NX.SLOT_DT, ["data", "grad", "rows", "channels", "grad_state"]),
+        "gpn_net_rulebook_t": (NX.RB_DT, ["nbr", "nbr_t", "pair_src", "pair_dst", "tile_off", "n_src", "n_dst", "K",
+                                          "reverse_taps"]),
+        "gpn_net_conv_t": (NX.CONV_DT, ["W", "dW", "cin", "cout"]),
+        "gpn_net_bn_t": (NX.BN_DT, ["weight", "bias", "running_mean", "running_var", "save_mean", "save_invstd",
+                                    "dweight", "dbias", "eps", "momentum", "C", "reserved"]),
+        "gpn_net_op_t": (NX.OP_DT, ["kind", "src0", "src1", "dst", "rulebook", "param", "flags", "reserved"]),
+    }
+    body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/gpn.h"', "int main(void) {"]
+    for name, (_, names) in fields.items():
+        body.append(f'  printf("{name} %zu", sizeof({name}));')
+        for f in names:
+            body.append(f'  printf(" %zu", offsetof({name}, {f}));')
+        body.append('  printf("\\n");')
+    body.append("  return 0; }")
+    src.write_text("\n".join(body))
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(src)])  # also proves the header is plain C
+    for line in subprocess.check_output([str(exe)], text=True).strip().splitlines():
+        name, size, *offs = line.split()
+        dt, names = fields[name]
+        assert dt.itemsize == int(size), (name, dt.itemsize, size)
+        assert [dt.fields[f][1] for f in names] == [int(o) for o in offs], name

@@ -115,3 +115,67 @@ def test_full_size_train_step_runs_and_is_deterministic(cuda):
         grads.append(model.backbone.stem[0].weight.grad.clone())
     assert np.isfinite(losses[0]) and losses[0] == losses[1], losses
     assert torch.equal(grads[0], grads[1]), "conv fwd / dgrad / wgrad are fixed-order: bitwise reproducible"
+
+
+def _unet_case(cuda, without_stem):
+    import functools
+    import torch.nn as nn
+    from gapartnet_amd.network.backbone import SparseUNet
+    from gapartnet_amd.spconv import pytorch as spconv
+    from tests import synth
+    norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+    torch.manual_seed(3)
+    cin = 16 if without_stem else 6
+    net = SparseUNet.build(cin, [16, 32, 48, 64], 2, norm_fn, without_stem=without_stem).to(cuda)
+    rng = np.random.default_rng(7)
+    idx = torch.from_numpy(synth.surface_indices(rng, 3, [64, 64, 64], 2500)).to(cuda)
+    feats = torch.from_numpy(rng.normal(size=(idx.shape[0], cin)).astype(np.float32)).to(cuda)
+    return net, idx, feats, spconv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("without_stem", [False, True])
+@pytest.mark.parametrize("training", [True, False])
+def test_native_executor_matches_per_layer_path(cuda, without_stem, training):
+    """kernel family U: one-call forward/backward of the whole U-Net == the module-by-module walk (same kernels)"""
+    from gapartnet_amd.network import net_exec
+    net, idx, feats, spconv = _unet_case(cuda, without_stem)
+    assert net_exec.program_for(net) is not None, "the reference U-Net must be expressible as a program"
+    ref = copy.deepcopy(net)
+    ref.use_native_executor = False
+    net.train(training), ref.train(training)
+    outs, grads, in_grads = [], [], []
+    for model in (net, ref):
+        f = feats.clone().requires_grad_(True)
+        x = spconv.SparseConvTensor(f, idx, [64, 64, 64], 3)
+        y = model(x)
+        w = torch.linspace(-1, 1, y.features.numel(), device=cuda).view_as(y.features)
+        (y.features * w).sum().backward()
+        outs.append(y.features.detach())
+        in_grads.append(f.grad)
+        grads.append({k: p.grad for k, p in model.named_parameters()})
+        assert torch.equal(y.indices, idx)
+    assert torch.equal(outs[0], outs[1]), "forward: identical kernels in identical order -> bit-equal"
+    assert torch.allclose(in_grads[0], in_grads[1], rtol=1e-5, atol=1e-6)
+    for k in grads[1]:
+        assert grads[0][k] is not None, k
+        assert torch.allclose(grads[0][k], grads[1][k], rtol=1e-4, atol=1e-6), k
+    for (k, a), (_, b) in zip(net.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a, b), f"buffer / parameter {k} diverged (running statistics, num_batches_tracked)"
+
+
+@pytest.mark.gpu
+def test_native_executor_no_grad_and_frozen_input(cuda):
+    from gapartnet_amd.network import net_exec
+    net, idx, feats, spconv = _unet_case(cuda, True)
+    ref = copy.deepcopy(net)
+    ref.use_native_executor = False
+    with torch.no_grad():
+        a = net(spconv.SparseConvTensor(feats, idx, [64, 64, 64], 3)).features
+        b = ref(spconv.SparseConvTensor(feats, idx, [64, 64, 64], 3)).features
+    assert torch.equal(a, b)
+    # input that does not require grad: parameters still get their gradients
+    net(spconv.SparseConvTensor(feats, idx, [64, 64, 64], 3)).features.square().sum().backward()
+    ref(spconv.SparseConvTensor(feats, idx, [64, 64, 64], 3)).features.square().sum().backward()
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6), k

@@ -39,3 +39,23 @@ torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(35)
+
+# host-side time of each phase (no sync inside the phase; the queue is drained between phases)
+acc = {"fwd": 0.0, "bwd": 0.0, "opt": 0.0, "gpu_total": 0.0}
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    opt.zero_grad(set_to_none=True)
+    loss = model.training_step(batch, 0)
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    opt.step()
+    t3 = time.perf_counter()
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    acc["fwd"] += t1 - t0
+    acc["bwd"] += t2 - t1
+    acc["opt"] += t3 - t2
+    acc["gpu_total"] += t4 - t0
+print({k: round(v / 5 * 1e3, 2) for k, v in acc.items()})
