@@ -5,10 +5,16 @@
 // Here the host describes that walk once as a flat list of CONV / BN / CONCAT ops over numbered activation slots and
 // this file issues every launch of the forward (or of the backward, in reverse program order) from one native loop.
 // The arithmetic is exactly that of the per-layer entry points (gpn_spconv_fwd_w, gpn_spconv_wgrad, gpn_bn_*), which
-// this file calls; the only kernels of its own are the column concat / split and the gradient accumulation.
+// this file calls; the kernels of its own are the column concat / split, the gradient accumulation and a batched
+// weight packer (every weight of the program packed by a few launches at the start of a pass instead of one launch
+// per layer).  In backward the weight-gradient contractions run on a second (lower-priority) stream: they are off
+// the critical path (nothing in the backward pass consumes dW), so they fill the CUs the dependent dgrad / BN chain
+// of the small, deep levels leaves idle.
 #include <algorithm>
+#include <vector>
 
 #include "gpn_common.h"
+#include "spconv_pack.h"
 
 namespace {
 
@@ -62,6 +68,24 @@ __global__ void invstd_kernel(const float* __restrict__ var, float eps, int C, f
   if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
 }
 
+// batched weight packing: up to kPackBatch weights per launch, descriptors passed by value in the kernel arguments
+constexpr int kPackBatch = 24;
+struct PackDesc {
+  const float* W;
+  float* packed;
+  int K, cin_w, cout_w, flags;
+};
+struct PackBatch {
+  PackDesc d[kPackBatch];
+};
+
+__global__ __launch_bounds__(kThreads) void pack_many_kernel(PackBatch batch) {
+  const PackDesc d = batch.d[blockIdx.y];
+  const int64_t total = (int64_t)d.K * d.cin_w * d.cout_w;
+  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < total; t += (int64_t)gridDim.x * kThreads)
+    d.packed[t] = gpn::packed_weight_element(d.W, d.K, d.cin_w, d.cout_w, d.flags, t);
+}
+
 inline int grid_for(int64_t total) {
   int64_t g = gpn::cdiv(total, kThreads);
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -70,8 +94,10 @@ inline int grid_for(int64_t total) {
 inline size_t slot_bytes(const gpn_net_slot_t& s) { return (size_t)s.rows * s.channels * sizeof(float); }
 
 struct Need {
-  size_t tmp = 0;  // gradient staging buffer (largest slot that can receive a second gradient)
-  size_t op = 0;   // largest per-op workspace
+  size_t tmp = 0;     // gradient staging buffer (largest slot that can receive a second gradient)
+  size_t op = 0;      // largest per-op workspace of the main chain (conv tap-split partials, BN partials)
+  size_t wgrad = 0;   // largest wgrad workspace (side stream)
+  size_t packed = 0;  // all packed weights of the program
 };
 
 Need workspace_need(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, const gpn_net_rulebook_t* rbs,
@@ -83,10 +109,11 @@ Need workspace_need(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* sl
     if (op.kind == GPN_NET_CONV) {
       const gpn_net_rulebook_t& rb = rbs[op.rulebook];
       const gpn_net_conv_t& cv = convs[op.param];
-      size_t w = gpn_spconv_fwd_w_ws_bytes(rb.K, rb.n_dst, cv.cin, cv.cout);
-      size_t wt = gpn_spconv_fwd_w_ws_bytes(rb.K, rb.n_src, cv.cout, cv.cin);
-      size_t wg = gpn_spconv_wgrad_ws_bytes(rb.K, cv.cin, cv.cout, rb.n_dst);
-      n.op = std::max(n.op, std::max(w, std::max(wt, wg)));
+      size_t w = gpn_spconv_fwd_ws_bytes(rb.K, rb.n_dst, cv.cin, cv.cout);
+      size_t wt = gpn_spconv_fwd_ws_bytes(rb.K, rb.n_src, cv.cout, cv.cin);
+      n.op = std::max(n.op, std::max(w, wt));
+      n.wgrad = std::max(n.wgrad, gpn_spconv_wgrad_ws_bytes(rb.K, cv.cin, cv.cout, rb.n_dst));
+      n.packed += gpn::align_up((size_t)rb.K * cv.cin * cv.cout * sizeof(float));
       n.tmp = std::max(n.tmp, slot_bytes(s0));
     } else if (op.kind == GPN_NET_BN) {
       n.op = std::max(n.op, gpn_bn_ws_bytes(s0.rows, s0.channels));
@@ -95,7 +122,73 @@ Need workspace_need(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* sl
   }
   n.tmp = gpn::align_up(n.tmp);
   n.op = gpn::align_up(n.op);
+  n.wgrad = gpn::align_up(n.wgrad);
   return n;
+}
+
+// pack the weight of every CONV op into `area` (transposed [+ tap-reversed] for the backward pass); packed_of[i] is the
+// packed weight of op i.  ceil(n_conv / kPackBatch) launches.
+int pack_program(const gpn_net_op_t* ops, int n_ops, const gpn_net_rulebook_t* rbs, const gpn_net_conv_t* convs,
+                 bool transposed, char* area, std::vector<const float*>& packed_of, hipStream_t stream) {
+  packed_of.assign(n_ops, nullptr);
+  PackBatch batch;
+  int fill = 0;
+  int64_t max_total = 0;
+  size_t off = 0;
+  auto flush = [&]() -> int {
+    if (fill == 0) return GPN_OK;
+    int gx = (int)std::min<int64_t>(gpn::cdiv(max_total, kThreads), 256);
+    hipLaunchKernelGGL(pack_many_kernel, dim3(gx, fill), dim3(kThreads), 0, stream, batch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      gpn::set_error("gpn_net: weight packing launch failed: %s", hipGetErrorString(e));
+      return GPN_ERR_HIP;
+    }
+    fill = 0;
+    max_total = 0;
+    return GPN_OK;
+  };
+  for (int i = 0; i < n_ops; ++i) {
+    if (ops[i].kind != GPN_NET_CONV) continue;
+    const gpn_net_rulebook_t& rb = rbs[ops[i].rulebook];
+    const gpn_net_conv_t& cv = convs[ops[i].param];
+    float* dst = reinterpret_cast<float*>(area + off);
+    off += gpn::align_up((size_t)rb.K * cv.cin * cv.cout * sizeof(float));
+    packed_of[i] = dst;
+    int flags = GPN_LAYOUT_OKI;
+    if (transposed) flags |= GPN_PACK_TRANSPOSE | (rb.reverse_taps ? GPN_PACK_REVERSE : 0);
+    batch.d[fill++] = PackDesc{cv.W, dst, rb.K, cv.cin, cv.cout, flags};
+    max_total = std::max<int64_t>(max_total, (int64_t)rb.K * cv.cin * cv.cout);
+    if (fill == kPackBatch) {
+      int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  return flush();
+}
+
+// the second stream (and the events that order it against the caller's stream), one set per device
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork[8] = {};
+  hipEvent_t join = nullptr;
+  int next = 0;
+};
+
+SideStream* side_stream() {
+  static SideStream per_device[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& s = per_device[dev];
+  if (!s.stream) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically largest = lowest priority
+    if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+    for (auto& e : s.fork)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &s;
 }
 
 int check_program(const char* who, const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, int n_slots,
@@ -144,7 +237,7 @@ extern "C" size_t gpn_net_ws_bytes(const gpn_net_op_t* ops, int n_ops, const gpn
   (void)n_slots;
   if (!ops || !slots) return 0;
   const Need n = workspace_need(ops, n_ops, slots, rulebooks, convs);
-  return n.tmp + n.op;
+  return n.tmp + n.op + n.wgrad + n.packed;
 }
 
 extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
@@ -155,10 +248,15 @@ extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_
   int rc = check_program(__func__, ops, n_ops, slots, n_slots, rbs, n_rbs, convs, n_convs, bns, n_bns);
   if (rc) return rc;
   const Need need = workspace_need(ops, n_ops, slots, rbs, convs);
-  if (!ws || ws_bytes < need.op) {
-    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, need.op, ws_bytes);
+  if (!ws || ws_bytes < need.packed + need.op) {
+    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, need.packed + need.op, ws_bytes);
     return GPN_ERR_WS;
   }
+  std::vector<const float*> packed_of;
+  rc = pack_program(ops, n_ops, rbs, convs, false, static_cast<char*>(ws), packed_of, stream);
+  if (rc) return rc;
+  void* op_ws = static_cast<char*>(ws) + need.packed;
+  const size_t op_ws_bytes = ws_bytes - need.packed;
   for (int i = 0; i < n_ops; ++i) {
     const gpn_net_op_t& op = ops[i];
     const gpn_net_slot_t &s0 = slots[op.src0], &d = slots[op.dst];
@@ -169,15 +267,15 @@ extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_
     if (op.kind == GPN_NET_CONV) {
       const gpn_net_rulebook_t& rb = rbs[op.rulebook];
       const gpn_net_conv_t& cv = convs[op.param];
-      rc = gpn_spconv_fwd_w(s0.data, cv.W, rb.K, cv.cin, cv.cout, GPN_LAYOUT_OKI, rb.nbr, rb.n_dst, d.data, ws, ws_bytes,
-                            stream_);
+      rc = gpn_spconv_fwd(s0.data, packed_of[i], rb.nbr, rb.K, rb.n_dst, cv.cin, cv.cout, d.data, op_ws, op_ws_bytes,
+                          stream_);
     } else if (op.kind == GPN_NET_BN) {
       const gpn_net_bn_t& bn = bns[op.param];
       const float* res = op.src1 >= 0 ? slots[op.src1].data : nullptr;
       const int relu = (op.flags & GPN_NET_RELU) ? 1 : 0;
       if (training) {
         rc = gpn_bn_fwd_train(s0.data, res, bn.weight, bn.bias, s0.rows, bn.C, bn.eps, bn.momentum, relu, d.data,
-                              bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, ws, ws_bytes, stream_);
+                              bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, op_ws, op_ws_bytes, stream_);
       } else {
         if (!bn.running_mean || !bn.running_var || !bn.save_invstd) {
           gpn::set_error("%s: op %d: eval-mode BatchNorm needs running statistics", __func__, i);
@@ -239,13 +337,29 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
   int rc = check_program(__func__, ops, n_ops, slots, n_slots, rbs, n_rbs, convs, n_convs, bns, n_bns);
   if (rc) return rc;
   const Need need = workspace_need(ops, n_ops, slots, rbs, convs);
-  if (!ws || ws_bytes < need.tmp + need.op) {
-    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, need.tmp + need.op, ws_bytes);
+  const size_t total_need = need.tmp + need.packed + need.op + need.wgrad;
+  if (!ws || ws_bytes < total_need) {
+    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, total_need, ws_bytes);
     return GPN_ERR_WS;
   }
-  float* tmp = static_cast<float*>(ws);
-  void* op_ws = static_cast<char*>(ws) + need.tmp;
-  const size_t op_ws_bytes = ws_bytes - need.tmp;
+  char* base = static_cast<char*>(ws);
+  float* tmp = reinterpret_cast<float*>(base);
+  void* op_ws = base + need.tmp + need.packed;
+  const size_t op_ws_bytes = need.op;
+  void* wgrad_ws = base + need.tmp + need.packed + need.op;
+  const size_t wgrad_ws_bytes = ws_bytes - (need.tmp + need.packed + need.op);
+  std::vector<const float*> packed_of;
+  rc = pack_program(ops, n_ops, rbs, convs, true, base + need.tmp, packed_of, stream);
+  if (rc) return rc;
+  SideStream* side = side_stream();
+  if (!side) {
+    gpn::set_error("%s: could not create the weight-gradient stream", __func__);
+    return GPN_ERR_HIP;
+  }
+  // the side stream may still be reading the workspace of the previous call on this device
+  GPN_CHECK_HIP(hipEventRecord(side->join, side->stream));
+  GPN_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
+  bool forked = false;
   for (int i = n_ops - 1; i >= 0; --i) {
     const gpn_net_op_t& op = ops[i];
     gpn_net_slot_t &s0 = slots[op.src0], &d = slots[op.dst];
@@ -262,9 +376,15 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
           gpn::set_error("%s: op %d: rulebook has no pair lists for wgrad", __func__, i);
           return GPN_ERR_ARG;
         }
+        // d.grad is final here (every consumer of slot d ran earlier in this reverse walk): fork the contraction
+        hipEvent_t ev = side->fork[side->next];
+        side->next = (side->next + 1) % 8;
+        GPN_CHECK_HIP(hipEventRecord(ev, stream));
+        GPN_CHECK_HIP(hipStreamWaitEvent(side->stream, ev, 0));
         rc = gpn_spconv_wgrad(s0.data, d.grad, rb.pair_src, rb.pair_dst, rb.tile_off, rb.K, rb.n_dst, cv.cin, cv.cout,
-                              GPN_LAYOUT_OKI, cv.dW, op_ws, op_ws_bytes, stream_);
+                              GPN_LAYOUT_OKI, cv.dW, wgrad_ws, wgrad_ws_bytes, (gpn_stream_t)side->stream);
         if (rc) return rc;
+        forked = true;
       }
       if (op.src0 != 0 || need_input_grad) {
         if (!s0.grad || !rb.nbr_t) {
@@ -272,9 +392,8 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
           return GPN_ERR_ARG;
         }
         GradTarget t = grad_target(s0, tmp);
-        rc = gpn_spconv_fwd_w(d.grad, cv.W, rb.K, cv.cin, cv.cout,
-                              GPN_LAYOUT_OKI | GPN_PACK_TRANSPOSE | (rb.reverse_taps ? GPN_PACK_REVERSE : 0), rb.nbr_t,
-                              rb.n_src, t.ptr, op_ws, op_ws_bytes, stream_);
+        rc = gpn_spconv_fwd(d.grad, packed_of[i], rb.nbr_t, rb.K, rb.n_src, cv.cout, cv.cin, t.ptr, op_ws, op_ws_bytes,
+                            stream_);
         if (rc) return rc;
         rc = commit(s0, t, stream);
         if (rc) return rc;
@@ -323,6 +442,10 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
       s0.grad_state = 1;
       s1.grad_state = 1;
     }
+  }
+  if (forked) {  // join: whatever the caller enqueues next (optimizer, the next pass) sees every dW
+    GPN_CHECK_HIP(hipEventRecord(side->join, side->stream));
+    GPN_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
   }
   return GPN_OK;
 }

@@ -18,6 +18,7 @@
 //    packed weights.  wgrad contracts over pairs: A = in[src]^T, B = dout[dst], 4 pairs per MFMA,
 //    split over (tap, pair-range, cin-group) workgroups with a fixed-order partial reduction.
 #include "gpn_common.h"
+#include "spconv_pack.h"
 
 namespace {
 
@@ -27,28 +28,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // weight packing:  packed[k][cb][nt][lane][s] = Wop[k][16cb + 4(lane>>4) + s][16nt + (lane&15)]
 __global__ void pack_weights_kernel(const float* __restrict__ W, int K, int cin_w, int cout_w, int flags,
                                     float* __restrict__ packed) {
-  const int cin = (flags & GPN_PACK_TRANSPOSE) ? cout_w : cin_w;
-  const int cout = (flags & GPN_PACK_TRANSPOSE) ? cin_w : cout_w;
-  const int64_t total = (int64_t)K * cin * cout;
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * cin_w * cout_w;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
-  const int s = (int)(t & 3);
-  const int lane = (int)((t >> 2) & 63);
-  int64_t r = t >> 8;
-  const int NT = cout / 16, CB = cin / 16;
-  const int nt = (int)(r % NT); r /= NT;
-  const int cb = (int)(r % CB); r /= CB;
-  const int k = (int)r;
-  const int ci = cb * 16 + 4 * (lane >> 4) + s;
-  const int co = nt * 16 + (lane & 15);
-  const int kk = (flags & GPN_PACK_REVERSE) ? (K - 1 - k) : k;
-  // element (tap kk, input channel wi, output channel wo) of the stored weight
-  const int wi = (flags & GPN_PACK_TRANSPOSE) ? co : ci;
-  const int wo = (flags & GPN_PACK_TRANSPOSE) ? ci : co;
-  float v;
-  if (flags & GPN_LAYOUT_OKI) v = W[((int64_t)wo * K + kk) * cin_w + wi];   // spconv-2.x parameter [Cout][K][Cin]
-  else v = W[((int64_t)kk * cin_w + wi) * cout_w + wo];                     // canonical [K][Cin][Cout]
-  packed[t] = v;
+  packed[t] = gpn::packed_weight_element(W, K, cin_w, cout_w, flags, t);
 }
 
 // ------------------------------------------------------------------------------------------------

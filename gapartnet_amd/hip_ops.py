@@ -79,9 +79,11 @@ class Rulebook:
 
 
 # ---------------------------------------------------------------------------------------------------- V
-def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_size, grid_dims, want_csr=False):
+def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_size, grid_dims, want_csr=False,
+             want_stats=False):
     """Kernel V. Returns (voxel_feats [V,C], voxel_coords [V,3] i32, voxel_seg [V] i32, pc_voxel_id [M] i32
-    [, point_order [M] i32, voxel_point_start [V+1] i32]).  One host sync (number of voxels)."""
+    [, point_order [M] i32, voxel_point_start [V+1] i32] [, stats]).  One host sync (number of voxels); with
+    ``want_stats`` the same read also brings stats = {"max_coord": [3 ints], "dropped": points outside the grid}."""
     dev = _dev(points, feats, seg_offsets)
     points, feats = _c(points, torch.float32), _c(feats, torch.float32)
     seg_offsets = _c(seg_offsets, torch.int64)
@@ -101,10 +103,19 @@ def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_siz
                             i64(S), host_f32x3(voxel_size), host_i32x3(grid_dims), ptr(vf), ptr(vc), ptr(vseg),
                             ptr(pid), ptr(nv), ptr(order), ptr(vstart), ptr(ws), szt(ws.numel()), _stream()),
           "gpn_voxelize")
-    V = int(nv.item())
+    stats = None
+    if want_stats:
+        live = torch.arange(M, device=dev)[:, None] < nv
+        head = torch.cat([nv, torch.where(live, vc, torch.zeros_like(vc)).amax(0).to(torch.int64) if M > 0 else
+                          torch.zeros((3,), dtype=torch.int64, device=dev), (pid < 0).sum()[None]]).tolist()
+        V, stats = head[0], {"max_coord": head[1:4], "dropped": head[4]}
+    else:
+        V = int(nv.item())
     out = (vf[:V], vc[:V], vseg[:V], pid)
     if want_csr:
         out = out + (order, vstart[:V + 1])
+    if want_stats:
+        out = out + (stats,)
     return out
 
 

@@ -37,17 +37,43 @@ def compute_npcs_loss(npcs_preds: torch.Tensor, gt_npcs: torch.Tensor, proposal_
     return per_proposal.min(dim=-1)[0].mean()
 
 
+def compute_npcs_loss_masked(npcs_preds: torch.Tensor, gt_npcs: torch.Tensor, proposal_indices: torch.Tensor,
+                             symmetry_matrix: torch.Tensor, member: torch.Tensor, num_proposals: int) -> torch.Tensor:
+    """``compute_npcs_loss`` restricted to the points where ``member`` is set, WITHOUT selecting them: same value as
+    compute_npcs_loss(npcs_preds[member], gt_npcs[member], proposal_indices[member], symmetry_matrix[member]) (0 when
+    no point is a member), but no data-dependent shapes and therefore no host sync.  ``proposal_indices`` must be
+    non-decreasing with values in [0, num_proposals); per-proposal sums are differences of a float64 running sum
+    (deterministic, differentiable)."""
+    targets = torch.matmul(gt_npcs[:, None, None, :], symmetry_matrix).squeeze(2)          # [n, m, 3]
+    dist2 = ((npcs_preds[:, None, :] - targets - 0.5) ** 2).sum(dim=-1)                  # [n, m]
+    cost = torch.where(dist2 <= 0.01, 5 * dist2, torch.sqrt(dist2) - 0.05)
+    cost = torch.where(member[:, None], cost, torch.zeros_like(cost))
+    n, m = cost.shape
+    running = torch.cat([cost.new_zeros((1, m), dtype=torch.float64), cost.double().cumsum(0)], dim=0)
+    members = torch.cat([member.new_zeros((1,), dtype=torch.int64), member.long().cumsum(0)], dim=0)
+    edges = torch.searchsorted(proposal_indices.contiguous(),
+                               torch.arange(num_proposals + 1, dtype=proposal_indices.dtype, device=cost.device))
+    seg_sum = running[edges[1:]] - running[edges[:-1]]                                    # [P, m]
+    seg_cnt = members[edges[1:]] - members[edges[:-1]]                                    # [P]
+    has = seg_cnt > 0
+    per_proposal = (seg_sum / seg_cnt.clamp(min=1)[:, None]).to(cost.dtype)
+    best = per_proposal.min(dim=-1)[0]
+    total = torch.where(has, best, torch.zeros_like(best)).sum()
+    return total / has.sum().clamp(min=1)
+
+
 # ------------------------------------------------------------------------------------------------- re-voxelise
 def segmented_voxelize(pt_xyz: torch.Tensor, pt_features: torch.Tensor, segment_offsets: torch.Tensor,
                        segment_indices: torch.Tensor, num_points_per_segment: torch.Tensor, score_fullscale: float,
-                       score_scale: float, jitter: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
-                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                       score_scale: float, jitter: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                       with_extras: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Scale every proposal into a ``score_fullscale``^3 grid and voxelise it as its own batch element
     (grouping_utils.py:47-104).  -> (voxel_features, voxel_coords [V,4] = (proposal, x, y, z), pc_voxel_id).
 
     ``jitter`` = the two uniform 3-vectors the reference draws with torch.rand(3) (grouping_utils.py:86-90, one pair
     shared by all proposals, drawn in eval too); pass them to make a run reproducible, else they are drawn here in
-    the same order from the device generator."""
+    the same order from the device generator.  ``with_extras`` appends {"csr": points grouped by voxel (for the
+    gather's backward), "dropped": number of points that fell outside the grid}, both from the voxeliser's own pass."""
     begin, end = segment_offsets[:-1], segment_offsets[1:]
     mean = segmented_reduce(pt_xyz, begin, end, mode="sum") / num_points_per_segment[:, None]
     centered = pt_xyz - mean[segment_indices]
@@ -73,6 +99,11 @@ def segmented_voxelize(pt_xyz: torch.Tensor, pt_features: torch.Tensor, segment_
     rmin = torch.zeros((1, 3), dtype=torch.float32, device=dev)
     rmax = torch.full((1, 3), full, dtype=torch.float32, device=dev)
     # direct kernel-V call with host-known grid (no sync for the range tensors, unlike the generic wrapper)
+    if with_extras:
+        vf, vc, vseg, pid, order, starts, stats = backend.raw().voxelize(
+            scaled, pt_features, segment_offsets.to(torch.int64), rmin, rmax, [1.0, 1.0, 1.0], [int(full) + 1] * 3,
+            want_csr=True, want_stats=True)
+        return vf, torch.cat([vseg[:, None], vc], dim=1), pid, {"csr": (order, starts), "dropped": stats["dropped"]}
     vf, vc, vseg, pid = backend.raw().voxelize(scaled, pt_features, segment_offsets.to(torch.int64), rmin, rmax,
                                                [1.0, 1.0, 1.0], [int(full) + 1] * 3)
     voxel_coords = torch.cat([vseg[:, None], vc], dim=1)

@@ -32,6 +32,18 @@ def focal_loss(inputs: torch.Tensor, targets: torch.Tensor, alpha: Optional[torc
                reduction: str = "mean", ignore_index: int = -100) -> torch.Tensor:
     """multi-class focal loss: -(1 - p_t)^gamma * log p_t (optionally class-weighted by alpha); rows whose target is
     ``ignore_index`` are removed first; an all-ignored batch gives 0 (losses.py:35-64)."""
+    if ignore_index is not None and reduction in ("mean", "sum"):
+        # masked form of "drop the ignored rows, then reduce": no boolean-mask selection, so no host sync
+        keep = targets != ignore_index
+        safe = torch.where(keep, targets, torch.zeros_like(targets))
+        log_p = F.log_softmax(inputs, dim=-1)
+        log_pt = log_p.gather(1, safe[:, None]).squeeze(-1)
+        ce = -log_pt if alpha is None else -log_pt * alpha[safe]
+        loss = torch.where(keep, ce * (1 - log_pt.exp()) ** gamma, torch.zeros_like(ce))
+        if reduction == "sum":
+            return loss.sum()
+        count = keep.sum()
+        return torch.where(count > 0, loss.sum() / count.clamp(min=1), torch.zeros_like(loss.sum()))
     if ignore_index is not None:
         keep = targets != ignore_index
         targets = targets[keep]

@@ -31,8 +31,8 @@ from ..structure.instances import Instances
 from ..structure.point_cloud import PointCloud, PointCloudBatch
 from ..structure.segmentation import Segmentation
 from .backbone import SparseUNet
-from .grouping_utils import (apply_nms, cluster_proposals, compute_ap, compute_npcs_loss, filter_invalid_proposals,
-                             get_gt_scores, offsets_from_counts, segmented_voxelize)
+from .grouping_utils import (apply_nms, cluster_proposals, compute_ap, compute_npcs_loss, compute_npcs_loss_masked,
+                             filter_invalid_proposals, get_gt_scores, offsets_from_counts, segmented_voxelize)
 from .losses import dice_loss, focal_loss, mean_iou, pixel_accuracy
 
 _SPLITS = ["val", "test_intra", "test_inter"]
@@ -165,7 +165,8 @@ class GAPartNet(LightningModule):
 
     def proposal_clustering_and_revoxelize(self, pt_xyz: torch.Tensor, batch_indices: torch.Tensor,
                                            pt_features: torch.Tensor, sem_preds: torch.Tensor,
-                                           offset_preds: torch.Tensor, instance_labels: Optional[torch.Tensor]):
+                                           offset_preds: torch.Tensor, instance_labels: Optional[torch.Tensor],
+                                           batch_size: Optional[int] = None):
         """dual-set clustering and per-proposal re-voxelisation (model.py:228-346).
         -> (voxel_tensor, pc_voxel_id, proposals) or (None, None, None) when no proposal survives."""
         device = pt_xyz.device
@@ -180,10 +181,18 @@ class GAPartNet(LightningModule):
         if instance_labels is not None:
             instance_labels = instance_labels[valid_indices]
 
-        # CSR over the scenes that still have points
-        _, scene_compact, scene_counts = torch.unique_consecutive(batch_indices, return_inverse=True, return_counts=True)
-        scene_compact = scene_compact.int()
-        scene_offsets = offsets_from_counts(scene_counts)
+        if batch_size is not None:
+            # CSR over all scenes (empty ones included: they own no points and no queries, so the clusters are the
+            # same): batch_indices is sorted, so the offsets are a binary search - no host sync
+            scene_compact = batch_indices.int()
+            scene_offsets = torch.searchsorted(
+                scene_compact, torch.arange(batch_size + 1, dtype=torch.int32, device=device)).to(torch.int32)
+        else:
+            # CSR over the scenes that still have points
+            _, scene_compact, scene_counts = torch.unique_consecutive(batch_indices, return_inverse=True,
+                                                                      return_counts=True)
+            scene_compact = scene_compact.int()
+            scene_offsets = offsets_from_counts(scene_counts)
 
         # set 1: clusters in xyz; set 2: clusters in xyz shifted by the predicted centre offsets
         labels_a, order_a = cluster_proposals(pt_xyz, scene_compact, scene_offsets, sem_preds,
@@ -193,7 +202,14 @@ class GAPartNet(LightningModule):
         labels = torch.cat([labels_a, labels_b + labels_a.shape[0]], dim=0)
         sorted_indices = torch.cat([order_a, order_b], dim=0)
 
-        _, proposal_indices, sizes = torch.unique_consecutive(labels, return_inverse=True, return_counts=True)
+        # size of the run (cluster) every point belongs to, with the run count bounded by the point count instead of
+        # read back from the device (the reference's unique_consecutive here is one more host sync)
+        n_pts = labels.shape[0]
+        run_start = torch.ones((n_pts,), dtype=torch.bool, device=device)
+        run_start[1:] = labels[1:] != labels[:-1]
+        proposal_indices = run_start.long().cumsum(0) - 1
+        sizes = torch.zeros((n_pts,), dtype=torch.int64, device=device).scatter_add_(
+            0, proposal_indices, torch.ones((n_pts,), dtype=torch.int64, device=device))
         keep_point = torch.nonzero((sizes >= self.min_num_points_per_proposal)[proposal_indices]).squeeze(1)
         sorted_indices = sorted_indices[keep_point]
         if sorted_indices.shape[0] == 0:
@@ -209,12 +225,13 @@ class GAPartNet(LightningModule):
         num_proposals = sizes.shape[0]
         proposal_offsets = offsets_from_counts(sizes)
 
-        voxel_features, voxel_coords, pc_voxel_id = segmented_voxelize(
+        voxel_features, voxel_coords, pc_voxel_id, extras = segmented_voxelize(
             pt_xyz, pt_features, proposal_offsets, proposal_indices, sizes, self.score_fullscale, self.score_scale,
-            jitter=self.revoxelize_jitter)
+            jitter=self.revoxelize_jitter, with_extras=True)
         voxel_tensor = spconv.SparseConvTensor(voxel_features, voxel_coords.int(),
                                                spatial_shape=[self.score_fullscale] * 3, batch_size=num_proposals)
-        if not bool((pc_voxel_id >= 0).all()):
+        voxel_tensor.point_csr = extras["csr"]  # points grouped by voxel: the transpose of the voxel->point gathers
+        if extras["dropped"] != 0:
             raise RuntimeError("re-voxelisation dropped points: a proposal left its score_fullscale^3 grid "
                                "(the reference stops in pdb here, model.py:328-330)")
 
@@ -228,7 +245,7 @@ class GAPartNet(LightningModule):
                                proposals: Instances) -> torch.Tensor:
         offsets = proposals.proposal_offsets
         feats = self.score_unet(voxel_tensor)
-        feats = GF.gather_rows(feats.features, pc_voxel_id)
+        feats = GF.gather_rows(feats.features, pc_voxel_id, getattr(voxel_tensor, "point_csr", None))
         pooled, _ = segmented_maxpool(feats, offsets[:-1], offsets[1:])
         return self.score_head(pooled)
 
@@ -243,7 +260,7 @@ class GAPartNet(LightningModule):
 
     def forward_proposal_npcs(self, voxel_tensor: spconv.SparseConvTensor, pc_voxel_id: torch.Tensor) -> torch.Tensor:
         feats = self.npcs_unet(voxel_tensor)
-        return GF.gather_rows(self.npcs_head(feats.features), pc_voxel_id)
+        return GF.gather_rows(self.npcs_head(feats.features), pc_voxel_id, getattr(voxel_tensor, "point_csr", None))
 
     def loss_proposal_npcs(self, npcs_logits: torch.Tensor, gt_npcs: torch.Tensor, proposals: Instances) -> torch.Tensor:
         """symmetry-aware NPCS loss on points whose predicted part class is right and that carry a non-zero NPCS
@@ -270,21 +287,16 @@ class GAPartNet(LightningModule):
         self.symmetry_matrix_3 = self.symmetry_matrix_3.to(dev)
         sym = self.symmetry_indices[sem_preds]
 
+        # the three symmetry groups (sym < 3, == 3, == 4), each with its own table of candidate rotations.  The reference
+        # selects every group with four boolean masks (twelve host syncs); here each group's loss is evaluated on all
+        # points with the non-members masked out (grouping_utils.compute_npcs_loss_masked): same value, no sync
+        num_proposals = proposals.proposal_offsets.shape[0] - 1
         loss = 0
-        # the three symmetry groups (sym < 3, == 3, == 4), each with its own table of candidate rotations: points are
-        # bucketed with one stable sort and ONE host read of the three bucket sizes (the reference selects each group
-        # with four boolean masks = twelve host syncs); inside a bucket the points keep their order
-        group = (sym >= 3).long() + (sym >= 4).long()
-        order = torch.sort(group, stable=True)[1]
-        n0, n1, n2 = torch.bincount(group, minlength=3)[:3].tolist()
-        start = 0
-        for size, table, base in ((n0, self.symmetry_matrix_1, 0), (n1, self.symmetry_matrix_2, 3),
-                                  (n2, self.symmetry_matrix_3, 4)):
-            if size > 0:
-                members = order[start:start + size]
-                loss = loss + compute_npcs_loss(npcs_preds[members], gt_npcs[members], proposal_indices[members],
-                                                table[sym[members] - base])
-            start += size
+        for member, table, base in ((sym < 3, self.symmetry_matrix_1, 0), (sym == 3, self.symmetry_matrix_2, 3),
+                                    (sym == 4, self.symmetry_matrix_3, 4)):
+            rows = (sym - base).clamp(0, table.shape[0] - 1)
+            loss = loss + compute_npcs_loss_masked(npcs_preds, gt_npcs, proposal_indices, table[rows], member,
+                                                   num_proposals)
         return loss
 
     # ------------------------------------------------------------------------------------------ one step
@@ -331,7 +343,7 @@ class GAPartNet(LightningModule):
         if self.current_epoch >= self.start_clustering:
             voxel_tensor, pc_voxel_id, proposals = self.proposal_clustering_and_revoxelize(
                 pt_xyz=pt_xyz, batch_indices=data_batch.batch_indices, pt_features=pc_feature, sem_preds=sem_preds,
-                offset_preds=offsets_preds, instance_labels=instance_labels)
+                offset_preds=offsets_preds, instance_labels=instance_labels, batch_size=batch_size)
             if proposals is not None:
                 if sem_labels is not None:
                     proposals.sem_labels = sem_labels[proposals.valid_indices[proposals.sorted_indices]]

@@ -186,7 +186,7 @@ def _identity_rulebook(n: int, device):
     rows = torch.arange(n, dtype=torch.int32, device=device)
     tile_off = torch.clamp(torch.arange(n_tiles(n) + 1, dtype=torch.int32, device=device) * 32, max=n).reshape(1, -1)
     nbr = torch.cat([rows, torch.full((1,), -1, dtype=torch.int32, device=device)])
-    return Rulebook(rows, rows, tile_off.contiguous(), 1, n, n, torch.tensor(n, dtype=torch.int64, device=device), nbr)
+    return Rulebook(rows, rows, tile_off.contiguous(), 1, n, n, torch.full((), n, dtype=torch.int64, device=device), nbr)
 
 
 class SubMConv3d(_SparseConvBase):

@@ -86,9 +86,12 @@ class PointCloud:
             return torch.cat([getattr(pc, attr) for pc in point_clouds], dim=0)
 
         points = cat("points")
-        batch_indices = torch.repeat_interleave(
-            torch.arange(n_scenes, dtype=torch.int32, device=device),
-            torch.as_tensor(counts, dtype=torch.int64, device=device))
+        if len(set(counts)) == 1:  # equal-size scenes: no count tensor, so nothing to copy to / read back from the device
+            batch_indices = torch.arange(n_scenes, dtype=torch.int32, device=device).repeat_interleave(counts[0])
+        else:
+            batch_indices = torch.repeat_interleave(
+                torch.arange(n_scenes, dtype=torch.int32, device=device),
+                torch.as_tensor(counts, dtype=torch.int64, device=device), output_size=sum(counts))
 
         num_instances = num_points_per_instance = instance_sem_labels = None
         if first.num_instances is not None:
@@ -153,9 +156,10 @@ def voxelize_scenes(xyz: torch.Tensor, feats: torch.Tensor, counts: Sequence[int
     vs = torch.as_tensor(list(voxel_size), dtype=torch.float32, device=device)
     cells = (torch.floor((rmax - rmin) / vs).max(0)[0].to(torch.int64) + 2).tolist()  # host sync #1 (3 ints)
     out = backend.raw().voxelize(xyz, feats, offsets_dev, rmin, rmax, [float(v) for v in voxel_size], cells,
-                                 want_csr=True)
-    vf, vc, vseg, pid, order, starts = out
+                                 want_csr=True, want_stats=True)
+    vf, vc, vseg, pid, order, starts, stats = out
     indices = torch.cat([vseg[:, None], vc], dim=1).contiguous()
-    # (max coord + 1).clamp(min=128) per scene then max over scenes == max over the batch, clamped
-    spatial_shape = (vc.max(0)[0].to(torch.int64) + 1).clamp(min=128).tolist() if vc.shape[0] > 0 else [128] * 3
+    # (max coord + 1).clamp(min=128) per scene then max over scenes == max over the batch, clamped; the maxima come
+    # back with the voxel count in the kernel wrapper's single host read
+    spatial_shape = [max(int(m) + 1, 128) for m in stats["max_coord"]] if vc.shape[0] > 0 else [128] * 3
     return indices, vf, spatial_shape, pid, (order, starts)

@@ -23,13 +23,17 @@ def _t(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
-def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_size, grid_dims, want_csr=False):
+def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_size, grid_dims, want_csr=False,
+             want_stats=False):
     vf, vc, vs, pid = O.voxelize(_np(points), _np(feats), _np(seg_offsets), _np(seg_range_min), _np(seg_range_max),
                                  voxel_size, grid_dims)
     out = (_t(vf), _t(vc), _t(vs), _t(pid))
     if want_csr:
         order, starts = rows_csr(out[3], vf.shape[0])
         out = out + (order, starts)
+    if want_stats:
+        out = out + ({"max_coord": [int(v) for v in vc.max(0)] if vc.shape[0] else [0, 0, 0],
+                      "dropped": int((pid < 0).sum())},)
     return out
 
 

@@ -208,3 +208,58 @@ def test_validation_epoch_produces_ap_metrics():
                 "monitor_metrics/mean_mAP", "monitor_metrics/mean_AP@50", "monitor_metrics/mean_imou"):
         assert key in metrics and np.isfinite(metrics[key]), key
     assert model.validation_step_outputs == []
+
+
+def test_sync_free_loss_forms_equal_the_selecting_forms():
+    """the masked (no boolean-mask selection) forms used in the training step == the reference's selecting forms"""
+    from gapartnet_amd.network.losses import focal_loss
+    g = torch.Generator().manual_seed(0)
+    # NPCS loss: members selected vs masked
+    n, P, m = 400, 9, 4
+    pi = torch.sort(torch.randint(0, P, (n,), generator=g))[0]
+    pred = torch.rand((n, 3), generator=g, requires_grad=True)
+    gt = torch.rand((n, 3), generator=g) - 0.5
+    sym = torch.linalg.qr(torch.randn((n, m, 3, 3), generator=g))[0]
+    for member in (torch.rand((n,), generator=g) < 0.4, torch.zeros((n,), dtype=torch.bool), pi != 3):
+        masked = G.compute_npcs_loss_masked(pred, gt, pi, sym, member, P)
+        if member.any():
+            want = G.compute_npcs_loss(pred[member], gt[member], pi[member], sym[member])
+            assert torch.allclose(masked, want, rtol=1e-5, atol=1e-7)
+            ga = torch.autograd.grad(masked, pred)[0]
+            gb = torch.autograd.grad(want, pred)[0]
+            assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-8)
+        else:
+            assert masked.item() == 0.0
+    # focal loss with ignored rows
+    logits = torch.randn((50, 6), generator=g, requires_grad=True)
+    target = torch.randint(0, 6, (50,), generator=g)
+    target[::7] = -100
+    keep = target != -100
+    for reduction in ("mean", "sum"):
+        got = focal_loss(logits, target, gamma=2.0, reduction=reduction, ignore_index=-100)
+        want = focal_loss(logits[keep], target[keep], gamma=2.0, reduction=reduction, ignore_index=None)
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert focal_loss(logits, torch.full((50,), -100), ignore_index=-100).item() == 0.0
+
+
+def test_clustering_with_known_batch_size_equals_the_compacting_form():
+    """proposal_clustering_and_revoxelize(batch_size=B) (CSR over all scenes, no host read) gives the same proposals as
+    the reference's form (CSR over the scenes that still have points), also when a scene has no valid point"""
+    from oracle import torch_ops
+    model = make_model((0, 0), channels=[16, 32])
+    model.revoxelize_jitter = (torch.full((3,), 0.25), torch.full((3,), 0.75))
+    rng = np.random.default_rng(4)
+    pts, batch = synth.clustered_points(rng, 3, 600, n_clusters=4)
+    xyz = torch.from_numpy(pts)
+    bidx = torch.from_numpy(batch)
+    feats = torch.from_numpy(rng.normal(size=(xyz.shape[0], 16)).astype(np.float32))
+    sem = torch.from_numpy(rng.integers(1, 3, xyz.shape[0]).astype(np.int64))
+    sem[bidx == 1] = 0  # scene 1 contributes no valid point
+    off = torch.zeros_like(xyz)
+    with backend.using(torch_ops):
+        a = model.proposal_clustering_and_revoxelize(xyz, bidx, feats, sem, off, None)
+        b = model.proposal_clustering_and_revoxelize(xyz, bidx, feats, sem, off, None, batch_size=3)
+    assert torch.equal(a[0].indices, b[0].indices) and torch.equal(a[0].features, b[0].features)
+    assert torch.equal(a[1], b[1])
+    for f in ("sorted_indices", "proposal_offsets", "proposal_indices", "batch_indices", "sem_preds"):
+        assert torch.equal(getattr(a[2], f), getattr(b[2], f)), f

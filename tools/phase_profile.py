@@ -40,6 +40,47 @@ for p in PHASES:
     wrap(p)
 
 
+def wrap_fn(owner, attr, label):
+    fn = getattr(owner, attr)
+
+    def inner(*a, **k):
+        if SYNC[0]:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn(*a, **k)
+        if SYNC[0]:
+            torch.cuda.synchronize()
+        acc[label] += time.perf_counter() - t0
+        return out
+    setattr(owner, attr, inner)
+
+
+from gapartnet_amd import hip_ops
+from gapartnet_amd.network import net_exec
+SUB = ["  rulebook_subm3", "  rulebook_down", "  voxelize", "  net forward call", "  net backward call", "  ball_query", "  ccl"]
+wrap_fn(hip_ops, "rulebook_subm3", SUB[0])
+wrap_fn(hip_ops, "rulebook_down", SUB[1])
+wrap_fn(hip_ops, "voxelize", SUB[2])
+wrap_fn(hip_ops, "ball_query", SUB[5])
+wrap_fn(hip_ops, "ccl", SUB[6])
+_orig_call = net_exec._call
+
+
+def _timed_call(fn_name, *a, **k):
+    label = SUB[3] if fn_name == "gpn_net_forward" else SUB[4]
+    if SYNC[0]:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = _orig_call(fn_name, *a, **k)
+    if SYNC[0]:
+        torch.cuda.synchronize()
+    acc[label] += time.perf_counter() - t0
+    return out
+
+
+net_exec._call = _timed_call
+
+
 def step():
     t0 = time.perf_counter()
     opt.zero_grad(set_to_none=True)
@@ -74,5 +115,5 @@ for sync in (False, True):
     res[sync] = (dict(acc), (time.perf_counter() - t0) / 5 * 1e3)
 print(f"step: {res[False][1]:.2f} ms free-running, {res[True][1]:.2f} ms with a sync around every phase")
 print(f"{'phase':40s} {'host ms':>9s} {'synced ms':>10s}")
-for k in PHASES + ["TOTAL forward", "backward", "optimizer"]:
+for k in PHASES + ["TOTAL forward", "backward", "optimizer"] + SUB:
     print(f"{k:40s} {res[False][0].get(k, 0) / 5 * 1e3:9.2f} {res[True][0].get(k, 0) / 5 * 1e3:10.2f}")
