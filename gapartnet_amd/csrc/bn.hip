@@ -7,6 +7,10 @@
 // (sum g, sum g*xhat with the ReLU mask folded in) + finalize + one apply pass producing dx (and the residual's
 // gradient).  Compared with separate BatchNorm / add / ReLU kernels this removes three full read+write passes per
 // layer in forward and two in backward.  All reductions are fixed-order (deterministic).
+//
+// Small matrices (N <= kSmallRows: the deep levels of the U-Net, where a layer's kernels run at the
+// launch-latency floor) take a single-launch form instead: one workgroup per float4 column computes the statistics of
+// its four channels and applies them in a second sweep over the (L2-resident) column - one launch instead of three.
 #include "gpn_common.h"
 
 namespace {
@@ -165,6 +169,142 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ x, const float* __
   }
 }
 
+constexpr int kSmallRows = 1024;
+
+// Small-N layout: a workgroup owns CG adjacent float4 columns (CG = 4: 64 contiguous bytes per row) and 256 / CG row
+// lanes; thread t -> column t % CG, row lane t / CG.
+// fixed-order sums of eight values per thread over the threads that share a column, all eight in one tree (one pair
+// of barriers); results valid in every thread of that column
+template <int CG>
+__device__ __forceinline__ void column_sum8(double (&v)[8], double (*scratch)[CG][8] /* [4][CG][8] */) {
+#pragma unroll
+  for (int off = 32; off >= CG; off >>= 1) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] += __shfl_down(v[q], off, 64);
+  }
+  if ((threadIdx.x & 63) < CG) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) scratch[threadIdx.x >> 6][threadIdx.x & 63][q] = v[q];
+  }
+  __syncthreads();
+  const int cg = threadIdx.x % CG;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = (scratch[0][cg][q] + scratch[1][cg][q]) + (scratch[2][cg][q] + scratch[3][cg][q]);
+}
+
+// single-launch training forward for small N
+template <int CG>
+__global__ __launch_bounds__(kThreads) void bn_small_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ weight,
+    const float* __restrict__ bias, int N, int C4, float eps, float momentum, int relu, float* __restrict__ y,
+    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
+    float* __restrict__ running_var) {
+  __shared__ double scratch[4][CG][8];
+  constexpr int R = kThreads / CG;
+  const int c4 = blockIdx.x * CG + threadIdx.x % CG;
+  const int rl = threadIdx.x / CG;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int row = rl; row < N; row += R) {
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[(int64_t)row * C4 + c4];
+    s0 += xv;
+    s1 += xv * xv;
+  }
+  double sums[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sums[j] = (double)s0[j], sums[4 + j] = (double)s1[j];
+  column_sum8<CG>(sums, scratch);
+  f32x4 mu, is;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double s = sums[j], ss = sums[4 + j];
+    const double m = s / (double)N;
+    double var = ss / (double)N - m * m;
+    if (var < 0.0) var = 0.0;
+    mu[j] = (float)m;
+    is[j] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rl == 0) {
+      const int c = c4 * 4 + j;
+      mean[c] = mu[j];
+      invstd[c] = is[j];
+      if (running_mean) {
+        const double unbiased = N > 1 ? var * ((double)N / (double)(N - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+      }
+    }
+  }
+  const f32x4 w = reinterpret_cast<const f32x4*>(weight)[c4], b = reinterpret_cast<const f32x4*>(bias)[c4];
+#pragma unroll 8
+  for (int row = rl; row < N; row += R) {
+    const int64_t t = (int64_t)row * C4 + c4;
+    f32x4 v = (reinterpret_cast<const f32x4*>(x)[t] - mu) * is * w + b;
+    if (res) v += reinterpret_cast<const f32x4*>(res)[t];
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(y)[t] = v;
+  }
+}
+
+// single-launch backward for small N (same layout): dweight / dbias, then dx (and dres)
+template <int CG>
+__global__ __launch_bounds__(kThreads) void bn_small_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+    const float* __restrict__ weight, const float* __restrict__ mean, const float* __restrict__ invstd, int N, int C4,
+    int relu, int training, float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dweight,
+    float* __restrict__ dbias) {
+  __shared__ double scratch[4][CG][8];
+  constexpr int R = kThreads / CG;
+  const int c4 = blockIdx.x * CG + threadIdx.x % CG;
+  const int rl = threadIdx.x / CG;
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int row = rl; row < N; row += R) {
+    const int64_t t = (int64_t)row * C4 + c4;
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[t];
+    if (relu) {
+      const f32x4 yv = reinterpret_cast<const f32x4*>(y)[t];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+    }
+    s0 += g;
+    s1 += g * ((reinterpret_cast<const f32x4*>(x)[t] - mu) * is);
+  }
+  double sums[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sums[j] = (double)s0[j], sums[4 + j] = (double)s1[j];
+  column_sum8<CG>(sums, scratch);
+  f32x4 db, dw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) db[j] = (float)sums[j], dw[j] = (float)sums[4 + j];
+  if (rl == 0) {
+    reinterpret_cast<f32x4*>(dbias)[c4] = db;
+    reinterpret_cast<f32x4*>(dweight)[c4] = dw;
+  }
+  const f32x4 w = reinterpret_cast<const f32x4*>(weight)[c4];
+  const float inv_n = 1.0f / (float)N;
+#pragma unroll 8
+  for (int row = rl; row < N; row += R) {
+    const int64_t t = (int64_t)row * C4 + c4;
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[t];
+    if (relu) {
+      const f32x4 yv = reinterpret_cast<const f32x4*>(y)[t];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+    }
+    if (dres) reinterpret_cast<f32x4*>(dres)[t] = g;
+    f32x4 v = g;
+    if (training) {
+      const f32x4 xhat = (reinterpret_cast<const f32x4*>(x)[t] - mu) * is;
+      v = g - db * inv_n - xhat * (dw * inv_n);
+    }
+    reinterpret_cast<f32x4*>(dx)[t] = v * is * w;
+  }
+}
+
 int reduce_blocks(int64_t N, int C4) {
   const int R = kThreads / C4;
   int64_t b = gpn::cdiv(N, (int64_t)R * 8);
@@ -197,6 +337,16 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
   GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
   GPN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   const int C4 = C / 4;
+  if (N <= kSmallRows) {
+    if (C4 % 4 == 0)
+      hipLaunchKernelGGL(bn_small_fwd_kernel<4>, dim3(C4 / 4), dim3(kThreads), 0, stream, x, res, weight, bias, (int)N,
+                         C4, eps, momentum, relu, y, mean, invstd, running_mean, running_var);
+    else
+      hipLaunchKernelGGL(bn_small_fwd_kernel<1>, dim3(C4), dim3(kThreads), 0, stream, x, res, weight, bias, (int)N, C4,
+                         eps, momentum, relu, y, mean, invstd, running_mean, running_var);
+    GPN_CHECK_LAUNCH();
+    return GPN_OK;
+  }
   const int blocks = reduce_blocks(N, C4);
   double* partial = static_cast<double*>(ws);
   hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(blocks), dim3(kThreads), 0, stream, x, nullptr, nullptr, nullptr,
@@ -236,6 +386,16 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
   GPN_CHECK_ARG(x && dy && weight && mean && invstd && dx && dweight && dbias && ws && (y || !relu));
   GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
   const int C4 = C / 4;
+  if (N <= kSmallRows) {
+    if (C4 % 4 == 0)
+      hipLaunchKernelGGL(bn_small_bwd_kernel<4>, dim3(C4 / 4), dim3(kThreads), 0, stream, x, y, dy, weight, mean, invstd,
+                         (int)N, C4, relu, training, dx, dres, dweight, dbias);
+    else
+      hipLaunchKernelGGL(bn_small_bwd_kernel<1>, dim3(C4), dim3(kThreads), 0, stream, x, y, dy, weight, mean, invstd,
+                         (int)N, C4, relu, training, dx, dres, dweight, dbias);
+    GPN_CHECK_LAUNCH();
+    return GPN_OK;
+  }
   const int blocks = reduce_blocks(N, C4);
   double* partial = static_cast<double*>(ws);
   hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(blocks), dim3(kThreads), 0, stream, x, y, dy, mean, invstd, N, C4, relu,

@@ -4,12 +4,13 @@ import sys
 from collections import defaultdict
 
 path, out = sys.argv[1], sys.argv[2]
+words = sys.argv[3].split(",") if len(sys.argv) > 3 else ["spconv", "wgrad"]  # kernel-name filter
 agg = defaultdict(lambda: [0, 0.0])
 with open(path) as fh:
     rd = csv.DictReader(fh)
     for r in rd:
         name = r["Kernel_Name"]
-        if "spconv" not in name and "wgrad" not in name:
+        if not any(w in name for w in words):
             continue
         short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         key = (short, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""),
