@@ -21,6 +21,8 @@
 // K-permutation is baked into the packed weights.  The fp32 MFMA is exact (== an fmaf chain) and the summation order
 // is fixed (tap-major), so results are deterministic.  Small layers split their taps over grid.z into partial outputs
 // that a fixed-order kernel sums.
+#include <algorithm>
+
 #include "gpn_common.h"
 
 namespace {
@@ -174,6 +176,140 @@ __global__ void spconv_fwd_kernel(const float* __restrict__ in, const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent tile-streaming variant for the large levels (K = 27 or 8, >= 1024 tiles, no tap split).
+// The lock-step kernel above pays a workgroup start-up (index column + slab round trips before the first MFMA) once
+// per 16-row tile and one barrier per stage, and its 1024-thread workgroups leave only two slots per CU to hide that
+// in: on the two largest levels it ran at 3.5-4.6x its MFMA time.  Here a workgroup
+// (8 waves, one or two per CU) is persistent: it stages the slab of an input block once and every wave streams
+// through many tiles with the rings carried ACROSS tile boundaries - while tile i is contracted, the index column
+// of tile i+1 refills the slots tile i has consumed and its first gathers are already in flight, so a wave never
+// restarts cold.  For cin > 16 the input blocks are the outer loop (slab staged CB times per workgroup, no barrier
+// inside a pass); block 0 writes the partial output rows and later blocks add to them (fixed order: deterministic).
+// Tiles are dealt so that each XCD owns a contiguous range of rows and neighbouring tiles run at the same time on
+// the same XCD (they gather largely the same source rows: L2 hits).
+template <int NTW, int KT, int D>
+__global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __restrict__ in,
+                                                                const float* __restrict__ packed,
+                                                                const int32_t* __restrict__ nbr, int64_t n_dst, int cin,
+                                                                int nt_total, int64_t tiles, float* __restrict__ out) {
+  static_assert(KT % D == 0, "ring slots are compile-time: the gather distance must divide the tap count");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* slab = reinterpret_cast<f32x4*>(smem);  // [KT][NTW][64 lanes]
+  constexpr int WPB = 8;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+
+  // tile ownership: XCD x (workgroup ids go round-robin over the 8 XCDs) owns tiles [tile_lo, tile_hi); inside it
+  // wave slot j takes tiles tile_lo + j, + waves_per_xcd, ...
+  const int xcd = blockIdx.x & 7;
+  const int waves_per_xcd = (gridDim.x >> 3) * WPB;
+  const int slot = (blockIdx.x >> 3) * WPB + wave;
+  const int64_t tiles_per_xcd = (tiles + 7) >> 3;
+  const int64_t tile_lo = xcd * tiles_per_xcd;
+  const int64_t tile_hi = tile_lo + tiles_per_xcd < tiles ? tile_lo + tiles_per_xcd : tiles;
+  const int64_t first = tile_lo + slot;
+  const int m = first < tile_hi ? (int)((tile_hi - first + waves_per_xcd - 1) / waves_per_xcd) : 0;
+
+  const int nt0 = blockIdx.y * NTW;
+  const int ntw = (nt_total - nt0 < NTW) ? (nt_total - nt0) : NTW;
+  const int cout = nt_total * 16;
+  const int CB = cin >> 4;
+  const f32x4* __restrict__ pw = reinterpret_cast<const f32x4*>(packed);
+
+  // addresses are (uniform 64-bit base) + (32-bit per-lane element offset): one VGPR per pending load instead of two
+  // and no per-lane 64-bit arithmetic (the host guarantees n * channels < 2^30 elements for this kernel)
+  auto clamp_row = [&](int64_t tile) -> uint32_t {
+    const int64_t r = tile * 16 + i16;
+    return (uint32_t)(r < n_dst ? r : n_dst - 1);
+  };
+  auto load_a = [&](int32_t idx, const float* in_cb) -> f32x4 {
+    const uint32_t s = idx < 0 ? 0u : (uint32_t)idx;  // absent neighbours gather row 0, zeroed before the MFMA
+    return *reinterpret_cast<const f32x4*>(in_cb + (s * (uint32_t)cin + 4u * (uint32_t)g));
+  };
+
+  for (int cb = 0; cb < CB; ++cb) {
+    if (cb > 0) __syncthreads();  // every wave has finished its pass over the previous block's slab
+    for (int q = tid; q < KT * NTW * 64; q += WPB * 64) {
+      const int t = q / (NTW * 64);
+      const int rem = q - t * (NTW * 64);
+      int nt = rem >> 6;
+      nt = nt < ntw ? nt : 0;
+      slab[q] = pw[((int64_t)(t * CB + cb) * nt_total + nt0 + nt) * 64 + (rem & 63)];
+    }
+    // rings of the wave's first tile (their round trip overlaps the slab's)
+    int32_t ireg[KT];
+    f32x4 areg[D];
+    const float* in_cb = in + cb * 16;
+    if (m > 0) {
+      const uint32_t rc = clamp_row(first);
+#pragma unroll
+      for (int u = 0; u < KT; ++u) ireg[u] = (nbr + (int64_t)u * n_dst)[rc];
+#pragma unroll
+      for (int u = 0; u < D; ++u) areg[u] = load_a(ireg[u], in_cb);
+    }
+    __syncthreads();
+
+    for (int i = 0; i < m; ++i) {
+      const int64_t cur = first + (int64_t)i * waves_per_xcd;
+      const int64_t nxt = i + 1 < m ? cur + waves_per_xcd : cur;  // last tile: refills become harmless duplicates
+      const int64_t row0 = cur * 16;
+      const bool row_ok = row0 + i16 < n_dst;
+      const uint32_t rc_next = clamp_row(nxt);
+
+      f32x4 acc[NTW], prev[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}, prev[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (cb > 0) {  // partial sums of the earlier input blocks (issued now, consumed at the end of the tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + 4 * g + r;
+          const uint32_t rr = (uint32_t)(row < n_dst ? row : n_dst - 1);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            prev[nt][r] = out[rr * (uint32_t)cout + (uint32_t)((nt0 + (nt < ntw ? nt : 0)) * 16 + i16)];
+        }
+      }
+
+#pragma unroll
+      for (int u = 0; u < KT; ++u) {
+        const int32_t idx = row_ok ? ireg[u] : -1;
+        if (__builtin_amdgcn_ballot_w64(idx >= 0) != 0) {
+          f32x4 a = areg[u % D];
+          if (idx < 0) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const f32x4* sb = slab + u * (NTW * 64) + lane;
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            if (nt < ntw) {
+              const f32x4 bf = sb[nt * 64];
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf.x, acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf.y, acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf.z, acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf.w, acc[nt], 0, 0, 0);
+            }
+          }
+        }
+        asm volatile("" ::: "memory");  // keep the unrolled taps in program order
+        // slot u now belongs to the next tile; the gather D taps ahead uses this tile's column while u + D < KT and
+        // the next tile's (refilled KT - D taps ago) after that - the same expression either way
+        ireg[u] = (nbr + (int64_t)u * n_dst)[rc_next];
+        areg[u % D] = load_a(ireg[(u + D) % KT], in_cb);
+      }
+
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + 4 * g + r;
+        if (row < n_dst) {
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            if (nt < ntw) out[(uint32_t)row * (uint32_t)cout + (uint32_t)((nt0 + nt) * 16 + i16)] = acc[nt][r] + prev[nt][r];
+        }
+      }
+    }
+  }
+}
+
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int splits, int64_t elems4,
                                        float* __restrict__ out) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,10 +388,58 @@ int dispatch_cw(const FwdPlan& p, const float* in, const float* packed, const in
   }
 }
 
+// the persistent tile-streaming kernel serves the large levels: K = 27 / 8 and enough tiles that no tap split is needed
+struct StreamPlan {
+  bool use;
+  int ntw, groups;
+};
+
+StreamPlan plan_stream(int K, int64_t n_dst, int cin, int cout) {
+  const int nt = cout / 16;
+  StreamPlan p;
+  p.groups = (int)gpn::cdiv(nt, 4);  // up to 4 output-column tiles per workgroup (slab = K x ntw KiB of LDS)
+  p.ntw = (int)gpn::cdiv(nt, p.groups);
+  p.use = (K == 27 || K == 8) && gpn::cdiv(n_dst, 16) >= 1024 &&
+          n_dst * (int64_t)std::max(cin, cout) < ((int64_t)1 << 30);  // the kernel uses 32-bit element offsets
+  return p;
+}
+
+template <int NTW, int KT, int D>
+int launch_stream(int groups, const float* in, const float* packed, const int32_t* nbr, int64_t n_dst, int cin,
+                  int nt_total, float* out, hipStream_t stream) {
+  constexpr size_t lds = (size_t)KT * NTW * 64 * 16;
+  // persistent grid = (workgroups that are resident at once) x CUs: asked from the runtime once per instantiation
+  static int wgs = 0;
+  if (wgs == 0) {
+    GPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_fwd_stream_kernel<NTW, KT, D>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0, dev = 0, cus = 0;
+    GPN_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_stream_kernel<NTW, KT, D>, 512, lds));
+    GPN_CHECK_HIP(hipGetDevice(&dev));
+    GPN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    wgs = (cus * per_cu + 7) / 8 * 8;
+  }
+  const dim3 grid((unsigned)wgs, (unsigned)groups, 1);
+  hipLaunchKernelGGL((spconv_fwd_stream_kernel<NTW, KT, D>), grid, dim3(512), lds, stream, in, packed, nbr, n_dst, cin,
+                     nt_total, gpn::cdiv(n_dst, 16), out);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+template <int NTW>
+int dispatch_stream(int groups, const float* in, const float* packed, const int32_t* nbr, int K, int64_t n_dst,
+                    int cin, int nt_total, float* out, hipStream_t stream) {
+  if (K == 27) return launch_stream<NTW, 27, 9>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+  return launch_stream<NTW, 8, 8>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+}
+
 }  // namespace
 
 extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout) {
   if (n_dst <= 0 || cin < 16 || cout < 16) return 0;
+  if (plan_stream(K, n_dst, cin, cout).use) return 0;
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   return p.splits > 1 ? gpn::align_up((size_t)p.splits * n_dst * cout * sizeof(float)) : 0;
 }
@@ -268,6 +452,16 @@ extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int3
   if (n_dst == 0) return GPN_OK;
   GPN_CHECK_ARG(in && packed_w && nbr && out);
   const int nt = cout / 16;
+  const StreamPlan sp = plan_stream(K, n_dst, cin, cout);
+  if (sp.use) {
+    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
+    switch (sp.ntw) {
+      case 1: return dispatch_stream<1>(sp.groups, in, packed_w, nbr, K, n_dst, cin, nt, out, stream);
+      case 2: return dispatch_stream<2>(sp.groups, in, packed_w, nbr, K, n_dst, cin, nt, out, stream);
+      case 3: return dispatch_stream<3>(sp.groups, in, packed_w, nbr, K, n_dst, cin, nt, out, stream);
+      default: return dispatch_stream<4>(sp.groups, in, packed_w, nbr, K, n_dst, cin, nt, out, stream);
+    }
+  }
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   float* target = out;
   if (p.splits > 1) {
