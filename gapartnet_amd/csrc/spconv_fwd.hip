@@ -218,15 +218,23 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
   const int CB = cin >> 4;
   const f32x4* __restrict__ pw = reinterpret_cast<const f32x4*>(packed);
 
-  // addresses are (uniform 64-bit base) + (32-bit per-lane element offset): one VGPR per pending load instead of two
-  // and no per-lane 64-bit arithmetic (the host guarantees n * channels < 2^30 elements for this kernel)
+  // Gathers and index reads are buffer loads: wave-uniform descriptor + 32-bit per-lane byte offset (one VGPR per
+  // pending load, no per-lane 64-bit arithmetic), and an absent neighbour becomes an out-of-range offset, which the
+  // hardware answers with zeros WITHOUT touching memory.  (The host guarantees every byte offset < 2^31.)
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t nbr_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(nbr), 0, 0x7fffffff, 0x00020000);
+  const uint32_t col_bytes = (uint32_t)n_dst * 4u;  // one tap's column of the neighbour table
   auto clamp_row = [&](int64_t tile) -> uint32_t {
     const int64_t r = tile * 16 + i16;
     return (uint32_t)(r < n_dst ? r : n_dst - 1);
   };
-  auto load_a = [&](int32_t idx, const float* in_cb) -> f32x4 {
-    const uint32_t s = idx < 0 ? 0u : (uint32_t)idx;  // absent neighbours gather row 0, zeroed before the MFMA
-    return *reinterpret_cast<const f32x4*>(in_cb + (s * (uint32_t)cin + 4u * (uint32_t)g));
+  auto load_idx = [&](int u, uint32_t row) -> int32_t {
+    return __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(row * 4u), (int)(u * col_bytes), 0));
+  };
+  auto load_a = [&](int32_t idx, int cb) -> f32x4 {
+    const uint32_t off = idx < 0 ? 0x80000000u : ((uint32_t)idx * (uint32_t)cin + 4u * (uint32_t)g) * 4u;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, cb * 64, 0));
   };
 
   for (int cb = 0; cb < CB; ++cb) {
@@ -241,13 +249,12 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
     // rings of the wave's first tile (their round trip overlaps the slab's)
     int32_t ireg[KT];
     f32x4 areg[D];
-    const float* in_cb = in + cb * 16;
     if (m > 0) {
       const uint32_t rc = clamp_row(first);
 #pragma unroll
-      for (int u = 0; u < KT; ++u) ireg[u] = (nbr + (int64_t)u * n_dst)[rc];
+      for (int u = 0; u < KT; ++u) ireg[u] = load_idx(u, rc);
 #pragma unroll
-      for (int u = 0; u < D; ++u) areg[u] = load_a(ireg[u], in_cb);
+      for (int u = 0; u < D; ++u) areg[u] = load_a(ireg[u], cb);
     }
     __syncthreads();
 
@@ -259,6 +266,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
       const uint32_t rc_next = clamp_row(nxt);
 
       f32x4 acc[NTW], prev[NTW];
+      f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};  // second accumulator of the NTW == 1 case
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}, prev[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (cb > 0) {  // partial sums of the earlier input blocks (issued now, consumed at the end of the tile)
@@ -277,24 +285,35 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
         const int32_t idx = row_ok ? ireg[u] : -1;
         if (__builtin_amdgcn_ballot_w64(idx >= 0) != 0) {
           f32x4 a = areg[u % D];
-          if (idx < 0) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (!row_ok) a = (f32x4){0.f, 0.f, 0.f, 0.f};  // rows past the end (absent neighbours already read as zeros)
           const f32x4* sb = slab + u * (NTW * 64) + lane;
+          f32x4 bf[NTW];
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            if (nt < ntw) {
-              const f32x4 bf = sb[nt * 64];
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf.x, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf.y, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf.z, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf.w, acc[nt], 0, 0, 0);
+          for (int nt = 0; nt < NTW; ++nt) bf[nt] = sb[nt * 64];
+          // the four k-steps of a tap on one accumulator are a dependent chain (40-cycle latency vs 32-cycle issue):
+          // interleave the column tiles, and with a single column tile alternate two accumulators
+          if (NTW == 1) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[0].x, acc[0], 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[0].y, acc2, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[0].z, acc[0], 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[0].w, acc2, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+              if (nt < ntw) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[nt].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[nt].y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[nt].z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[nt].w, acc[nt], 0, 0, 0);
+              }
             }
           }
         }
         asm volatile("" ::: "memory");  // keep the unrolled taps in program order
         // slot u now belongs to the next tile; the gather D taps ahead uses this tile's column while u + D < KT and
         // the next tile's (refilled KT - D taps ago) after that - the same expression either way
-        ireg[u] = (nbr + (int64_t)u * n_dst)[rc_next];
-        areg[u % D] = load_a(ireg[(u + D) % KT], in_cb);
+        ireg[u] = load_idx(u, rc_next);
+        areg[u % D] = load_a(ireg[(u + D) % KT], cb);
       }
 
 #pragma unroll
@@ -303,7 +322,9 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
         if (row < n_dst) {
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt)
-            if (nt < ntw) out[(uint32_t)row * (uint32_t)cout + (uint32_t)((nt0 + nt) * 16 + i16)] = acc[nt][r] + prev[nt][r];
+            if (nt < ntw)
+              out[(uint32_t)row * (uint32_t)cout + (uint32_t)((nt0 + nt) * 16 + i16)] =
+                  (NTW == 1 ? acc[nt][r] + acc2[r] : acc[nt][r]) + prev[nt][r];
         }
       }
     }
@@ -399,8 +420,10 @@ StreamPlan plan_stream(int K, int64_t n_dst, int cin, int cout) {
   StreamPlan p;
   p.groups = (int)gpn::cdiv(nt, 4);  // up to 4 output-column tiles per workgroup (slab = K x ntw KiB of LDS)
   p.ntw = (int)gpn::cdiv(nt, p.groups);
+  // the kernel addresses with 32-bit byte offsets (< 2^31): source rows (at most 8 n_dst of them, for a stride-2 conv),
+  // output rows and the neighbour table must fit
   p.use = (K == 27 || K == 8) && gpn::cdiv(n_dst, 16) >= 1024 &&
-          n_dst * (int64_t)std::max(cin, cout) < ((int64_t)1 << 30);  // the kernel uses 32-bit element offsets
+          n_dst * (int64_t)8 * std::max(cin, cout) * 4 < ((int64_t)1 << 31) && (int64_t)K * n_dst * 4 < ((int64_t)1 << 31);
   return p;
 }
 

@@ -42,21 +42,20 @@ def compute_npcs_loss_masked(npcs_preds: torch.Tensor, gt_npcs: torch.Tensor, pr
     """``compute_npcs_loss`` restricted to the points where ``member`` is set, WITHOUT selecting them: same value as
     compute_npcs_loss(npcs_preds[member], gt_npcs[member], proposal_indices[member], symmetry_matrix[member]) (0 when
     no point is a member), but no data-dependent shapes and therefore no host sync.  ``proposal_indices`` must be
-    non-decreasing with values in [0, num_proposals); per-proposal sums are differences of a float64 running sum
-    (deterministic, differentiable)."""
+    non-decreasing with values in [0, num_proposals)."""
     targets = torch.matmul(gt_npcs[:, None, None, :], symmetry_matrix).squeeze(2)          # [n, m, 3]
     dist2 = ((npcs_preds[:, None, :] - targets - 0.5) ** 2).sum(dim=-1)                  # [n, m]
     cost = torch.where(dist2 <= 0.01, 5 * dist2, torch.sqrt(dist2) - 0.05)
     cost = torch.where(member[:, None], cost, torch.zeros_like(cost))
-    n, m = cost.shape
-    running = torch.cat([cost.new_zeros((1, m), dtype=torch.float64), cost.double().cumsum(0)], dim=0)
-    members = torch.cat([member.new_zeros((1,), dtype=torch.int64), member.long().cumsum(0)], dim=0)
+    # per-proposal sums over the (contiguous) runs of proposal_indices: ordered segment sums (deterministic,
+    # differentiable); `unsafe=True` skips the lengths-vs-size validation, which would be a host sync
     edges = torch.searchsorted(proposal_indices.contiguous(),
                                torch.arange(num_proposals + 1, dtype=proposal_indices.dtype, device=cost.device))
-    seg_sum = running[edges[1:]] - running[edges[:-1]]                                    # [P, m]
-    seg_cnt = members[edges[1:]] - members[edges[:-1]]                                    # [P]
+    lengths = edges[1:] - edges[:-1]
+    seg_sum = torch.segment_reduce(cost, "sum", lengths=lengths, unsafe=True)              # [P, m]
+    seg_cnt = torch.segment_reduce(member.to(cost.dtype), "sum", lengths=lengths, unsafe=True)  # [P]
     has = seg_cnt > 0
-    per_proposal = (seg_sum / seg_cnt.clamp(min=1)[:, None]).to(cost.dtype)
+    per_proposal = seg_sum / seg_cnt.clamp(min=1)[:, None]
     best = per_proposal.min(dim=-1)[0]
     total = torch.where(has, best, torch.zeros_like(best)).sum()
     return total / has.sum().clamp(min=1)
