@@ -58,6 +58,17 @@ def build_step(model, optimizer, world, device):
     return step
 
 
+def measured_traffic():
+    """HBM bytes per launch of the conv kernel family from the committed PMC passes (profiles/traffic.json, produced by
+    tools/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this command); None if absent"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            return float(json.load(fh)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def roofline_from_profile(device):
     """Σ algorithmic work / Σ hipEvent time per kernel family over one instrumented step."""
     import ctypes
@@ -155,7 +166,7 @@ def main():
         if dom["ms"] > 0 and dom["launches"] > 0:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             roof = dict(bound="mfma", kernel=dom["kernel"], achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None, launches=dom["launches"],
+                        frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=measured_traffic(), launches=dom["launches"],
                         avg_launch_us=dom["ms"] * 1e3 / dom["launches"],
                         algorithmic_gbs=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
                         hbm_frac=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
