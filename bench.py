@@ -132,15 +132,19 @@ def main():
             for j in range(2)]
     model.train()
 
+    # batches are prepared (voxelised, rulebooks built) one step ahead on a second stream: the loader side of the path
+    from gapartnet_amd.dataset.prefetch import DevicePrefetcher
+    total_steps = args.warmup + args.steps + 1
+    feed = iter(DevicePrefetcher((pool[i % 2] for i in range(total_steps)), model, device))
     for i in range(args.warmup):
-        step(pool[i % 2], i)
+        step(next(feed), i)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(pool[i % 2], i)
+        step(next(feed), i)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -157,7 +161,7 @@ def main():
         lib = _C.lib()
         lib.gpn_prof_reset(); lib.gpn_prof_enable(1)
         GF.CONV_LOG = []
-        step(pool[0], 0)
+        step(next(feed), 0)
         torch.cuda.synchronize(device)
         lib.gpn_prof_enable(0)
         prof = roofline_from_profile(device)
@@ -174,7 +178,7 @@ def main():
                                                        tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0)
                                      for v in prof.values()})
     elif world > 1:
-        step(pool[0], 0)  # keep ranks in lock-step through the extra DDP step
+        step(next(feed), 0)  # keep ranks in lock-step through the extra DDP step
     if world > 1:
         dist.barrier()
 

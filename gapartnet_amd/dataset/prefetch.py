@@ -1,0 +1,84 @@
+"""On-device batch preparation one step ahead (SURVEY.md §8f "next": loader side of the hot path).
+
+The reference voxelises every scene in CPU DataLoader workers (dataset/gapartnet.py:179-205) and builds the spconv
+rulebooks inside the forward pass.  Here both run on the GPU, and this iterator runs them for batch i+1 on a SECOND
+stream while the GPU is still busy with the backward pass of batch i-1 / forward of batch i: the host reads that batch
+preparation needs (voxel count, grid extent, per-level row counts) then wait only for that stream's own small kernels
+instead of draining the training stream, which removes the longest host stall of the step.
+
+Yields ``PointCloudBatch`` objects (what ``GAPartNet.training_step`` accepts directly) whose ``voxel_tensor`` already
+carries the rulebook pyramid of the backbone in its ``indice_dict``.
+"""
+from dataclasses import fields, is_dataclass
+from typing import Iterable, Optional
+
+import torch
+
+from ..structure.point_cloud import PointCloud, PointCloudBatch
+
+
+def _tensors(obj, seen):
+    """every tensor reachable from a prepared batch (dataclasses, containers, sparse tensors, rulebooks)"""
+    if obj is None or id(obj) in seen:
+        return
+    if isinstance(obj, torch.Tensor):
+        seen.add(id(obj))
+        yield obj
+        return
+    if isinstance(obj, (str, bytes, int, float, bool)):
+        return
+    seen.add(id(obj))
+    if isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors(v, seen)
+    elif is_dataclass(obj):
+        for f in fields(obj):
+            yield from _tensors(getattr(obj, f.name), seen)
+        yield from _tensors(getattr(obj, "__dict__", None), seen)
+    elif hasattr(obj, "__dict__"):
+        yield from _tensors(vars(obj), seen)
+
+
+class DevicePrefetcher:
+    """``for batch in DevicePrefetcher(loader, model, device)``: batches come out collated, voxelised and with the
+    backbone's rulebooks built, each prepared on a side stream while the previous one trains."""
+
+    def __init__(self, batches: Iterable, model, device: torch.device):
+        assert device.type == "cuda", "batch preparation runs on the GPU (the product has no CPU path)"
+        self.batches, self.model, self.device = batches, model, device
+        self.stream = torch.cuda.Stream(device=device)
+
+    def _prepare(self, raw):
+        if raw is None:
+            return None
+        with torch.cuda.stream(self.stream):
+            if isinstance(raw, PointCloudBatch):
+                batch = raw
+            else:
+                pcs = [pc.to(self.device) if hasattr(pc, "to") else pc for pc in raw]
+                batch = PointCloud.collate(pcs, voxel_size=self.model.voxel_size)
+            backbone = getattr(self.model, "backbone", None)
+            if backbone is not None and getattr(backbone, "use_native_executor", False) and batch.voxel_tensor is not None:
+                from ..network import net_exec
+                prog = net_exec.program_for(backbone)
+                if prog is not None and batch.voxel_tensor.features.shape[0] > 0:
+                    prog.rulebooks(batch.voxel_tensor)  # cached in voxel_tensor.indice_dict under the modules' keys
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return batch, done
+
+    def __iter__(self):
+        it = iter(self.batches)
+        ahead = self._prepare(next(it, None))
+        while ahead is not None:
+            batch, done = ahead
+            consumer = torch.cuda.current_stream(self.device)
+            consumer.wait_event(done)
+            for t in _tensors(batch, set()):
+                if t.is_cuda:
+                    t.record_stream(consumer)  # allocated on the side stream, used (and freed) on the training stream
+            ahead = self._prepare(next(it, None))
+            yield batch

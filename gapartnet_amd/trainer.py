@@ -143,7 +143,11 @@ class Trainer:
                 sampler.set_epoch(epoch)
             model.train()
             t0 = time.time()
-            for batch_idx, batch in enumerate(train_dataloaders):
+            feed = train_dataloaders
+            if self.device.type == "cuda" and hasattr(model, "voxel_size"):
+                from .dataset.prefetch import DevicePrefetcher
+                feed = DevicePrefetcher(train_dataloaders, model, self.device)  # batch i+1 prepared while batch i trains
+            for batch_idx, batch in enumerate(feed):
                 if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
                     break
                 batch = move_batch(batch, self.device)
