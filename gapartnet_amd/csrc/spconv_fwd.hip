@@ -188,14 +188,14 @@ __global__ void spconv_fwd_kernel(const float* __restrict__ in, const float* __r
 // inside a pass); block 0 writes the partial output rows and later blocks add to them (fixed order: deterministic).
 // Tiles are dealt so that each XCD owns a contiguous range of rows and neighbouring tiles run at the same time on
 // the same XCD (they gather largely the same source rows: L2 hits).
-template <int NTW, int KT, int D>
+template <int NTW, int KT, int D, int CW>  // CW = 16-channel input blocks contracted per pass (slab = KT x CW x NTW KiB)
 __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __restrict__ in,
                                                                 const float* __restrict__ packed,
                                                                 const int32_t* __restrict__ nbr, int64_t n_dst, int cin,
                                                                 int nt_total, int64_t tiles, float* __restrict__ out) {
   static_assert(KT % D == 0, "ring slots are compile-time: the gather distance must divide the tap count");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x4* slab = reinterpret_cast<f32x4*>(smem);  // [KT][NTW][64 lanes]
+  f32x4* slab = reinterpret_cast<f32x4*>(smem);  // [KT][CW][NTW][64 lanes]
   constexpr int WPB = 8;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -232,29 +232,32 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
   auto load_idx = [&](int u, uint32_t row) -> int32_t {
     return __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(row * 4u), (int)(u * col_bytes), 0));
   };
-  auto load_a = [&](int32_t idx, int cb) -> f32x4 {
+  auto load_a = [&](int32_t idx, int cb, f32x4 (&a)[CW]) {  // the CW 64-byte pieces of one gathered row
     const uint32_t off = idx < 0 ? 0x80000000u : ((uint32_t)idx * (uint32_t)cin + 4u * (uint32_t)g) * 4u;
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, cb * 64, 0));
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+      a[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, (cb + c) * 64, 0));
   };
 
-  for (int cb = 0; cb < CB; ++cb) {
-    if (cb > 0) __syncthreads();  // every wave has finished its pass over the previous block's slab
-    for (int q = tid; q < KT * NTW * 64; q += WPB * 64) {
-      const int t = q / (NTW * 64);
-      const int rem = q - t * (NTW * 64);
-      int nt = rem >> 6;
+  for (int cb = 0; cb < CB; cb += CW) {  // CW divides CB (host)
+    if (cb > 0) __syncthreads();  // every wave has finished its pass over the previous blocks' slab
+    for (int q = tid; q < KT * CW * NTW * 64; q += WPB * 64) {
+      const int t = q / (CW * NTW * 64);
+      const int rem = q - t * (CW * NTW * 64);
+      const int c = rem / (NTW * 64);
+      int nt = (rem - c * (NTW * 64)) >> 6;
       nt = nt < ntw ? nt : 0;
-      slab[q] = pw[((int64_t)(t * CB + cb) * nt_total + nt0 + nt) * 64 + (rem & 63)];
+      slab[q] = pw[((int64_t)(t * CB + cb + c) * nt_total + nt0 + nt) * 64 + (rem & 63)];
     }
     // rings of the wave's first tile (their round trip overlaps the slab's)
     int32_t ireg[KT];
-    f32x4 areg[D];
+    f32x4 areg[D][CW];
     if (m > 0) {
       const uint32_t rc = clamp_row(first);
 #pragma unroll
       for (int u = 0; u < KT; ++u) ireg[u] = load_idx(u, rc);
 #pragma unroll
-      for (int u = 0; u < D; ++u) areg[u] = load_a(ireg[u], cb);
+      for (int u = 0; u < D; ++u) load_a(ireg[u], cb, areg[u]);
     }
     __syncthreads();
 
@@ -284,27 +287,31 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
       for (int u = 0; u < KT; ++u) {
         const int32_t idx = row_ok ? ireg[u] : -1;
         if (__builtin_amdgcn_ballot_w64(idx >= 0) != 0) {
-          f32x4 a = areg[u % D];
-          if (!row_ok) a = (f32x4){0.f, 0.f, 0.f, 0.f};  // rows past the end (absent neighbours already read as zeros)
-          const f32x4* sb = slab + u * (NTW * 64) + lane;
-          f32x4 bf[NTW];
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) bf[nt] = sb[nt * 64];
-          // the four k-steps of a tap on one accumulator are a dependent chain (40-cycle latency vs 32-cycle issue):
-          // interleave the column tiles, and with a single column tile alternate two accumulators
-          if (NTW == 1) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[0].x, acc[0], 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[0].y, acc2, 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[0].z, acc[0], 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[0].w, acc2, 0, 0, 0);
-          } else {
+          for (int c = 0; c < CW; ++c) {
+            f32x4 a = areg[u % D][c];
+            if (!row_ok) a = (f32x4){0.f, 0.f, 0.f, 0.f};  // rows past the end (absent neighbours already read as zeros)
+            const f32x4* sb = slab + (u * CW + c) * (NTW * 64) + lane;
+            f32x4 bf[NTW];
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-              if (nt < ntw) {
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[nt].x, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[nt].y, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[nt].z, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[nt].w, acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NTW; ++nt) bf[nt] = sb[nt * 64];
+            // the four k-steps of a tap stay a dependent chain per accumulator (interleaving column tiles measured 1.6x
+            // slower); with a single column tile and a single block two accumulators alternate (40-cycle dependent latency
+            // vs 32-cycle issue)
+            if (NTW == 1 && CW == 1) {
+              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[0].x, acc[0], 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[0].y, acc2, 0, 0, 0);
+              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[0].z, acc[0], 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[0].w, acc2, 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int nt = 0; nt < NTW; ++nt) {
+                if (nt < ntw) {
+                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[nt].x, acc[nt], 0, 0, 0);
+                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[nt].y, acc[nt], 0, 0, 0);
+                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[nt].z, acc[nt], 0, 0, 0);
+                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[nt].w, acc[nt], 0, 0, 0);
+                }
               }
             }
           }
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
         // slot u now belongs to the next tile; the gather D taps ahead uses this tile's column while u + D < KT and
         // the next tile's (refilled KT - D taps ago) after that - the same expression either way
         ireg[u] = load_idx(u, rc_next);
-        areg[u % D] = load_a(ireg[(u + D) % KT], cb);
+        load_a(ireg[(u + D) % KT], cb, areg[u % D]);
       }
 
 #pragma unroll
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
           for (int nt = 0; nt < NTW; ++nt)
             if (nt < ntw)
               out[(uint32_t)row * (uint32_t)cout + (uint32_t)((nt0 + nt) * 16 + i16)] =
-                  (NTW == 1 ? acc[nt][r] + acc2[r] : acc[nt][r]) + prev[nt][r];
+                  (NTW == 1 && CW == 1 ? acc[nt][r] + acc2[r] : acc[nt][r]) + prev[nt][r];
         }
       }
     }
@@ -427,17 +434,17 @@ StreamPlan plan_stream(int K, int64_t n_dst, int cin, int cout) {
   return p;
 }
 
-template <int NTW, int KT, int D>
+template <int NTW, int KT, int D, int CW>
 int launch_stream(int groups, const float* in, const float* packed, const int32_t* nbr, int64_t n_dst, int cin,
                   int nt_total, float* out, hipStream_t stream) {
-  constexpr size_t lds = (size_t)KT * NTW * 64 * 16;
+  constexpr size_t lds = (size_t)KT * CW * NTW * 64 * 16;
   // persistent grid = (workgroups that are resident at once) x CUs: asked from the runtime once per instantiation
   static int wgs = 0;
   if (wgs == 0) {
-    GPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_fwd_stream_kernel<NTW, KT, D>),
+    GPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_fwd_stream_kernel<NTW, KT, D, CW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0, dev = 0, cus = 0;
-    GPN_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_stream_kernel<NTW, KT, D>, 512, lds));
+    GPN_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_stream_kernel<NTW, KT, D, CW>, 512, lds));
     GPN_CHECK_HIP(hipGetDevice(&dev));
     GPN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (per_cu < 1) per_cu = 1;
@@ -445,7 +452,7 @@ int launch_stream(int groups, const float* in, const float* packed, const int32_
     wgs = (cus * per_cu + 7) / 8 * 8;
   }
   const dim3 grid((unsigned)wgs, (unsigned)groups, 1);
-  hipLaunchKernelGGL((spconv_fwd_stream_kernel<NTW, KT, D>), grid, dim3(512), lds, stream, in, packed, nbr, n_dst, cin,
+  hipLaunchKernelGGL((spconv_fwd_stream_kernel<NTW, KT, D, CW>), grid, dim3(512), lds, stream, in, packed, nbr, n_dst, cin,
                      nt_total, gpn::cdiv(n_dst, 16), out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
@@ -454,8 +461,15 @@ int launch_stream(int groups, const float* in, const float* packed, const int32_
 template <int NTW>
 int dispatch_stream(int groups, const float* in, const float* packed, const int32_t* nbr, int K, int64_t n_dst,
                     int cin, int nt_total, float* out, hipStream_t stream) {
-  if (K == 27) return launch_stream<NTW, 27, 9>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
-  return launch_stream<NTW, 8, 8>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+  // two input blocks per pass when the slab allows it (K x 2 x ntw KiB <= 108): a 32-channel level is then a single pass
+  // (whole 128-byte rows gathered back to back, no read-modify-write of the output)
+  const bool two = (cin / 16) % 2 == 0 && NTW <= 2;
+  if (K == 27) {
+    if (two) return launch_stream<NTW, 27, 3, (NTW <= 2 ? 2 : 1)>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+    return launch_stream<NTW, 27, 9, 1>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+  }
+  if (two) return launch_stream<NTW, 8, 4, (NTW <= 2 ? 2 : 1)>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+  return launch_stream<NTW, 8, 8, 1>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
 }
 
 }  // namespace
