@@ -170,11 +170,12 @@ int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int cig = (ct_tiles + CT - 1) / CT;
   // enough pair slices for ~4096 workgroups (each slice is a latency-bound gather loop), at least ~128 dst rows
-  // per slice, and at most 64 MB of partials
+  // per slice, and at most 8 MB of partials (they are written and re-read by the reduce: 37 MB at 48 channels cost more
+  // than the extra slices saved)
   int64_t S = 4096 / ((int64_t)K * cig);
   const int64_t cap = n_dst / 128;
   if (S > cap) S = cap;
-  const int64_t mem_cap = ((int64_t)64 << 20) / ((int64_t)K * cin * cout * 4);
+  const int64_t mem_cap = ((int64_t)8 << 20) / ((int64_t)K * cin * cout * 4);
   if (S > mem_cap) S = mem_cap;
   if (S < 1) S = 1;
   if (S > 512) S = 512;
