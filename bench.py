@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0           # same guide, HBM3E peak (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step (BASELINE config 3: bs=8/GPU)")
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--schedule", type=str, default="0,0", help="training_schedule; 0,0 = every head active")

@@ -98,3 +98,36 @@ def test_executor_struct_layouts_match_the_header(tmp_path):
         dt, names = fields[name]
         assert dt.itemsize == int(size), (name, dt.itemsize, size)
         assert [dt.fields[f][1] for f in names] == [int(o) for o in offs], name
+
+
+def test_executor_rejects_malformed_programs_without_touching_the_device(lib):
+    """gpn_net_forward validates the whole program (slot / table indices, shapes) before its first launch"""
+    import numpy as np
+    from gapartnet_amd.network import net_exec as NX
+    lib.gpn_last_error.restype = ctypes.c_char_p
+
+    def vp(a):
+        return ctypes.c_void_p(a.ctypes.data)
+
+    slots = np.zeros(2, NX.SLOT_DT)
+    slots["rows"], slots["channels"] = 100, 16
+    rbs = np.zeros(1, NX.RB_DT)
+    rbs["n_src"], rbs["n_dst"], rbs["K"] = 100, 100, 27
+    convs = np.zeros(1, NX.CONV_DT)
+    convs["cin"], convs["cout"] = 16, 32  # does not match slot 1's 16 channels
+    bns = np.zeros(1, NX.BN_DT)
+    ops = np.zeros(1, NX.OP_DT)
+    ops[0] = (NX.OP_CONV, 0, -1, 1, 0, 0, 0, 0)
+
+    def run(ops_arr):
+        return lib.gpn_net_forward(vp(ops_arr), len(ops_arr), vp(slots), 2, vp(rbs), 1, vp(convs), 1, vp(bns), 1, 1, None,
+                                   ctypes.c_size_t(0), None)
+
+    assert run(ops) == 1 and b"does not match" in lib.gpn_last_error()
+    bad = ops.copy()
+    bad["dst"] = 7
+    assert run(bad) == 1 and b"out of range" in lib.gpn_last_error()
+    bad = ops.copy()
+    bad["kind"] = 9
+    assert run(bad) == 1 and b"unknown op" in lib.gpn_last_error()
+    assert lib.gpn_net_forward(None, 1, None, 0, None, 0, None, 0, None, 0, 1, None, ctypes.c_size_t(0), None) == 1
