@@ -61,6 +61,60 @@ def compute_npcs_loss_masked(npcs_preds: torch.Tensor, gt_npcs: torch.Tensor, pr
     return total / has.sum().clamp(min=1)
 
 
+class SymmetryTables:
+    """the three symmetry tables of the NPCS loss ([3,2,3,3] for symmetry types 0-2, [1,12,3,3] for type 3, [1,24,3,3]
+    for type 4; misc/info.py:338-346) flattened for ``compute_npcs_loss_grouped``:
+      flat  [3, 3 * n_matrices]   every candidate rotation side by side (one matmul gives every candidate target)
+      cols  [n_types, m_max]      per symmetry type, the columns of its candidates (short lists padded by repeating
+                                  their last candidate: a repeated candidate cannot change a minimum)
+      group [n_types]             which of the three tables (= loss terms) a type belongs to"""
+
+    def __init__(self, tables, device):
+        mats, cols, group = [], [], []
+        m_max = max(t.shape[1] for t in tables)
+        for g, table in enumerate(tables):
+            for t in range(table.shape[0]):
+                start = len(mats)
+                mats.extend(table[t, m] for m in range(table.shape[1]))
+                ids = list(range(start, start + table.shape[1]))
+                cols.append(ids + [ids[-1]] * (m_max - len(ids)))
+                group.append(g)
+        stacked = torch.stack(mats).to(device=device, dtype=torch.float32)            # [n_matrices, 3, 3]
+        self.flat = stacked.permute(1, 0, 2).reshape(3, -1).contiguous()             # [3, n_matrices * 3]
+        self.cols = torch.tensor(cols, dtype=torch.int64, device=device)
+        self.group = torch.tensor(group, dtype=torch.int64, device=device)
+        self.n_groups = len(tables)
+
+
+def compute_npcs_loss_grouped(npcs_preds: torch.Tensor, gt_npcs: torch.Tensor, proposal_indices: torch.Tensor,
+                              sym: torch.Tensor, tables: SymmetryTables, num_proposals: int) -> torch.Tensor:
+    """sum over the symmetry groups of ``compute_npcs_loss`` on that group's points (model.py:446-462 calls it once per
+    group on boolean-mask selections), evaluated for all groups at once and without selecting anything:
+      * every candidate target of every point comes from ONE [n,3] x [3, 3*38] matmul instead of a per-point gather of
+        3x3 matrices (which moved 136 MB per call);
+      * per (proposal, group) means are ordered segment sums over the runs of ``proposal_indices`` (non-decreasing, values
+        in [0, num_proposals)) of the member-masked costs; a group without points contributes 0, as the reference's
+        ``if`` does.
+    ``sym`` = symmetry type of every point.  No data-dependent shapes, so no host sync."""
+    n = npcs_preds.shape[0]
+    targets = (gt_npcs @ tables.flat).view(n, tables.flat.shape[1] // 3, 3)             # [n, n_matrices, 3]
+    dist2 = ((npcs_preds[:, None, :] - targets - 0.5) ** 2).sum(dim=-1)                  # [n, n_matrices]
+    cost = torch.where(dist2 <= 0.01, 5 * dist2, torch.sqrt(dist2) - 0.05)
+    cost = cost.gather(1, tables.cols[sym])                                              # [n, m_max] own candidates
+    member = tables.group[sym][:, None] == torch.arange(tables.n_groups, device=sym.device)[None, :]   # [n, G]
+    m_max = tables.cols.shape[1]
+    masked = (cost[:, None, :] * member[:, :, None].to(cost.dtype)).reshape(n, tables.n_groups * m_max)
+    edges = torch.searchsorted(proposal_indices.contiguous(),
+                               torch.arange(num_proposals + 1, dtype=proposal_indices.dtype, device=cost.device))
+    lengths = edges[1:] - edges[:-1]
+    seg_sum = torch.segment_reduce(masked, "sum", lengths=lengths, unsafe=True).view(num_proposals, tables.n_groups, m_max)
+    seg_cnt = torch.segment_reduce(member.to(cost.dtype), "sum", lengths=lengths, unsafe=True)   # [P, G]
+    has = seg_cnt > 0
+    best = (seg_sum / seg_cnt.clamp(min=1)[:, :, None]).min(dim=-1)[0]                   # [P, G]
+    per_group = torch.where(has, best, torch.zeros_like(best)).sum(0) / has.sum(0).clamp(min=1)
+    return per_group.sum()
+
+
 # ------------------------------------------------------------------------------------------------- re-voxelise
 def segmented_voxelize(pt_xyz: torch.Tensor, pt_features: torch.Tensor, segment_offsets: torch.Tensor,
                        segment_indices: torch.Tensor, num_points_per_segment: torch.Tensor, score_fullscale: float,

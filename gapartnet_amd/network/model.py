@@ -31,7 +31,7 @@ from ..structure.instances import Instances
 from ..structure.point_cloud import PointCloud, PointCloudBatch
 from ..structure.segmentation import Segmentation
 from .backbone import SparseUNet
-from .grouping_utils import (apply_nms, cluster_proposals, compute_ap, compute_npcs_loss, compute_npcs_loss_masked,
+from .grouping_utils import (apply_nms, cluster_proposals, compute_ap, compute_npcs_loss, compute_npcs_loss_grouped, SymmetryTables,
                              filter_invalid_proposals, get_gt_scores, offsets_from_counts, segmented_voxelize)
 from .losses import dice_loss, focal_loss, mean_iou, pixel_accuracy
 
@@ -287,17 +287,14 @@ class GAPartNet(LightningModule):
         self.symmetry_matrix_3 = self.symmetry_matrix_3.to(dev)
         sym = self.symmetry_indices[sem_preds]
 
-        # the three symmetry groups (sym < 3, == 3, == 4), each with its own table of candidate rotations.  The reference
-        # selects every group with four boolean masks (twelve host syncs); here each group's loss is evaluated on all
-        # points with the non-members masked out (grouping_utils.compute_npcs_loss_masked): same value, no sync
+        # the reference evaluates compute_npcs_loss once per symmetry group (sym < 3, == 3, == 4) on boolean-mask
+        # selections (twelve host syncs); compute_npcs_loss_grouped gives the same sum in one pass with none
+        tables = getattr(self, "_symmetry_tables", None)
+        if tables is None or tables.flat.device != dev:
+            tables = SymmetryTables((self.symmetry_matrix_1, self.symmetry_matrix_2, self.symmetry_matrix_3), dev)
+            self._symmetry_tables = tables
         num_proposals = proposals.proposal_offsets.shape[0] - 1
-        loss = 0
-        for member, table, base in ((sym < 3, self.symmetry_matrix_1, 0), (sym == 3, self.symmetry_matrix_2, 3),
-                                    (sym == 4, self.symmetry_matrix_3, 4)):
-            rows = (sym - base).clamp(0, table.shape[0] - 1)
-            loss = loss + compute_npcs_loss_masked(npcs_preds, gt_npcs, proposal_indices, table[rows], member,
-                                                   num_proposals)
-        return loss
+        return compute_npcs_loss_grouped(npcs_preds, gt_npcs, proposal_indices, sym, tables, num_proposals)
 
     # ------------------------------------------------------------------------------------------ one step
     def _collate(self, point_clouds: Union[Sequence[PointCloud], PointCloudBatch]) -> PointCloudBatch:

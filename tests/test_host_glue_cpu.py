@@ -230,6 +230,22 @@ def test_sync_free_loss_forms_equal_the_selecting_forms():
             assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-8)
         else:
             assert masked.item() == 0.0
+    # all three symmetry groups at once (the form the training step uses) == the reference's per-group selecting loop
+    from gapartnet_amd.misc.info import get_symmetry_matrix
+    t1, t2, t3 = get_symmetry_matrix()
+    tables = G.SymmetryTables((t1, t2, t3), torch.device("cpu"))
+    for case in range(3):
+        types = torch.randint(0, 5, (n,), generator=g) if case < 2 else torch.full((n,), 1)
+        if case == 1:
+            types[pi == 2] = 4
+        got = G.compute_npcs_loss_grouped(pred, gt, pi, types, tables, P)
+        want = 0
+        for mask, table, base in ((types < 3, t1, 0), (types == 3, t2, 3), (types == 4, t3, 4)):
+            if mask.any():
+                want = want + G.compute_npcs_loss(pred[mask], gt[mask], pi[mask], table[types[mask] - base])
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-7), (case, got, want)
+        ga, gb = torch.autograd.grad(got, pred)[0], torch.autograd.grad(want, pred)[0]
+        assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-8)
     # focal loss with ignored rows
     logits = torch.randn((50, 6), generator=g, requires_grad=True)
     target = torch.randint(0, 6, (50,), generator=g)
