@@ -80,6 +80,68 @@ def sparse_conv(features: torch.Tensor, weight: torch.Tensor, rb, rb_t, reverse_
     return out
 
 
+_IDENTITY_RULEBOOKS = {}
+_AB_TORCH_LINEAR = bool(int(__import__('os').environ.get('GPN_AB_TORCH_LINEAR', '0')))  # A/B switch for tools/
+
+
+def _identity_rulebook(n: int, device):
+    """K = 1 rulebook mapping every row to itself (cached per (rows, device); a handful of sizes per step)"""
+    key = (int(n), str(device))
+    rb = _IDENTITY_RULEBOOKS.get(key)
+    if rb is None:
+        from .spconv.pytorch import _identity_rulebook as build
+        if len(_IDENTITY_RULEBOOKS) > 64:
+            _IDENTITY_RULEBOOKS.clear()
+        rb = _IDENTITY_RULEBOOKS[key] = build(int(n), device)
+    return rb
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b as the K = 1 case of the fused conv kernels, output channels zero-padded to a multiple of 16;
+    one autograd node with three library calls (forward, dgrad, wgrad) and no autograd-visible pad / slice ops"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ops = backend.raw()
+        x = x.contiguous()
+        cout, cin = weight.shape
+        cout_p = _pad16(cout)
+        w = weight.detach()
+        if cout_p != cout:
+            w = F.pad(w, (0, 0, 0, cout_p - cout))
+        w = w.contiguous().view(cout_p, 1, cin)
+        rb = _identity_rulebook(x.shape[0], x.device)
+        out = ops.conv_fwd(x, w, rb, "oki")
+        ctx.save_for_backward(x, w)
+        ctx.rb, ctx.cout, ctx.has_bias = rb, cout, bias is not None
+        y = out[:, :cout] if cout_p != cout else out
+        return y + bias if bias is not None else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = backend.raw()
+        x, w = ctx.saved_tensors
+        cout, cout_p = ctx.cout, w.shape[0]
+        dy_p = dy.contiguous() if cout_p == cout else F.pad(dy, (0, cout_p - cout))
+        dx = ops.conv_dgrad(dy_p, w, ctx.rb, ctx.rb, False, "oki") if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(x, dy_p, ctx.rb, "oki").view(cout_p, x.shape[1])[:cout]
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear`` for the per-point / per-voxel heads (model.py:160-175: Linear(16, n) on 10^5 rows).  These are
+    K = 1 cases of the fused conv kernel family (forward, dgrad, wgrad): at [160k, 16] x [16, 3..27] the library GEMMs
+    the framework dispatches to run at 0.2-0.4 TFLOP/s (fwd+bwd 260-380 us per layer vs 200-250 here).
+    Falls back to F.linear for shapes the kernels do not cover."""
+    if (backend.raw().name != "hip" or not x.is_cuda or x.dim() != 2 or x.shape[1] % 16 != 0 or x.shape[0] < 4096
+            or x.dtype != torch.float32 or _AB_TORCH_LINEAR):
+        return F.linear(x, weight, bias)
+    return _LinearFn.apply(x, weight, bias)
+
+
 class _GatherRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, idx, csr):

@@ -132,7 +132,7 @@ class GAPartNet(LightningModule):
         return GF.gather_rows(voxel_features.features, pc_batch.pc_voxel_id, getattr(pc_batch, "pc_voxel_csr", None))
 
     def forward_sem_seg(self, pc_feature: torch.Tensor) -> torch.Tensor:
-        return self.sem_seg_head(pc_feature)
+        return GF.linear(pc_feature, self.sem_seg_head.weight, self.sem_seg_head.bias)
 
     def loss_sem_seg(self, sem_logits: torch.Tensor, sem_labels: torch.Tensor) -> torch.Tensor:
         if self.use_sem_focal_loss:
@@ -146,7 +146,13 @@ class GAPartNet(LightningModule):
         return loss
 
     def forward_offset(self, pc_feature: torch.Tensor) -> torch.Tensor:
-        return self.offset_head(pc_feature)
+        fc0, norm, act, fc1 = self.offset_head[0], self.offset_head[1], self.offset_head[2], self.offset_head[3]
+        if not (isinstance(fc0, nn.Linear) and isinstance(norm, nn.BatchNorm1d) and isinstance(act, nn.ReLU)
+                and isinstance(fc1, nn.Linear)):
+            return self.offset_head(pc_feature)
+        # Linear -> BatchNorm1d -> ReLU -> Linear on the same kernels as the backbone layers (GF.linear, GF.bn_act)
+        hidden = GF.bn_act(GF.linear(pc_feature, fc0.weight, fc0.bias), norm, relu=True)
+        return GF.linear(hidden, fc1.weight, fc1.bias)
 
     def loss_offset(self, offsets: torch.Tensor, gt_offsets: torch.Tensor, sem_labels: torch.Tensor,
                     instance_labels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -260,7 +266,8 @@ class GAPartNet(LightningModule):
 
     def forward_proposal_npcs(self, voxel_tensor: spconv.SparseConvTensor, pc_voxel_id: torch.Tensor) -> torch.Tensor:
         feats = self.npcs_unet(voxel_tensor)
-        return GF.gather_rows(self.npcs_head(feats.features), pc_voxel_id, getattr(voxel_tensor, "point_csr", None))
+        logits = GF.linear(feats.features, self.npcs_head.weight, self.npcs_head.bias)
+        return GF.gather_rows(logits, pc_voxel_id, getattr(voxel_tensor, "point_csr", None))
 
     def loss_proposal_npcs(self, npcs_logits: torch.Tensor, gt_npcs: torch.Tensor, proposals: Instances) -> torch.Tensor:
         """symmetry-aware NPCS loss on points whose predicted part class is right and that carry a non-zero NPCS

@@ -344,3 +344,23 @@ def test_conv_parameter_layout_matches_canonical(H, cuda):
     assert torch.equal(H.conv_fwd(f, W, rb), H.conv_fwd(f, Wp, rb, "oki"))
     assert torch.equal(H.conv_dgrad(g, W, rb, rb, True), H.conv_dgrad(g, Wp, rb, rb, True, "oki"))
     assert torch.equal(H.conv_wgrad(f, g, rb).permute(2, 0, 1), H.conv_wgrad(f, g, rb, "oki"))
+
+
+@pytest.mark.parametrize("n,cin,cout", [(20000, 16, 10), (5000, 32, 27), (4096, 16, 16)])
+def test_linear_through_the_conv_kernels_matches_torch(H, cuda, n, cin, cout):
+    """GF.linear (K = 1 case of the fused conv family, output channels zero-padded to 16) vs F.linear, 1e-4"""
+    import torch.nn.functional as F
+    from gapartnet_amd import functional as GF
+    g = torch.Generator().manual_seed(n + cout)
+    x = torch.randn(n, cin, generator=g).to(cuda).requires_grad_(True)
+    w = (torch.randn(cout, cin, generator=g) * 0.2).to(cuda).requires_grad_(True)
+    b = torch.randn(cout, generator=g).to(cuda).requires_grad_(True)
+    dy = torch.randn(n, cout, generator=g).to(cuda)
+    ref = F.linear(x, w, b)
+    gref = torch.autograd.grad(ref, [x, w, b], dy)
+    got = GF.linear(x, w, b)
+    ggot = torch.autograd.grad(got, [x, w, b], dy)
+    assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(ggot[0], gref[0], atol=1e-4, rtol=1e-4)
+    assert torch.allclose(ggot[1], gref[1], atol=1e-3 * max(1.0, float(gref[1].abs().max())), rtol=1e-3)
+    assert torch.allclose(ggot[2], gref[2], atol=1e-3 * max(1.0, float(gref[2].abs().max())), rtol=1e-3)
