@@ -377,8 +377,16 @@ def ball_query(points, query, batch_indices, batch_offsets, radius, num_samples,
     Q, K = query.shape[0], int(num_samples)
     idx = torch.empty((Q, K), dtype=torch.int32, device=dev)
     cnt = torch.zeros((Q,), dtype=torch.int32, device=dev)
-    check(_C.lib().gpn_ball_query(ptr(points), ptr(query), ptr(bi), ptr(bo), ptr(pl), ptr(ql), i64(points.shape[0]),
-                                  i64(Q), i64(bo.shape[0] - 1), f32(radius), i32(K), ptr(idx), ptr(cnt), _stream()),
+    L = _C.lib()
+    Np = points.shape[0]
+    if Np >= 2048 and radius > 0:  # grid-accelerated form (identical results); tiny inputs: the plain scan is one launch
+        ws = _ws(L.gpn_ball_query_grid_ws_bytes(i64(Np)), dev)
+        check(L.gpn_ball_query_grid(ptr(points), ptr(query), ptr(bi), ptr(bo), ptr(pl), ptr(ql), i64(Np), i64(Q),
+                                    i64(bo.shape[0] - 1), f32(radius), i32(K), ptr(idx), ptr(cnt), ptr(ws),
+                                    szt(ws.numel()), _stream()), "gpn_ball_query_grid")
+        return idx, cnt
+    check(L.gpn_ball_query(ptr(points), ptr(query), ptr(bi), ptr(bo), ptr(pl), ptr(ql), i64(Np),
+                           i64(Q), i64(bo.shape[0] - 1), f32(radius), i32(K), ptr(idx), ptr(cnt), _stream()),
           "gpn_ball_query")
     return idx, cnt
 

@@ -268,6 +268,14 @@ int gpn_ball_query(const float* points, const float* query, const int32_t* batch
                    const int32_t* batch_offsets, const int32_t* point_labels,
                    const int32_t* query_labels, int64_t Np, int64_t Q, int64_t S, float radius, int K,
                    int32_t* indices, int32_t* count, gpn_stream_t stream);
+/* same contract and results, O(n k) instead of O(n^2): points binned into a uniform grid (one radix sort), one wave per
+ * query over its 27 neighbour cells, hits ranked back into ascending point index; dense neighbourhoods fall back to the
+ * index-order scan inside the kernel. */
+size_t gpn_ball_query_grid_ws_bytes(int64_t Np);
+int gpn_ball_query_grid(const float* points, const float* query, const int32_t* batch_indices,
+                        const int32_t* batch_offsets, const int32_t* point_labels, const int32_t* query_labels,
+                        int64_t Np, int64_t Q, int64_t S, float radius, int K, int32_t* indices, int32_t* count, void* ws,
+                        size_t ws_bytes, gpn_stream_t stream);
 
 /* L — connected components.  replaces epic_ops.ccl.connected_components_labeling
  * (network/grouping_utils.py:135-137).  begin_end [2Q] i32 interleaved (begin,end) into edges [E];

@@ -364,3 +364,35 @@ def test_linear_through_the_conv_kernels_matches_torch(H, cuda, n, cin, cout):
     assert torch.allclose(ggot[0], gref[0], atol=1e-4, rtol=1e-4)
     assert torch.allclose(ggot[1], gref[1], atol=1e-3 * max(1.0, float(gref[1].abs().max())), rtol=1e-3)
     assert torch.allclose(ggot[2], gref[2], atol=1e-3 * max(1.0, float(gref[2].abs().max())), rtol=1e-3)
+
+
+@pytest.mark.parametrize("case", ["surface", "dense", "labels", "far_queries"])
+def test_grid_ball_query_is_bit_exact(H, cuda, case):
+    """the grid-accelerated ball query (>= 2048 points) == the oracle's index-order scan: sparse neighbourhoods (ranked hit
+    lists), dense ones (more hits than the per-wave list: in-kernel fallback scan, truncation at K), label filter, queries
+    outside the points' bounding box, an empty segment"""
+    rng = np.random.default_rng({"surface": 1, "dense": 2, "labels": 3, "far_queries": 4}[case])
+    if case == "dense":
+        centres = rng.uniform(-0.5, 0.5, (6, 3))
+        pts = (centres[rng.integers(0, 6, 9000)] + rng.normal(scale=0.004, size=(9000, 3))).astype(np.float32)
+        offs = np.array([0, 4000, 4000, 9000], np.int32)
+        K, r = 300, 0.03
+    else:
+        pts, _ = synth.clustered_points(rng, 3, 3000)
+        offs = np.array([0, 3000, 6000, 9000], np.int32)
+        K, r = 50, 0.04
+    batch = np.repeat(np.arange(3, dtype=np.int32), np.diff(offs))
+    lab = rng.integers(1, 4, pts.shape[0]).astype(np.int32) if case == "labels" else None
+    if case == "far_queries":
+        q = np.concatenate([pts[::3] + 0.01, rng.uniform(-3, 3, (500, 3))]).astype(np.float32)
+        qb = rng.integers(0, 3, q.shape[0]).astype(np.int32)
+        ql = None
+    else:
+        q, qb, ql = pts, batch, lab
+    ref_idx, ref_cnt = O.ball_query(pts, q, qb, offs, r, K, lab, ql)
+    idx, cnt = H.ball_query(dev(pts, cuda), dev(q, cuda), dev(qb, cuda), dev(offs, cuda), r, K,
+                            None if lab is None else dev(lab, cuda), None if ql is None else dev(ql, cuda))
+    assert np.array_equal(host(cnt), ref_cnt)
+    assert np.array_equal(host(idx), ref_idx)
+    if case == "dense":
+        assert (ref_cnt == K).mean() > 0.5, "the dense case must exercise truncation"
