@@ -2,8 +2,8 @@
 // it in every block of the reference network (network/backbone.py:40-49: relu(bn(conv(x)) [+ shortcut])).
 //
 // HBM-streaming kernels: [N, C] row-major with C in 16..224, read as float4.  Training forward = statistics pass
-// (per-workgroup partial sums in double for a cancellation-safe variance; the last workgroup to finish - a ticket
-// counter - combines them in workgroup order and writes mean, 1/std and the running statistics) + one apply pass that also adds the residual and applies ReLU.  Backward = one reduction pass
+// (per-workgroup partial sums, combined in double for a cancellation-safe variance) + tiny finalize (mean, 1/std,
+// running-stat update) + one apply pass that also adds the residual and applies ReLU.  Backward = one reduction pass
 // (sum g, sum g*xhat with the ReLU mask folded in) + finalize + one apply pass producing dx (and the residual's
 // gradient).  Compared with separate BatchNorm / add / ReLU kernels this removes three full read+write passes per
 // layer in forward and two in backward.  All reductions are fixed-order (deterministic).
@@ -11,35 +11,21 @@
 // Small matrices (N <= kSmallRows: the deep levels of the U-Net, where a layer's kernels run at the
 // launch-latency floor) take a single-launch form instead: one workgroup per float4 column computes the statistics of
 // its four channels and applies them in a second sweep over the (L2-resident) column - one launch instead of three.
-#include <map>
-#include <mutex>
-#include <utility>
-
 #include "gpn_common.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 64;  // reduction workgroups; the last one to finish combines their partials
+constexpr int kMaxBlocks = 512;
 
 // thread layout for column-wise reductions: c4 = tid % C4 (float4 column), r = tid / C4 (row lane), R = 256 / C4 rows
-// what the last workgroup of a reduction pass needs to finish the statistics (so that no separate finalize launch runs)
-struct BnFinalize {
-  unsigned int* ticket;  // zero on entry; the last workgroup to arrive resets it
-  float eps, momentum;
-  float *out0, *out1;    // fwd: mean, invstd      bwd: dbias, dweight
-  float *running_mean, *running_var;
-};
-
 template <bool BWD>
 __global__ __launch_bounds__(kThreads) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ dy, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int64_t N, int C4, int relu,
-                                                             double* __restrict__ partial /* [blocks][2][C] */,
-                                                             BnFinalize fin) {
+                                                             double* __restrict__ partial /* [blocks][2][C] */) {
   __shared__ double red[2][kThreads][4];
-  __shared__ unsigned int s_ticket;
   const int R = kThreads / C4;
   const int r = threadIdx.x / C4, c4 = threadIdx.x - r * C4;
   const bool lane_ok = r < R;
@@ -86,37 +72,44 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_kernel(const float* __rest
     for (int rr = 0; rr < R; ++rr) acc += red[q][rr * C4 + cc4][j];
     partial[((int64_t)blockIdx.x * 2 + q) * C + c] = acc;
   }
-  // ---- the last workgroup to finish combines the partials (fixed order over workgroup index: deterministic) ----
-  __threadfence();  // this workgroup's partials are visible device-wide before its ticket is
-  __syncthreads();
-  if (threadIdx.x == 0) s_ticket = atomicAdd(fin.ticket, 1u);
-  __syncthreads();
-  if (s_ticket != gridDim.x - 1) return;
-  __threadfence();
-  const int nb = gridDim.x;
-  for (int c = threadIdx.x; c < C; c += kThreads) {
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nb; ++b) {  // device-scope loads: other CUs' partials must not be served from this CU's L1
-      s += __hip_atomic_load(&partial[((int64_t)b * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ss += __hip_atomic_load(&partial[((int64_t)b * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!BWD) {
-      const double m = s / (double)N;
-      double var = ss / (double)N - m * m;
-      if (var < 0.0) var = 0.0;
-      fin.out0[c] = (float)m;
-      fin.out1[c] = (float)(1.0 / sqrt(var + (double)fin.eps));
-      if (fin.running_mean) {
-        const double unbiased = N > 1 ? var * ((double)N / (double)(N - 1)) : var;
-        fin.running_mean[c] = (float)((1.0 - fin.momentum) * fin.running_mean[c] + fin.momentum * m);
-        fin.running_var[c] = (float)((1.0 - fin.momentum) * fin.running_var[c] + fin.momentum * unbiased);
-      }
-    } else {
-      fin.out0[c] = (float)s;   // dbias
-      fin.out1[c] = (float)ss;  // dweight
-    }
+}
+
+// one 64-thread workgroup per channel sums the per-workgroup partials: strided per-lane sums, then a fixed-order
+// shuffle tree (deterministic); a serial loop over up to 512 partials per channel cost 25 us per layer
+__device__ __forceinline__ void sum_partials(const double* __restrict__ partial, int blocks, int C, int c, double& s,
+                                             double& ss) {
+  s = 0.0;
+  ss = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 64) {
+    s += partial[((int64_t)b * 2 + 0) * C + c];
+    ss += partial[((int64_t)b * 2 + 1) * C + c];
   }
-  if (threadIdx.x == 0) *fin.ticket = 0u;  // ready for the next pass on this stream
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    ss += __shfl_down(ss, off, 64);
+  }
+}
+
+// forward finalize: mean / invstd, running statistics (momentum; unbiased variance as torch.nn.BatchNorm1d)
+__global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(const double* __restrict__ partial, int blocks, int64_t N,
+                                                             int C, float eps, float momentum, float* __restrict__ mean,
+                                                             float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var) {
+  const int c = blockIdx.x;
+  double s, ss;
+  sum_partials(partial, blocks, C, c, s, ss);
+  if (threadIdx.x != 0) return;
+  const double m = s / (double)N;
+  double var = ss / (double)N - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = N > 1 ? var * ((double)N / (double)(N - 1)) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
 }
 
 // y = relu?( (x - mean) * invstd * w + b [+ res] )
@@ -136,6 +129,17 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __
     }
     reinterpret_cast<f32x4*>(y)[t] = v;
   }
+}
+
+// backward finalize: dweight = sum g*xhat, dbias = sum g
+__global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(const double* __restrict__ partial, int blocks, int C,
+                                                             float* __restrict__ dweight, float* __restrict__ dbias) {
+  const int c = blockIdx.x;
+  double s, ss;
+  sum_partials(partial, blocks, C, c, s, ss);
+  if (threadIdx.x != 0) return;
+  dbias[c] = (float)s;
+  dweight[c] = (float)ss;
 }
 
 // dx = invstd * w * (g - dbias/N - xhat * dweight/N)   (training)   |   dx = invstd * w * g   (eval);  dres = g
@@ -301,24 +305,6 @@ __global__ __launch_bounds__(kThreads) void bn_small_bwd_kernel(
   }
 }
 
-// one ticket word per (device, stream, direction), allocated on first use and left at zero by every pass; passes on
-// the same stream are ordered, passes on different streams get different words
-unsigned int* ticket_word(hipStream_t stream, int slot) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, unsigned int*> words;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = words.find({dev, stream});
-  if (it == words.end()) {
-    unsigned int* p = nullptr;
-    if (hipMalloc(&p, 512) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, 512) != hipSuccess) return nullptr;
-    it = words.emplace(std::make_pair(dev, stream), p).first;
-  }
-  return it->second + slot * 64;  // 256 bytes apart
-}
-
 int reduce_blocks(int64_t N, int C4) {
   const int R = kThreads / C4;
   int64_t b = gpn::cdiv(N, (int64_t)R * 8);
@@ -363,10 +349,11 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
   }
   const int blocks = reduce_blocks(N, C4);
   double* partial = static_cast<double*>(ws);
-  unsigned int* ticket = ticket_word(stream, 0);
-  GPN_CHECK_ARG(ticket != nullptr);
   hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(blocks), dim3(kThreads), 0, stream, x, nullptr, nullptr, nullptr,
-                     nullptr, N, C4, 0, partial, BnFinalize{ticket, eps, momentum, mean, invstd, running_mean, running_var});
+                     nullptr, N, C4, 0, partial);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, stream, partial, blocks, N, C,
+                     eps, momentum, mean, invstd, running_mean, running_var);
   GPN_CHECK_LAUNCH();
   const int64_t total4 = N * C4;
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, res, mean, invstd,
@@ -411,10 +398,11 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
   }
   const int blocks = reduce_blocks(N, C4);
   double* partial = static_cast<double*>(ws);
-  unsigned int* ticket = ticket_word(stream, 1);
-  GPN_CHECK_ARG(ticket != nullptr);
   hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(blocks), dim3(kThreads), 0, stream, x, y, dy, mean, invstd, N, C4, relu,
-                     partial, BnFinalize{ticket, 0.f, 0.f, dbias, dweight, nullptr, nullptr});
+                     partial);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, stream, partial, blocks, C,
+                     dweight, dbias);
   GPN_CHECK_LAUNCH();
   const int64_t total4 = N * C4;
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, y, dy, mean, invstd,
