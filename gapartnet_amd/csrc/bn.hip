@@ -41,6 +41,7 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_kernel(const float* __rest
   const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
   const int64_t row_end = row_begin + rows_per_block < N ? row_begin + rows_per_block : N;
   if (lane_ok) {
+#pragma unroll 4
     for (int64_t row = row_begin + r; row < row_end; row += R) {
       const f32x4 xv = reinterpret_cast<const f32x4*>(x)[row * C4 + c4];
       if (!BWD) {

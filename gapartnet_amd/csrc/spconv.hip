@@ -142,6 +142,147 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad, LDS-staged form.  The kernel above feeds every MFMA with per-lane 4-byte gathers in the MFMA's own operand
+// layout (lane (i,g) = channel i of pair g): ~7 issued instructions per pair, so it is bound by instruction issue, not
+// by the matrix pipe (10-18 TFLOP/s).  Here a workgroup stages 64 pairs at a time: thread (row = t/4, q = t%4) gathers
+// 16-byte pieces of in[src[row]] and dout[dst[row]] (whole 64-byte pieces per 4 threads), the rows go through registers
+// into LDS tiles ([pair][channel], pitch chosen so that the strided fragment reads below are bank-conflict free), and
+// each wave contracts 16 of the 64 pairs: per k-step (4 pairs) CT + NT ds_read_b32 feed CT x NT MFMAs.  The gathers of
+// tile i+1 and the pair indices of tile i+2 are in flight while tile i is contracted.
+// Same grid, same (tap, slice) partial layout and the same fixed-order reductions as above: deterministic.
+template <int W>
+struct LdsPitch {  // floats per LDS row for W payload floats: pitch % 64 in {16, 48} => rows g, g+1, g+2, g+3 hit distinct banks
+  static constexpr int value = (W % 64 == 16 || W % 64 == 48) ? W : ((W + 16) % 64 == 16 || (W + 16) % 64 == 48) ? W + 16 : W + 32;
+};
+
+template <int CT, int NT>
+__global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
+    const float* __restrict__ in, const float* __restrict__ dout, const int32_t* __restrict__ pair_src,
+    const int32_t* __restrict__ pair_dst, const int32_t* __restrict__ tile_off, int64_t n_tiles, int cin,
+    int S, float* __restrict__ partial) {
+  constexpr int T = 64;  // pairs per tile
+  constexpr int COUT = NT * 16;
+  constexpr int PA = LdsPitch<CT * 16>::value, PB = LdsPitch<COUT>::value;
+  constexpr int TILE_FLOATS = T * (PA + PB);
+  constexpr int RED_FLOATS = CT * NT * 256;
+  __shared__ __attribute__((aligned(16))) float smem[TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS];
+  __shared__ int32_t sidx[2][2][T];  // [tile parity][src / dst][pair]
+  float* sA = smem;
+  float* sB = smem + T * PA;
+
+  const int k = blockIdx.x, s = blockIdx.y, cig = blockIdx.z;
+  const int K = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int row = tid >> 2, q = tid & 3;  // gather role: pair `row` of the tile, 16-byte piece q of each 64-byte block
+  const int ct_tiles = cin >> 4;
+  const int ct0 = cig * CT;
+
+  const int32_t l_begin = tile_off[(int64_t)k * (n_tiles + 1)];
+  const int32_t l_end = tile_off[(int64_t)k * (n_tiles + 1) + n_tiles];
+  const int32_t len = l_end - l_begin;
+  int32_t chunk = (len + S - 1) / S;
+  chunk = (chunk + 3) & ~3;
+  const int32_t a = l_begin + s * chunk;
+  int32_t b = a + chunk;
+  if (b > l_end) b = l_end;
+
+  f32x4 acc[CT][NT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (a < b) {  // uniform per workgroup
+    const int32_t last = b - 1;
+    const int n_pair_tiles = (b - a + T - 1) / T;
+    auto load_idx = [&](int tile, int32_t& s_, int32_t& d_) {  // threads 0..63: pair `tid` of the tile (clamped)
+      int32_t p = a + tile * T + (tid & (T - 1));
+      p = p < last ? p : last;
+      s_ = pair_src[p];
+      d_ = pair_dst[p];
+    };
+    auto gather = [&](int parity, f32x4 (&ra)[CT], f32x4 (&rb)[NT]) {
+      const int32_t src = sidx[parity][0][row], dst = sidx[parity][1][row];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int t = (ct0 + ct < ct_tiles) ? (ct0 + ct) : (ct_tiles - 1);
+        ra[ct] = *reinterpret_cast<const f32x4*>(in + (int64_t)src * cin + t * 16 + 4 * q);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rb[nt] = *reinterpret_cast<const f32x4*>(dout + (int64_t)dst * COUT + nt * 16 + 4 * q);
+    };
+
+    // prologue: indices of tiles 0 and 1, rows of tile 0
+    int32_t is_, id_;
+    load_idx(0, is_, id_);
+    if (tid < T) { sidx[0][0][tid] = is_; sidx[0][1][tid] = id_; }
+    load_idx(1, is_, id_);
+    __syncthreads();
+    f32x4 ra[CT], rb[NT];
+    gather(0, ra, rb);
+    if (tid < T) { sidx[1][0][tid] = is_; sidx[1][1][tid] = id_; }
+
+    for (int i = 0; i < n_pair_tiles; ++i) {
+      __syncthreads();  // the previous tile's fragment reads are done; sidx[(i+1)&1] is visible
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<f32x4*>(sA + row * PA + ct * 16 + 4 * q) = ra[ct];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(sB + row * PB + nt * 16 + 4 * q) = rb[nt];
+      gather((i + 1) & 1, ra, rb);  // rows of tile i+1 (clamped duplicates past the end): in flight during the contraction
+      load_idx(i + 2, is_, id_);
+      __syncthreads();  // tile i is in LDS
+      const int32_t p_base = a + i * T + wave * 16;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int pl = wave * 16 + st * 4 + g;  // pair of this lane in this k-step
+        const bool valid = p_base + st * 4 + g < b;
+        float bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = sB[pl * PB + nt * 16 + i16];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          float av = sA[pl * PA + ct * 16 + i16];
+          av = (valid && ct0 + ct < ct_tiles) ? av : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[ct][nt], 0, 0, 0);
+        }
+      }
+      if (tid < T) { sidx[i & 1][0][tid] = is_; sidx[i & 1][1][tid] = id_; }  // indices of tile i+2
+    }
+    __syncthreads();  // the tiles alias the reduction buffer below
+  }
+
+  // fixed-order reduction over the 4 waves through LDS (element (ct,nt,r,lane) -> red[((ct*NT+nt)*4+r)*64+lane])
+  float* red = smem;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* qd = red + ((ct * NT + nt) * 4 + r) * 64 + lane;
+            if (w == 0) *qd = acc[ct][nt][r];
+            else *qd += acc[ct][nt][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* pbase = partial + ((int64_t)s * K + k) * (int64_t)cin * COUT;
+  for (int e = tid; e < CT * NT * 256; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, tn = e >> 8;
+    const int nt = tn % NT, ct = tn / NT;
+    if (ct0 + ct >= ct_tiles) continue;
+    const int ci = (ct0 + ct) * 16 + 4 * (l >> 4) + r;
+    const int co = nt * 16 + (l & 15);
+    pbase[(int64_t)ci * COUT + co] = red[e];
+  }
+}
+
 // dW[e] = sum_s partial[s][e]: 16 lanes per element stride over the slices, then a fixed-order shuffle tree
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t elems,
                                                            int K, int cin, int cout, int oki,
@@ -189,7 +330,7 @@ int launch_wgrad(const float* in, const float* dout, const int32_t* pair_src, co
   const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
   const int ct_tiles = cin / 16;
   const int cig = (ct_tiles + CT - 1) / CT;
-  hipLaunchKernelGGL((spconv_wgrad_kernel<CT, NT>), dim3(K, S, cig), dim3(256), 0, stream, in, dout, pair_src,
+  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), dim3(K, S, cig), dim3(256), 0, stream, in, dout, pair_src,
                      pair_dst, tile_off, n_tiles, cin, S, partial);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
