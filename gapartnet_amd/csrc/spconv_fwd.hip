@@ -232,8 +232,11 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
   auto load_idx = [&](int u, uint32_t row) -> int32_t {
     return __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(row * 4u), (int)(u * col_bytes), 0));
   };
-  auto load_a = [&](int32_t idx, int cb, f32x4 (&a)[CW]) {  // the CW 64-byte pieces of one gathered row
-    const uint32_t off = idx < 0 ? 0x80000000u : ((uint32_t)idx * (uint32_t)cin + 4u * (uint32_t)g) * 4u;
+  // the CW 64-byte pieces of one gathered row; absent neighbours and rows past the end of the tensor read as zeros
+  // (out-of-range offset), so the MFMA operands need no select - a VALU op between two MFMAs of a dependent chain
+  // costs ~40 cycles on this core
+  auto load_a = [&](int32_t idx, bool row_valid, int cb, f32x4 (&a)[CW]) {
+    const uint32_t off = (idx < 0 || !row_valid) ? 0x80000000u : ((uint32_t)idx * (uint32_t)cin + 4u * (uint32_t)g) * 4u;
 #pragma unroll
     for (int c = 0; c < CW; ++c)
       a[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, (cb + c) * 64, 0));
@@ -256,8 +259,9 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
       const uint32_t rc = clamp_row(first);
 #pragma unroll
       for (int u = 0; u < KT; ++u) ireg[u] = load_idx(u, rc);
+      const bool ok_first = first * 16 + i16 < n_dst;
 #pragma unroll
-      for (int u = 0; u < D; ++u) load_a(ireg[u], cb, areg[u]);
+      for (int u = 0; u < D; ++u) load_a(ireg[u], ok_first, cb, areg[u]);
     }
     __syncthreads();
 
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
       const int64_t nxt = i + 1 < m ? cur + waves_per_xcd : cur;  // last tile: refills become harmless duplicates
       const int64_t row0 = cur * 16;
       const bool row_ok = row0 + i16 < n_dst;
+      const bool row_ok_next = nxt * 16 + i16 < n_dst;
       const uint32_t rc_next = clamp_row(nxt);
 
       f32x4 acc[NTW], prev[NTW];
@@ -285,12 +290,11 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
 
 #pragma unroll
       for (int u = 0; u < KT; ++u) {
-        const int32_t idx = row_ok ? ireg[u] : -1;
-        if (__builtin_amdgcn_ballot_w64(idx >= 0) != 0) {
+        // wave-uniform skip of taps no row of the tile has (64-bit compare mask straight into a scalar branch)
+        if (__builtin_amdgcn_sicmp(ireg[u], -1, 38 /* ICMP_SGT */) != 0) {
 #pragma unroll
           for (int c = 0; c < CW; ++c) {
-            f32x4 a = areg[u % D][c];
-            if (!row_ok) a = (f32x4){0.f, 0.f, 0.f, 0.f};  // rows past the end (absent neighbours already read as zeros)
+            const f32x4 a = areg[u % D][c];
             const f32x4* sb = slab + (u * CW + c) * (NTW * 64) + lane;
             f32x4 bf[NTW];
 #pragma unroll
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
         // slot u now belongs to the next tile; the gather D taps ahead uses this tile's column while u + D < KT and
         // the next tile's (refilled KT - D taps ago) after that - the same expression either way
         ireg[u] = load_idx(u, rc_next);
-        load_a(ireg[(u + D) % KT], cb, areg[u % D]);
+        load_a(ireg[(u + D) % KT], (u + D < KT) ? row_ok : row_ok_next, cb, areg[u % D]);
       }
 
 #pragma unroll
