@@ -390,6 +390,8 @@ class WgradWorker {
           }
         } else if (closed_.load(std::memory_order_acquire) && done == published_.load(std::memory_order_acquire)) {
           break;
+        } else {
+          std::this_thread::yield();  // nothing published yet: give the core away (8 ranks share the host's cores)
         }
       }
       finished_.store(true, std::memory_order_release);
