@@ -192,7 +192,7 @@ template <int NTW, int KT, int D, int CW>  // CW = 16-channel input blocks contr
 __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __restrict__ in,
                                                                 const float* __restrict__ packed,
                                                                 const int32_t* __restrict__ nbr, int64_t n_dst, int cin,
-                                                                int nt_total, int64_t tiles, float* __restrict__ out) {
+                                                                int nt_total, int64_t tiles, int cb_per_split, float* __restrict__ out_base) {
   static_assert(KT % D == 0, "ring slots are compile-time: the gather distance must divide the tap count");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4* slab = reinterpret_cast<f32x4*>(smem);  // [KT][CW][NTW][64 lanes]
@@ -217,6 +217,11 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
   const int cout = nt_total * 16;
   const int CB = cin >> 4;
   const f32x4* __restrict__ pw = reinterpret_cast<const f32x4*>(packed);
+  // mid-size levels (about one tile per wave) split the input blocks over grid.z: each slice is a single pass writing
+  // its own partial output (summed afterwards in slice order) instead of CB sequential passes with their start-ups
+  const int cb_lo = blockIdx.z * cb_per_split;
+  const int cb_hi = (cb_lo + cb_per_split < CB) ? (cb_lo + cb_per_split) : CB;
+  float* __restrict__ out = out_base + (int64_t)blockIdx.z * n_dst * cout;
 
   // Gathers and index reads are buffer loads: wave-uniform descriptor + 32-bit per-lane byte offset (one VGPR per
   // pending load, no per-lane 64-bit arithmetic), and an absent neighbour becomes an out-of-range offset, which the
@@ -242,8 +247,8 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
       a[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, (cb + c) * 64, 0));
   };
 
-  for (int cb = 0; cb < CB; cb += CW) {  // CW divides CB (host)
-    if (cb > 0) __syncthreads();  // every wave has finished its pass over the previous blocks' slab
+  for (int cb = cb_lo; cb < cb_hi; cb += CW) {  // CW divides CB and cb_per_split (host)
+    if (cb > cb_lo) __syncthreads();  // every wave has finished its pass over the previous blocks' slab
     for (int q = tid; q < KT * CW * NTW * 64; q += WPB * 64) {
       const int t = q / (CW * NTW * 64);
       const int rem = q - t * (CW * NTW * 64);
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
       f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};  // second accumulator of the NTW == 1 case
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}, prev[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (cb > 0) {  // partial sums of the earlier input blocks (issued now, consumed at the end of the tile)
+      if (cb > cb_lo) {  // partial sums of the earlier input blocks (issued now, consumed at the end of the tile)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t row = row0 + 4 * g + r;
@@ -424,6 +429,7 @@ int dispatch_cw(const FwdPlan& p, const float* in, const float* packed, const in
 struct StreamPlan {
   bool use;
   int ntw, groups;
+  int cw, cb_splits, cb_per_split;
 };
 
 StreamPlan plan_stream(int K, int64_t n_dst, int cin, int cout) {
@@ -435,11 +441,18 @@ StreamPlan plan_stream(int K, int64_t n_dst, int cin, int cout) {
   // output rows and the neighbour table must fit
   p.use = (K == 27 || K == 8) && gpn::cdiv(n_dst, 16) >= 1024 &&
           n_dst * (int64_t)8 * std::max(cin, cout) * 4 < ((int64_t)1 << 31) && (int64_t)K * n_dst * 4 < ((int64_t)1 << 31);
+  // two input blocks per pass when the slab allows it (K x 2 x ntw KiB <= 108): a 32-channel level is then one pass
+  const int CB = cin / 16;
+  p.cw = (CB % 2 == 0 && p.ntw <= 2) ? 2 : 1;
+  // fewer than ~2 tiles per wave slot: the passes over the input blocks run side by side (grid.z) into partial outputs
+  const int passes = CB / p.cw;
+  p.cb_splits = (gpn::cdiv(n_dst, 16) < 8192 && passes > 1) ? passes : 1;
+  p.cb_per_split = (passes / p.cb_splits) * p.cw;
   return p;
 }
 
 template <int NTW, int KT, int D, int CW>
-int launch_stream(int groups, const float* in, const float* packed, const int32_t* nbr, int64_t n_dst, int cin,
+int launch_stream(const StreamPlan& sp, const float* in, const float* packed, const int32_t* nbr, int64_t n_dst, int cin,
                   int nt_total, float* out, hipStream_t stream) {
   constexpr size_t lds = (size_t)KT * CW * NTW * 64 * 16;
   // persistent grid = (workgroups that are resident at once) x CUs: asked from the runtime once per instantiation
@@ -455,32 +468,33 @@ int launch_stream(int groups, const float* in, const float* packed, const int32_
     if (per_cu > 2) per_cu = 2;
     wgs = (cus * per_cu + 7) / 8 * 8;
   }
-  const dim3 grid((unsigned)wgs, (unsigned)groups, 1);
+  const dim3 grid((unsigned)wgs, (unsigned)sp.groups, (unsigned)sp.cb_splits);
   hipLaunchKernelGGL((spconv_fwd_stream_kernel<NTW, KT, D, CW>), grid, dim3(512), lds, stream, in, packed, nbr, n_dst, cin,
-                     nt_total, gpn::cdiv(n_dst, 16), out);
+                     nt_total, gpn::cdiv(n_dst, 16), sp.cb_per_split, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
 template <int NTW>
-int dispatch_stream(int groups, const float* in, const float* packed, const int32_t* nbr, int K, int64_t n_dst,
+int dispatch_stream(const StreamPlan& sp, const float* in, const float* packed, const int32_t* nbr, int K, int64_t n_dst,
                     int cin, int nt_total, float* out, hipStream_t stream) {
-  // two input blocks per pass when the slab allows it (K x 2 x ntw KiB <= 108): a 32-channel level is then a single pass
-  // (whole 128-byte rows gathered back to back, no read-modify-write of the output)
-  const bool two = (cin / 16) % 2 == 0 && NTW <= 2;
+  constexpr int CW2 = NTW <= 2 ? 2 : 1;  // (instantiated only where the slab fits)
   if (K == 27) {
-    if (two) return launch_stream<NTW, 27, 3, (NTW <= 2 ? 2 : 1)>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
-    return launch_stream<NTW, 27, 9, 1>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+    if (sp.cw == 2) return launch_stream<NTW, 27, 3, CW2>(sp, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+    return launch_stream<NTW, 27, 9, 1>(sp, in, packed, nbr, n_dst, cin, nt_total, out, stream);
   }
-  if (two) return launch_stream<NTW, 8, 4, (NTW <= 2 ? 2 : 1)>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
-  return launch_stream<NTW, 8, 8, 1>(groups, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+  if (sp.cw == 2) return launch_stream<NTW, 8, 4, CW2>(sp, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+  return launch_stream<NTW, 8, 8, 1>(sp, in, packed, nbr, n_dst, cin, nt_total, out, stream);
 }
 
 }  // namespace
 
 extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout) {
   if (n_dst <= 0 || cin < 16 || cout < 16) return 0;
-  if (plan_stream(K, n_dst, cin, cout).use) return 0;
+  {
+    const StreamPlan sp = plan_stream(K, n_dst, cin, cout);
+    if (sp.use) return sp.cb_splits > 1 ? gpn::align_up((size_t)sp.cb_splits * n_dst * cout * sizeof(float)) : 0;
+  }
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   return p.splits > 1 ? gpn::align_up((size_t)p.splits * n_dst * cout * sizeof(float)) : 0;
 }
@@ -495,13 +509,30 @@ extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int3
   const int nt = cout / 16;
   const StreamPlan sp = plan_stream(K, n_dst, cin, cout);
   if (sp.use) {
-    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
-    switch (sp.ntw) {
-      case 1: return dispatch_stream<1>(sp.groups, in, packed_w, nbr, K, n_dst, cin, nt, out, stream);
-      case 2: return dispatch_stream<2>(sp.groups, in, packed_w, nbr, K, n_dst, cin, nt, out, stream);
-      case 3: return dispatch_stream<3>(sp.groups, in, packed_w, nbr, K, n_dst, cin, nt, out, stream);
-      default: return dispatch_stream<4>(sp.groups, in, packed_w, nbr, K, n_dst, cin, nt, out, stream);
+    float* target = out;
+    if (sp.cb_splits > 1) {
+      if (!ws || ws_bytes < (size_t)sp.cb_splits * n_dst * cout * sizeof(float)) {
+        gpn::set_error("gpn_spconv_fwd: workspace too small for %d input-block slices", sp.cb_splits);
+        return GPN_ERR_WS;
+      }
+      target = static_cast<float*>(ws);
     }
+    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
+    int rc;
+    switch (sp.ntw) {
+      case 1: rc = dispatch_stream<1>(sp, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
+      case 2: rc = dispatch_stream<2>(sp, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
+      case 3: rc = dispatch_stream<3>(sp, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
+      default: rc = dispatch_stream<4>(sp, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
+    }
+    if (rc == GPN_OK && sp.cb_splits > 1) {
+      const int64_t elems4 = n_dst * cout / 4;
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)gpn::cdiv(elems4, 256)), dim3(256), 0, stream, target,
+                         sp.cb_splits, elems4, out);
+      hipError_t e_ = hipGetLastError();
+      if (e_ != hipSuccess) { gpn::set_error("gpn_spconv_fwd: reduce launch failed: %s", hipGetErrorString(e_)); rc = GPN_ERR_HIP; }
+    }
+    return rc;
   }
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   float* target = out;
