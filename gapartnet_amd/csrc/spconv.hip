@@ -36,121 +36,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int K, int cin_
 
 // ------------------------------------------------------------------------------------------------
 // wgrad: partial[s][k][ci][co] = sum over the s-th slice of pair list k of in[src][ci] * dout[dst][co]
-// grid = (K, S, CIG); 256 threads = 4 waves striding over 4-pair groups; fixed-order LDS reduction.
-template <int CT, int NT>
-__global__ __launch_bounds__(256) void spconv_wgrad_kernel(
-    const float* __restrict__ in, const float* __restrict__ dout, const int32_t* __restrict__ pair_src,
-    const int32_t* __restrict__ pair_dst, const int32_t* __restrict__ tile_off, int64_t n_tiles, int cin,
-    int S, float* __restrict__ partial) {
-  constexpr int COUT = NT * 16;
-  __shared__ float red[CT * NT * 256];
-  const int k = blockIdx.x, s = blockIdx.y, cig = blockIdx.z;
-  const int K = gridDim.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i16 = lane & 15, g = lane >> 4;
-  const int ct_tiles = cin >> 4;
-  const int ct0 = cig * CT;
-
-  const int32_t l_begin = tile_off[(int64_t)k * (n_tiles + 1)];
-  const int32_t l_end = tile_off[(int64_t)k * (n_tiles + 1) + n_tiles];
-  const int32_t len = l_end - l_begin;
-  int32_t chunk = (len + S - 1) / S;
-  chunk = (chunk + 3) & ~3;
-  const int32_t a = l_begin + s * chunk;
-  int32_t b = a + chunk;
-  if (b > l_end) b = l_end;
-
-  f32x4 acc[CT][NT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // branch-free 2-deep software pipeline (pair indices two trips ahead, gathered values one trip ahead): addresses
-  // are clamped instead of guarded so the compiler can count the loads (partial s_waitcnt vmcnt) - lane-divergent
-  // guards made every trip pay two full dependent memory latencies.  Out-of-range lanes are zeroed at use.
-  int32_t p0 = a + 4 * wave;
-  if (p0 < b) {
-    const int32_t last = b - 1;
-    auto ld_idx = [&](int32_t q0, int32_t& s_, int32_t& d_) {
-      int32_t q = q0 + g;
-      q = q < last ? q : last;
-      s_ = pair_src[q];
-      d_ = pair_dst[q];
-    };
-    auto ld_rows = [&](int32_t s_, int32_t d_, float (&av)[CT], float (&bv)[NT]) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const int t = (ct0 + ct < ct_tiles) ? (ct0 + ct) : (ct_tiles - 1);
-        av[ct] = in[(int64_t)s_ * cin + t * 16 + i16];
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bv[nt] = dout[(int64_t)d_ * COUT + nt * 16 + i16];
-    };
-    int32_t s0, d0, s1, d1;
-    float av0[CT], bv0[NT];
-    ld_idx(p0, s0, d0);
-    ld_idx(p0 + 16, s1, d1);
-    ld_rows(s0, d0, av0, bv0);
-    for (; p0 < b; p0 += 16) {
-      int32_t s2, d2;
-      ld_idx(p0 + 32, s2, d2);
-      float av1[CT], bv1[NT];
-      ld_rows(s1, d1, av1, bv1);
-      const bool valid = p0 + g < b;
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const float a_ = (valid && ct0 + ct < ct_tiles) ? av0[ct] : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bv0[nt], acc[ct][nt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) av0[ct] = av1[ct];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bv0[nt] = bv1[nt];
-      s1 = s2;
-      d1 = d2;
-    }
-  }
-
-  // fixed-order reduction over the 4 waves through LDS (element (ct,nt,r,lane) -> red[((ct*NT+nt)*4+r)*64+lane])
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* q = red + ((ct * NT + nt) * 4 + r) * 64 + lane;
-            if (w == 0) *q = acc[ct][nt][r];
-            else *q += acc[ct][nt][r];
-          }
-    }
-    __syncthreads();
-  }
-  // store: D[row = 4g + r][col = i16] -> ci = (ct0+ct)*16 + 4g + r, co = nt*16 + i16
-  float* pbase = partial + ((int64_t)s * K + k) * (int64_t)cin * COUT;
-  for (int e = threadIdx.x; e < CT * NT * 256; e += 256) {
-    const int l = e & 63, r = (e >> 6) & 3, tn = e >> 8;
-    const int nt = tn % NT, ct = tn / NT;
-    if (ct0 + ct >= ct_tiles) continue;
-    const int ci = (ct0 + ct) * 16 + 4 * (l >> 4) + r;
-    const int co = nt * 16 + (l & 15);
-    pbase[(int64_t)ci * COUT + co] = red[e];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// wgrad, LDS-staged form.  The kernel above feeds every MFMA with per-lane 4-byte gathers in the MFMA's own operand
-// layout (lane (i,g) = channel i of pair g): ~7 issued instructions per pair, so it is bound by instruction issue, not
-// by the matrix pipe (10-18 TFLOP/s).  Here a workgroup stages 64 pairs at a time: thread (row = t/4, q = t%4) gathers
+// grid = (K, S, CIG); 256 threads = 4 waves; fixed-order LDS reduction over the waves, fixed-order reduce over slices.
+// LDS-staged: feeding every MFMA with per-lane 4-byte gathers in the MFMA's own operand layout (lane (i,g) = channel
+// i of pair g) costs ~7 issued instructions per pair and is bound by instruction issue, not by the matrix pipe
+// (10-18 TFLOP/s measured).  Here a workgroup stages 64 pairs at a time: thread (row = t/4, q = t%4) gathers
 // 16-byte pieces of in[src[row]] and dout[dst[row]] (whole 64-byte pieces per 4 threads), the rows go through registers
 // into LDS tiles ([pair][channel], pitch chosen so that the strided fragment reads below are bank-conflict free), and
 // each wave contracts 16 of the 64 pairs: per k-step (4 pairs) CT + NT ds_read_b32 feed CT x NT MFMAs.  The gathers of
 // tile i+1 and the pair indices of tile i+2 are in flight while tile i is contracted.
-// Same grid, same (tap, slice) partial layout and the same fixed-order reductions as above: deterministic.
+// Fixed assignment of pairs to waves and fixed-order reductions: deterministic.
 template <int W>
 struct LdsPitch {  // floats per LDS row for W payload floats: pitch % 64 in {16, 48} => rows g, g+1, g+2, g+3 hit distinct banks
   static constexpr int value = (W % 64 == 16 || W % 64 == 48) ? W : ((W + 16) % 64 == 16 || (W + 16) % 64 == 48) ? W + 16 : W + 32;

@@ -81,7 +81,6 @@ def sparse_conv(features: torch.Tensor, weight: torch.Tensor, rb, rb_t, reverse_
 
 
 _IDENTITY_RULEBOOKS = {}
-_AB_TORCH_LINEAR = bool(int(__import__('os').environ.get('GPN_AB_TORCH_LINEAR', '0')))  # A/B switch for tools/
 
 
 def _identity_rulebook(n: int, device):
@@ -137,7 +136,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     the framework dispatches to run at 0.2-0.4 TFLOP/s (fwd+bwd 260-380 us per layer vs 200-250 here).
     Falls back to F.linear for shapes the kernels do not cover."""
     if (backend.raw().name != "hip" or not x.is_cuda or x.dim() != 2 or x.shape[1] % 16 != 0 or x.shape[0] < 4096
-            or x.dtype != torch.float32 or _AB_TORCH_LINEAR):
+            or x.dtype != torch.float32):
         return F.linear(x, weight, bias)
     return _LinearFn.apply(x, weight, bias)
 
