@@ -275,8 +275,8 @@ extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_
     if (op.kind == GPN_NET_CONV) {
       const gpn_net_rulebook_t& rb = rbs[op.rulebook];
       const gpn_net_conv_t& cv = convs[op.param];
-      rc = gpn_spconv_fwd(s0.data, packed_of[i], rb.nbr, rb.K, rb.n_dst, cv.cin, cv.cout, d.data, op_ws, op_ws_bytes,
-                          stream_);
+      rc = gpn_spconv_fwd_ordered(s0.data, packed_of[i], rb.nbr, rb.nbr_p, rb.perm, rb.K, rb.n_dst, cv.cin, cv.cout, d.data,
+                                  op_ws, op_ws_bytes, stream_);
     } else if (op.kind == GPN_NET_BN) {
       const gpn_net_bn_t& bn = bns[op.param];
       const float* res = op.src1 >= 0 ? slots[op.src1].data : nullptr;
@@ -523,8 +523,8 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
           return GPN_ERR_ARG;
         }
         GradTarget t = grad_target(s0, tmp);
-        rc = gpn_spconv_fwd(d.grad, packed_of[i], rb.nbr_t, rb.K, rb.n_src, cv.cout, cv.cin, t.ptr, op_ws, op_ws_bytes,
-                            stream_);
+        rc = gpn_spconv_fwd_ordered(d.grad, packed_of[i], rb.nbr_t, rb.nbr_t_p, rb.perm_t, rb.K, rb.n_src, cv.cout, cv.cin,
+                                    t.ptr, op_ws, op_ws_bytes, stream_);
         if (rc) return rc;
         rc = commit(s0, t, stream);
         if (rc) return rc;

@@ -192,7 +192,8 @@ template <int NTW, int KT, int D, int CW>  // CW = 16-channel input blocks contr
 __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __restrict__ in,
                                                                 const float* __restrict__ packed,
                                                                 const int32_t* __restrict__ nbr, int64_t n_dst, int cin,
-                                                                int nt_total, int64_t tiles, int cb_per_split, float* __restrict__ out_base) {
+                                                                int nt_total, int64_t tiles, int cb_per_split, const int32_t* __restrict__ perm,
+                                                                float* __restrict__ out_base) {
   static_assert(KT % D == 0, "ring slots are compile-time: the gather distance must divide the tap count");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4* slab = reinterpret_cast<f32x4*>(smem);  // [KT][CW][NTW][64 lanes]
@@ -278,6 +279,19 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
       const bool row_ok_next = nxt * 16 + i16 < n_dst;
       const uint32_t rc_next = clamp_row(nxt);
 
+      // destination rows of this lane's accumulator fragment: tile positions row0 + 4g + r, or the rows the rulebook's
+      // tile order maps them to (`nbr` is then the table in that order; perm is padded past n_dst)
+      int32_t orow[4];
+      if (perm) {
+        const int4 pv = *reinterpret_cast<const int4*>(perm + row0 + 4 * g);
+        orow[0] = pv.x, orow[1] = pv.y, orow[2] = pv.z, orow[3] = pv.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + 4 * g + r;
+          orow[r] = (int32_t)(row < n_dst ? row : n_dst - 1);
+        }
+      }
       f32x4 acc[NTW], prev[NTW];
       f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};  // second accumulator of the NTW == 1 case
 #pragma unroll
@@ -285,8 +299,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
       if (cb > cb_lo) {  // partial sums of the earlier input blocks (issued now, consumed at the end of the tile)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = row0 + 4 * g + r;
-          const uint32_t rr = (uint32_t)(row < n_dst ? row : n_dst - 1);
+          const uint32_t rr = (uint32_t)orow[r];
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt)
             prev[nt][r] = out[rr * (uint32_t)cout + (uint32_t)((nt0 + (nt < ntw ? nt : 0)) * 16 + i16)];
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __r
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt)
             if (nt < ntw)
-              out[(uint32_t)row * (uint32_t)cout + (uint32_t)((nt0 + nt) * 16 + i16)] =
+              out[(uint32_t)orow[r] * (uint32_t)cout + (uint32_t)((nt0 + nt) * 16 + i16)] =
                   (NTW == 1 && CW == 1 ? acc[nt][r] + acc2[r] : acc[nt][r]) + prev[nt][r];
         }
       }
@@ -452,8 +465,8 @@ StreamPlan plan_stream(int K, int64_t n_dst, int cin, int cout) {
 }
 
 template <int NTW, int KT, int D, int CW>
-int launch_stream(const StreamPlan& sp, const float* in, const float* packed, const int32_t* nbr, int64_t n_dst, int cin,
-                  int nt_total, float* out, hipStream_t stream) {
+int launch_stream(const StreamPlan& sp, const float* in, const float* packed, const int32_t* nbr, const int32_t* perm,
+                  int64_t n_dst, int cin, int nt_total, float* out, hipStream_t stream) {
   constexpr size_t lds = (size_t)KT * CW * NTW * 64 * 16;
   // persistent grid = (workgroups that are resident at once) x CUs: asked from the runtime once per instantiation
   static int wgs = 0;
@@ -470,21 +483,21 @@ int launch_stream(const StreamPlan& sp, const float* in, const float* packed, co
   }
   const dim3 grid((unsigned)wgs, (unsigned)sp.groups, (unsigned)sp.cb_splits);
   hipLaunchKernelGGL((spconv_fwd_stream_kernel<NTW, KT, D, CW>), grid, dim3(512), lds, stream, in, packed, nbr, n_dst, cin,
-                     nt_total, gpn::cdiv(n_dst, 16), sp.cb_per_split, out);
+                     nt_total, gpn::cdiv(n_dst, 16), sp.cb_per_split, perm, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
 template <int NTW>
-int dispatch_stream(const StreamPlan& sp, const float* in, const float* packed, const int32_t* nbr, int K, int64_t n_dst,
-                    int cin, int nt_total, float* out, hipStream_t stream) {
+int dispatch_stream(const StreamPlan& sp, const float* in, const float* packed, const int32_t* nbr, const int32_t* perm,
+                    int K, int64_t n_dst, int cin, int nt_total, float* out, hipStream_t stream) {
   constexpr int CW2 = NTW <= 2 ? 2 : 1;  // (instantiated only where the slab fits)
   if (K == 27) {
-    if (sp.cw == 2) return launch_stream<NTW, 27, 3, CW2>(sp, in, packed, nbr, n_dst, cin, nt_total, out, stream);
-    return launch_stream<NTW, 27, 9, 1>(sp, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+    if (sp.cw == 2) return launch_stream<NTW, 27, 3, CW2>(sp, in, packed, nbr, perm, n_dst, cin, nt_total, out, stream);
+    return launch_stream<NTW, 27, 9, 1>(sp, in, packed, nbr, perm, n_dst, cin, nt_total, out, stream);
   }
-  if (sp.cw == 2) return launch_stream<NTW, 8, 4, CW2>(sp, in, packed, nbr, n_dst, cin, nt_total, out, stream);
-  return launch_stream<NTW, 8, 8, 1>(sp, in, packed, nbr, n_dst, cin, nt_total, out, stream);
+  if (sp.cw == 2) return launch_stream<NTW, 8, 4, CW2>(sp, in, packed, nbr, perm, n_dst, cin, nt_total, out, stream);
+  return launch_stream<NTW, 8, 8, 1>(sp, in, packed, nbr, perm, n_dst, cin, nt_total, out, stream);
 }
 
 }  // namespace
@@ -499,9 +512,11 @@ extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cou
   return p.splits > 1 ? gpn::align_up((size_t)p.splits * n_dst * cout * sizeof(float)) : 0;
 }
 
-extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* nbr, int K, int64_t n_dst,
-                              int cin, int cout, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+extern "C" int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p,
+                                      const int32_t* perm, int K, int64_t n_dst, int cin, int cout, float* out,
+                                      void* ws, size_t ws_bytes, gpn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG((nbr_p == nullptr) == (perm == nullptr));
   GPN_CHECK_ARG(K >= 1 && n_dst >= 0);
   GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
   if (n_dst == 0) return GPN_OK;
@@ -520,10 +535,10 @@ extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int3
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
     int rc;
     switch (sp.ntw) {
-      case 1: rc = dispatch_stream<1>(sp, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
-      case 2: rc = dispatch_stream<2>(sp, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
-      case 3: rc = dispatch_stream<3>(sp, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
-      default: rc = dispatch_stream<4>(sp, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
+      case 1: rc = dispatch_stream<1>(sp, in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, nt, target, stream); break;
+      case 2: rc = dispatch_stream<2>(sp, in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, nt, target, stream); break;
+      case 3: rc = dispatch_stream<3>(sp, in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, nt, target, stream); break;
+      default: rc = dispatch_stream<4>(sp, in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, nt, target, stream); break;
     }
     if (rc == GPN_OK && sp.cb_splits > 1) {
       const int64_t elems4 = n_dst * cout / 4;
@@ -561,6 +576,11 @@ extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int3
     }
   }
   return rc;
+}
+
+extern "C" int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* nbr, int K, int64_t n_dst,
+                              int cin, int cout, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream) {
+  return gpn_spconv_fwd_ordered(in, packed_w, nbr, nullptr, nullptr, K, n_dst, cin, cout, out, ws, ws_bytes, stream);
 }
 
 // One-call form used by the host wrapper: packs the weight (canonical or parameter layout, optional transpose /

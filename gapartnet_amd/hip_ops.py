@@ -73,6 +73,10 @@ class Rulebook:
     n_dst: int
     num_pairs: torch.Tensor  # 0-dim int64 on device (no host sync)
     nbr: Optional[torch.Tensor] = None  # tap-major neighbour table [K*n_dst + 1] i32 (-1 = none) the fused conv gathers from
+    # optional tile order of the large levels (gpn_rulebook_tile_order): the table with its columns sorted by neighbour
+    # mask inside 4096-row blocks, and the destination row of every tile position
+    nbr_p: Optional[torch.Tensor] = None
+    perm: Optional[torch.Tensor] = None
 
     def pairs_host(self) -> int:
         return int(self.num_pairs.item())
@@ -134,7 +138,26 @@ def rulebook_subm3(indices, spatial_shape) -> Rulebook:
     nbr = torch.empty((27 * N + 1,), dtype=torch.int32, device=dev)
     check(L.gpn_rulebook_subm3(ptr(indices), i64(N), host_i32x3(spatial_shape), ptr(nbr), ptr(src), ptr(dst), ptr(toff),
                                ptr(npairs), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_subm3")
-    return Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr)
+    rb = Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr)
+    if N >= TILE_ORDER_MIN_ROWS:
+        rb.perm, rb.nbr_p = tile_order(nbr, 27, N)
+    return rb
+
+
+TILE_ORDER_MIN_ROWS = 16384  # levels served by the persistent conv kernel (>= 1024 tiles)
+TILE_ORDER_BLOCK = 4096
+
+
+def tile_order(nbr, K, n):
+    """-> (perm [ceil(n/16)*16 + 16] i32, nbr_p [K*n + 1] i32): rows of every 4096-row block sorted by neighbour mask"""
+    dev = nbr.device
+    L = _C.lib()
+    perm = torch.empty(((n + 15) // 16 * 16 + 16,), dtype=torch.int32, device=dev)
+    nbr_p = torch.empty((K * n + 1,), dtype=torch.int32, device=dev)
+    ws = _ws(L.gpn_rulebook_tile_order_ws_bytes(i64(n)), dev)
+    check(L.gpn_rulebook_tile_order(ptr(nbr), i32(K), i64(n), i32(TILE_ORDER_BLOCK), ptr(perm), ptr(nbr_p), ptr(ws),
+                                    szt(ws.numel()), _stream()), "gpn_rulebook_tile_order")
+    return perm, nbr_p
 
 
 def rulebook_down(indices, spatial_shape, batch_size):

@@ -24,7 +24,8 @@ from ..spconv import pytorch as spconv
 
 # numpy mirrors of the C structs in include/gpn.h (sizes are checked against the header in tests/test_cabi.py)
 SLOT_DT = np.dtype([("data", "<u8"), ("grad", "<u8"), ("rows", "<i8"), ("channels", "<i4"), ("grad_state", "<i4")])
-RB_DT = np.dtype([("nbr", "<u8"), ("nbr_t", "<u8"), ("pair_src", "<u8"), ("pair_dst", "<u8"), ("tile_off", "<u8"),
+RB_DT = np.dtype([("nbr", "<u8"), ("nbr_t", "<u8"), ("nbr_p", "<u8"), ("perm", "<u8"), ("nbr_t_p", "<u8"), ("perm_t", "<u8"),
+                  ("pair_src", "<u8"), ("pair_dst", "<u8"), ("tile_off", "<u8"),
                   ("n_src", "<i8"), ("n_dst", "<i8"), ("K", "<i4"), ("reverse_taps", "<i4")])
 CONV_DT = np.dtype([("W", "<u8"), ("dW", "<u8"), ("cin", "<i4"), ("cout", "<i4")])
 BN_DT = np.dtype([("weight", "<u8"), ("bias", "<u8"), ("running_mean", "<u8"), ("running_var", "<u8"),
@@ -224,8 +225,11 @@ class NetProgram:
                     rb = spconv._identity_rulebook(n, x.features.device)
                     x.indice_dict[ikey] = rb
                 rb_t, rev = rb, 0
-            table[i] = (rb.nbr.data_ptr(), rb_t.nbr.data_ptr(), rb.pair_src.data_ptr(), rb.pair_dst.data_ptr(),
-                        rb.tile_off.data_ptr(), rb.n_src, rb.n_dst, rb.K, rev)
+            def opt(t):
+                return 0 if t is None else t.data_ptr()
+            table[i] = (rb.nbr.data_ptr(), rb_t.nbr.data_ptr(), opt(rb.nbr_p), opt(rb.perm), opt(rb_t.nbr_p), opt(rb_t.perm),
+                        rb.pair_src.data_ptr(), rb.pair_dst.data_ptr(), rb.tile_off.data_ptr(), rb.n_src, rb.n_dst, rb.K,
+                        rev)
             objs.append((rb, rb_t))
         return rows, table, objs, levels
 

@@ -105,6 +105,12 @@ int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32_t* spatial
                        int32_t* pair_src, int32_t* pair_dst, int32_t* tile_off, int64_t* num_pairs,
                        void* ws, size_t ws_bytes, gpn_stream_t stream);
 
+/* tile order for the fused conv (optional, large levels): rows of every block of block_rows (power of two) consecutive
+ * rows sorted by their neighbour mask (which of the K <= 32 taps exist), stable.  perm [ceil(n/16)*16 + 16] i32 (padding
+ * = n-1), nbr_p [K*n + 1] i32 = nbr with its columns in that order. */
+size_t gpn_rulebook_tile_order_ws_bytes(int64_t n);
+int gpn_rulebook_tile_order(const int32_t* nbr, int K, int64_t n, int block_rows, int32_t* perm, int32_t* nbr_p,
+                            void* ws, size_t ws_bytes, gpn_stream_t stream);
 /* k=2 stride=2 down-conv.  out shape = floor(D/2) per axis; inputs mapping outside are dropped.
  * Produces the coarse index set (ascending linear key; capacity N rows), fine_to_coarse [N] i32
  * (-1 = dropped), tap [N] i32 = (x&1)*4+(y&1)*2+(z&1), num_out [1] i64.
@@ -145,6 +151,12 @@ size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout);
 int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* nbr, int K, int64_t n_dst, int cin,
                    int cout, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream);
 /* pack + conv in one call (packed copy lives in the head of ws); cin_w/cout_w are the STORED weight's dims */
+/* the same conv over a rulebook that carries a TILE ORDER (gpn_rulebook_tile_order): nbr_p = the neighbour table in
+ * that order, perm = the destination row of every tile position.  Results are identical (a row's taps are summed in
+ * the same order); tiles whose rows share their neighbour mask simply skip more taps.  nbr_p / perm may both be NULL. */
+int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p,
+                           const int32_t* perm, int K, int64_t n_dst, int cin, int cout, float* out, void* ws,
+                           size_t ws_bytes, gpn_stream_t stream);
 size_t gpn_spconv_fwd_w_ws_bytes(int K, int64_t n_dst, int cin, int cout);
 int gpn_spconv_fwd_w(const float* in, const float* W, int K, int cin_w, int cout_w, int pack_flags, const int32_t* nbr,
                      int64_t n_dst, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream);
@@ -205,6 +217,10 @@ typedef struct gpn_net_slot {
 typedef struct gpn_net_rulebook {
   const int32_t* nbr;   /* [K][n_dst]  forward table */
   const int32_t* nbr_t; /* [K][n_src]  table of the transposed map */
+  const int32_t* nbr_p;   /* optional tile order of the forward map (gpn_rulebook_tile_order): table ... */
+  const int32_t* perm;    /* ... and destination rows; both NULL if absent */
+  const int32_t* nbr_t_p; /* the same for the transposed map */
+  const int32_t* perm_t;
   const int32_t* pair_src;
   const int32_t* pair_dst;
   const int32_t* tile_off;

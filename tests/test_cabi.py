@@ -76,8 +76,8 @@ def test_executor_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "sizes.c"
     fields = {
         "gpn_net_slot_t": (NX.SLOT_DT, ["data", "grad", "rows", "channels", "grad_state"]),
-        "gpn_net_rulebook_t": (NX.RB_DT, ["nbr", "nbr_t", "pair_src", "pair_dst", "tile_off", "n_src", "n_dst", "K",
-                                          "reverse_taps"]),
+        "gpn_net_rulebook_t": (NX.RB_DT, ["nbr", "nbr_t", "nbr_p", "perm", "nbr_t_p", "perm_t", "pair_src", "pair_dst",
+                                          "tile_off", "n_src", "n_dst", "K", "reverse_taps"]),
         "gpn_net_conv_t": (NX.CONV_DT, ["W", "dW", "cin", "cout"]),
         "gpn_net_bn_t": (NX.BN_DT, ["weight", "bias", "running_mean", "running_var", "save_mean", "save_invstd",
                                     "dweight", "dbias", "eps", "momentum", "C", "reserved"]),

@@ -396,3 +396,39 @@ def test_grid_ball_query_is_bit_exact(H, cuda, case):
     assert np.array_equal(host(idx), ref_idx)
     if case == "dense":
         assert (ref_cnt == K).mean() > 0.5, "the dense case must exercise truncation"
+
+
+def test_tile_ordered_conv_is_bit_equal(H, cuda):
+    """the rulebook's tile order (rows sorted by neighbour mask inside 4096-row blocks) changes which taps a tile skips,
+    not a single output bit: forward and dgrad through (nbr_p, perm) == through the plain table"""
+    import ctypes
+    from gapartnet_amd import _C
+    rng = np.random.default_rng(5)
+    shape = [160, 160, 160]
+    idx = dev(synth.surface_indices(rng, 4, shape, 9000), cuda)
+    n = idx.shape[0]
+    assert n >= H.TILE_ORDER_MIN_ROWS
+    rb = H.rulebook_subm3(idx, shape)
+    assert rb.perm is not None and rb.nbr_p is not None
+    perm = rb.perm[:n].long()
+    assert torch.equal(torch.sort(perm)[0], torch.arange(n, device=cuda)), "perm is a permutation"
+    assert torch.equal(rb.nbr_p[:27 * n].view(27, n), rb.nbr[:27 * n].view(27, n)[:, perm])
+    blocks = perm // H.TILE_ORDER_BLOCK
+    assert torch.equal(blocks, torch.sort(blocks)[0]), "rows stay inside their 4096-row block"
+    L = _C.lib()
+    for cin, cout in ((16, 16), (32, 32), (48, 48)):
+        x = dev(rng.normal(size=(n, cin)).astype(np.float32), cuda)
+        w = dev((rng.normal(size=(27, cin, cout)) / 20).astype(np.float32), cuda)
+        packed = H.pack_weights(w, 0)
+        outs = []
+        for ordered in (False, True):
+            out = torch.empty((n, cout), dtype=torch.float32, device=cuda)
+            ws = torch.empty((64 << 20,), dtype=torch.uint8, device=cuda)
+            rc = L.gpn_spconv_fwd_ordered(
+                H.ptr(x), H.ptr(packed), H.ptr(rb.nbr), H.ptr(rb.nbr_p if ordered else None),
+                H.ptr(rb.perm if ordered else None), H.i32(27), H.i64(n), H.i32(cin), H.i32(cout), H.ptr(out), H.ptr(ws),
+                H.szt(ws.numel()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, L.gpn_last_error()
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (cin, cout)
+        assert torch.equal(outs[0], H.conv_fwd(x, w, rb))
