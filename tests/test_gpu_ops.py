@@ -419,6 +419,19 @@ def test_tile_ordered_conv_is_bit_equal(H, cuda):
     for cin, cout in ((16, 16), (32, 32), (48, 48)):
         x = dev(rng.normal(size=(n, cin)).astype(np.float32), cuda)
         w = dev((rng.normal(size=(27, cin, cout)) / 20).astype(np.float32), cuda)
+        for flags in (0, H.PACK_TRANSPOSE | H.PACK_REVERSE):  # forward, and dgrad (same table, reversed transposed weights)
+            packed = H.pack_weights(w, flags)
+            outs = []
+            for ordered in (False, True):
+                out = torch.empty((n, cout), dtype=torch.float32, device=cuda)
+                ws = torch.empty((64 << 20,), dtype=torch.uint8, device=cuda)
+                rc = L.gpn_spconv_fwd_ordered(
+                    H.ptr(x), H.ptr(packed), H.ptr(rb.nbr), H.ptr(rb.nbr_p if ordered else None),
+                    H.ptr(rb.perm if ordered else None), H.i32(27), H.i64(n), H.i32(cin), H.i32(cout), H.ptr(out),
+                    H.ptr(ws), H.szt(ws.numel()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                assert rc == 0, L.gpn_last_error()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), (cin, cout, flags)
         packed = H.pack_weights(w, 0)
         outs = []
         for ordered in (False, True):
