@@ -88,7 +88,17 @@ def roofline_from_profile(device):
     for kid, label in names.items():
         launches, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         _C.check(lib.gpn_prof_get(kid, ctypes.byref(launches), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
-        out[kid] = dict(kernel=label, launches=int(launches.value), ms=float(ms.value), flops=work[kid][0], bytes=work[kid][1])
+        out[kid] = dict(kernel=label, launches=int(launches.value), ms_raw=float(ms.value), flops=work[kid][0],
+                        bytes=work[kid][1])
+    # a (start event, launch, stop event) bracket adds a fixed cost to every launch (dispatch latency + two timestamp
+    # packets): measured around an empty kernel on the same stream and subtracted, so that the durations agree with a
+    # profiler's kernel durations (profiles/r01_bench_kernel_stats.csv)
+    overhead = ctypes.c_double()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _C.check(lib.gpn_prof_bracket_overhead_us(stream, ctypes.byref(overhead)))
+    for v in out.values():
+        v["bracket_overhead_us"] = float(overhead.value)
+        v["ms"] = max(v["ms_raw"] - v["launches"] * overhead.value * 1e-3, 0.0)
     return out
 
 
@@ -172,6 +182,8 @@ def main():
             roof = dict(bound="mfma", kernel=dom["kernel"], achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=measured_traffic(), launches=dom["launches"],
                         avg_launch_us=dom["ms"] * 1e3 / dom["launches"],
+                        avg_launch_us_raw_events=dom["ms_raw"] * 1e3 / dom["launches"],
+                        event_bracket_overhead_us=dom["bracket_overhead_us"],
                         algorithmic_gbs=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
                         hbm_frac=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         all_kernels={v["kernel"]: dict(ms=v["ms"], launches=v["launches"],

@@ -1,5 +1,6 @@
 // gpn_core.hip — error reporting, entry-point registry and the in-library hipEvent profiler.
 #include <cstdarg>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -29,7 +30,7 @@ const char* kEntryPoints[] = {
     "gpn_instance_iou", "gpn_nms", "gpn_nms_ws_bytes", "gpn_pn2_ball_query", "gpn_pn2_group_points",
     "gpn_pn2_group_points_grad", "gpn_pn2_gather_points", "gpn_pn2_gather_points_grad",
     "gpn_pn2_furthest_point_sampling", "gpn_pn2_three_nn", "gpn_pn2_knn", "gpn_pn2_three_interpolate",
-    "gpn_pn2_three_interpolate_grad", "gpn_prof_enable", "gpn_prof_reset", "gpn_prof_get",
+    "gpn_pn2_three_interpolate_grad", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get",
     "gpn_last_error", "gpn_version"};
 }  // namespace
 
@@ -66,6 +67,36 @@ int gpn_version(void) { return 1; }
 int gpn_num_entry_points(void) { return (int)(sizeof(kEntryPoints) / sizeof(kEntryPoints[0])); }
 const char* gpn_entry_point_name(int i) {
   return (i >= 0 && i < gpn_num_entry_points()) ? kEntryPoints[i] : nullptr;
+}
+
+// fixed cost a (start event, launch, stop event) bracket adds to any kernel: measured around an empty kernel on the given
+// stream (median of 33 brackets), so that callers can subtract it from hipEvent-measured launch durations
+__global__ void gpn_prof_noop_kernel() {}
+
+int gpn_prof_bracket_overhead_us(gpn_stream_t stream_, double* overhead_us) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(overhead_us != nullptr);
+  constexpr int kReps = 33;
+  hipEvent_t a[kReps], b[kReps];
+  for (int i = 0; i < kReps; ++i) {
+    GPN_CHECK_HIP(hipEventCreate(&a[i]));
+    GPN_CHECK_HIP(hipEventCreate(&b[i]));
+  }
+  for (int i = 0; i < kReps; ++i) {
+    GPN_CHECK_HIP(hipEventRecord(a[i], stream));
+    hipLaunchKernelGGL(gpn_prof_noop_kernel, dim3(1), dim3(64), 0, stream);
+    GPN_CHECK_HIP(hipEventRecord(b[i], stream));
+  }
+  GPN_CHECK_HIP(hipEventSynchronize(b[kReps - 1]));
+  float t[kReps];
+  for (int i = 0; i < kReps; ++i) {
+    GPN_CHECK_HIP(hipEventElapsedTime(&t[i], a[i], b[i]));
+    hipEventDestroy(a[i]);
+    hipEventDestroy(b[i]);
+  }
+  std::sort(t, t + kReps);
+  *overhead_us = (double)t[kReps / 2] * 1e3;
+  return GPN_OK;
 }
 
 int gpn_prof_enable(int on) {

@@ -49,6 +49,9 @@ enum {
   GPN_K_CCL = 5,
   GPN_K_COUNT = 6
 };
+/* fixed cost of a (start event, launch, stop event) bracket, measured around an empty kernel on `stream` (median, us):
+ * subtract it from hipEvent-measured launch durations before comparing them with a profiler's kernel durations. */
+int gpn_prof_bracket_overhead_us(gpn_stream_t stream, double* overhead_us);
 int gpn_prof_enable(int on);
 int gpn_prof_reset(void);
 /* synchronises the recorded events; returns launches, total milliseconds, algorithmic flops and bytes */
