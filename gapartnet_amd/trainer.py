@@ -27,14 +27,18 @@ def init_distributed(device_type: str = "cuda"):
     """-> (rank, local_rank, world_size, device).  Initialises the process group when WORLD_SIZE > 1."""
     rank, local_rank, world = distributed_env()
     use_cuda = device_type == "cuda" and torch.cuda.is_available()
-    device = torch.device(f"cuda:{local_rank}") if use_cuda else torch.device("cpu")
+    # GPN_DIST_SHARE_DEVICE=1 (test rigs with fewer GPUs than ranks): every rank on cuda:0 and gloo instead of RCCL, which
+    # refuses two ranks on one device - exercises the multi-rank code path, not its performance
+    share = use_cuda and os.environ.get("GPN_DIST_SHARE_DEVICE") == "1"
+    device = torch.device(f"cuda:{0 if share else local_rank}") if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl" if use_cuda else "gloo", rank=rank, world_size=world,
-                                **({"device_id": device} if use_cuda else {}))
+        nccl = use_cuda and not share
+        dist.init_process_group(backend="nccl" if nccl else "gloo", rank=rank, world_size=world,
+                                **({"device_id": device} if nccl else {}))
     return rank, local_rank, world, device
 
 

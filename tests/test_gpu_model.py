@@ -206,3 +206,26 @@ def test_device_prefetcher_feeds_identical_steps(cuda):
     assert torch.equal(results[0][0], results[1][0]), (results[0][0], results[1][0])
     for a, b in zip(results[0][1], results[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_shares_one_device(cuda):
+    """bench.py's multi-rank path (DDP over the executor's single backward node, device prefetcher, per-rank scene shards,
+    max-over-ranks timing) with two ranks time-slicing ONE GPU over gloo (GPN_DIST_SHARE_DEVICE): the code path the driver
+    runs at N = 2/4/8 over RCCL, minus the performance"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPN_DIST_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--points", "6000", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config"]["global_batch"] == 4
