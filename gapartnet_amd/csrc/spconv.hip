@@ -359,7 +359,7 @@ extern "C" int gpn_scatter_rows_csr(const float* dout, const int32_t* order, con
   hipStream_t stream = (hipStream_t)stream_;
   GPN_CHECK_ARG(n_rows >= 0 && C >= 1);
   if (n_rows == 0) return GPN_OK;
-  GPN_CHECK_ARG(dout && order && starts && dtable);
+  GPN_CHECK_ARG(starts && dtable);  // dout / order may be NULL when no point exists (every starts[r] is then 0)
   hipLaunchKernelGGL(scatter_rows_csr_kernel, dim3((int)gpn::cdiv(n_rows * C, 256)), dim3(256), 0, stream, dout,
                      order, starts, n_rows, C, dtable);
   GPN_CHECK_LAUNCH();

@@ -445,3 +445,49 @@ def test_tile_ordered_conv_is_bit_equal(H, cuda):
             outs.append(out)
         assert torch.equal(outs[0], outs[1]), (cin, cout)
         assert torch.equal(outs[0], H.conv_fwd(x, w, rb))
+
+
+def test_empty_and_degenerate_inputs(H, cuda):
+    """zero-sized inputs through every operator of the path: same shapes / values as the oracle, no launch errors"""
+    f32, i32, i64 = np.float32, np.int32, np.int64
+    e3 = np.zeros((0, 3), f32)
+    # V: no points (one empty segment)
+    got = H.voxelize(dev(e3, cuda), dev(np.zeros((0, 4), f32), cuda), dev(np.array([0, 0], i64), cuda),
+                     dev(np.zeros((1, 3), f32), cuda), dev(np.ones((1, 3), f32), cuda), [0.1] * 3, [11] * 3)
+    assert got[0].shape == (0, 4) and got[1].shape == (0, 3) and got[3].shape == (0,)
+    # K1 / K2: no voxels
+    idx0 = dev(np.zeros((0, 4), i32), cuda)
+    rb = H.rulebook_subm3(idx0, [8, 8, 8])
+    assert rb.n_dst == 0 and int(rb.num_pairs.item()) == 0
+    out_idx, out_shape, rb_f, rb_b = H.rulebook_down(idx0, [8, 8, 8], 1)
+    assert out_idx.shape == (0, 4) and out_shape == [4, 4, 4] and rb_f.n_dst == 0
+    # C: a conv over nothing, and over one isolated voxel (only the centre tap exists)
+    w = dev(np.ones((27, 16, 16), f32), cuda)
+    assert H.conv_fwd(dev(np.zeros((0, 16), f32), cuda), w, rb).shape == (0, 16)
+    one = dev(np.array([[0, 3, 3, 3]], i32), cuda)
+    rb1 = H.rulebook_subm3(one, [8, 8, 8])
+    ref1 = O.rulebook_subm3(host(one), [8, 8, 8])
+    _check_rb(rb1, ref1)
+    x1 = dev(np.arange(16, dtype=f32)[None], cuda)
+    assert torch.equal(H.conv_fwd(x1, w, rb1), torch.full((1, 16), float(np.arange(16).sum()), device=cuda))
+    # G
+    assert H.gather_rows(dev(np.ones((5, 8), f32), cuda), dev(np.zeros((0,), i32), cuda)).shape == (0, 8)
+    assert torch.equal(H.scatter_rows(dev(np.zeros((0, 8), f32), cuda), dev(np.zeros((0,), i32), cuda), 5),
+                       torch.zeros((5, 8), device=cuda))
+    # B / L: no queries
+    idx, cnt = H.ball_query(dev(np.zeros((4, 3), f32), cuda), dev(e3, cuda), dev(np.zeros((0,), i32), cuda),
+                            dev(np.array([0, 4], i32), cuda), 0.1, 8)
+    assert idx.shape == (0, 8) and cnt.shape == (0,)
+    assert H.ccl(dev(np.zeros((0,), i32), cuda), dev(np.zeros((0,), i32), cuda)).shape == (0,)
+    # R / I / N: no proposals
+    v = dev(np.ones((6, 4), f32), cuda)
+    z = dev(np.zeros((0,), i32), cuda)
+    assert H.segmented_reduce(v, z, z, "sum").shape == (0, 4)
+    p, a = H.segmented_maxpool_fwd(v, z, z)
+    assert p.shape == (0, 4) and a.shape == (0, 4)
+    assert H.nms(dev(np.zeros((0, 0), f32), cuda), dev(np.zeros((0,), f32), cuda), 0.3).shape == (0,)
+    # an empty segment among non-empty ones keeps its slot (sum 0, min/max = the oracle's convention)
+    b, e = np.array([0, 3, 3], i32), np.array([3, 3, 6], i32)
+    for mode in ("sum", "min", "max"):
+        assert np.array_equal(host(H.segmented_reduce(v, dev(b, cuda), dev(e, cuda), mode)),
+                              O.segmented_reduce(host(v), b, e, mode)), mode
