@@ -229,3 +229,21 @@ def test_two_rank_bench_shares_one_device(cuda):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["config"]["global_batch"] == 4
+
+
+@pytest.mark.gpu
+def test_training_step_without_any_proposal(cuda):
+    """every point predicted as background: clustering has nothing to cluster, the proposal nets do not run, the step
+    still produces a finite loss and gradients for the backbone and the point heads only"""
+    model = make_model((0, 0), channels=[16, 32, 48]).to(cuda)
+    with torch.no_grad():
+        model.sem_seg_head.weight.zero_()
+        model.sem_seg_head.bias.fill_(-10.0)
+        model.sem_seg_head.bias[0] = 10.0
+    batch = [pc.to(cuda) for pc in make_batch(2, 4000)]
+    loss = model.training_step(batch, 0)
+    assert torch.isfinite(loss)
+    loss.backward()
+    assert model.backbone.stem[0].weight.grad is not None and torch.isfinite(model.backbone.stem[0].weight.grad).all()
+    assert all(p.grad is None for p in model.score_unet.parameters())
+    assert all(p.grad is None for p in model.npcs_unet.parameters())
