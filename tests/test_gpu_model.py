@@ -247,3 +247,40 @@ def test_training_step_without_any_proposal(cuda):
     assert model.backbone.stem[0].weight.grad is not None and torch.isfinite(model.backbone.stem[0].weight.grad).all()
     assert all(p.grad is None for p in model.score_unet.parameters())
     assert all(p.grad is None for p in model.npcs_unet.parameters())
+
+
+@pytest.mark.gpu
+def test_validation_epoch_on_the_gpu_matches_the_oracle_path(cuda):
+    """the eval path (validation_step -> filter / NMS -> AP, mIoU at epoch end) on the GPU gives the metrics the same
+    model gives over the CPU oracle (same proposals: clustering is bit-exact; scores within fp tolerance)"""
+    from oracle import torch_ops
+    from gapartnet_amd.trainer import MetricLog
+    model = make_model((0, 0), channels=[16, 32, 48]).eval()
+    model.revoxelize_jitter = (torch.full((3,), 0.3), torch.full((3,), 0.6))
+    results = []
+    for on_gpu in (False, True):
+        m = copy.deepcopy(model)
+        if on_gpu:
+            m = m.to(cuda)
+            m.revoxelize_jitter = tuple(t.to(cuda) for t in model.revoxelize_jitter)
+        log = MetricLog()
+        m._log_sink = log
+        with torch.no_grad():
+            for loader_idx in range(3):
+                batch = make_batch(2, 2500, seed0=2000 + 10 * loader_idx)
+                if on_gpu:
+                    m.validation_step([pc.to(cuda) for pc in batch], 0, loader_idx)
+                else:
+                    with backend.using(torch_ops):
+                        m.validation_step(batch, 0, loader_idx)
+            if on_gpu:
+                m.on_validation_epoch_end()
+            else:
+                with backend.using(torch_ops):
+                    m.on_validation_epoch_end()
+        results.append(log.reduce(cuda if on_gpu else torch.device("cpu")))
+    cpu, gpu = results
+    assert set(cpu) == set(gpu)
+    for key in cpu:
+        assert np.isfinite(gpu[key]), key
+        assert abs(cpu[key] - gpu[key]) <= 1e-3 * max(1.0, abs(cpu[key])), (key, cpu[key], gpu[key])
