@@ -4,7 +4,9 @@ The reference voxelises every scene in CPU DataLoader workers (dataset/gapartnet
 rulebooks inside the forward pass.  Here both run on the GPU, and this iterator runs them for batch i+1 on a SECOND
 stream while the GPU is still busy with the backward pass of batch i-1 / forward of batch i: the host reads that batch
 preparation needs (voxel count, grid extent, per-level row counts) then wait only for that stream's own small kernels
-instead of draining the training stream, which removes the longest host stall of the step.
+instead of draining the training stream, which removes the longest host stall of the step.  The preparation is triggered
+from INSIDE the training step (a hook the model calls between launching the backbone and the first host read of the
+clustering code), i.e. exactly where the host would otherwise wait for the GPU.
 
 Yields ``PointCloudBatch`` objects (what ``GAPartNet.training_step`` accepts directly) whose ``voxel_tensor`` already
 carries the rulebook pyramid of the backbone in its ``indice_dict``.
@@ -70,15 +72,34 @@ class DevicePrefetcher:
             done.record(self.stream)
         return batch, done
 
+    def _prepare_pending(self):
+        """called by the model in the middle of its step (GAPartNet._prefetch_hook): after the backbone and the point heads
+        have been launched and before the clustering code reads back from the device - the host would otherwise sit in
+        that read while the GPU works through the backbone"""
+        if self._has_pending:
+            self._has_pending = False
+            self._ahead = self._prepare(self._pending)
+            self._pending = None
+
     def __iter__(self):
         it = iter(self.batches)
-        ahead = self._prepare(next(it, None))
-        while ahead is not None:
-            batch, done = ahead
-            consumer = torch.cuda.current_stream(self.device)
-            consumer.wait_event(done)
-            for t in _tensors(batch, set()):
-                if t.is_cuda:
-                    t.record_stream(consumer)  # allocated on the side stream, used (and freed) on the training stream
-            ahead = self._prepare(next(it, None))
-            yield batch
+        self._ahead = self._prepare(next(it, None))
+        self._pending, self._has_pending = None, False
+        hook_owner = self.model if hasattr(self.model, "_prefetch_hook") else None
+        try:
+            while self._ahead is not None:
+                batch, done = self._ahead
+                self._ahead = None
+                consumer = torch.cuda.current_stream(self.device)
+                consumer.wait_event(done)
+                for t in _tensors(batch, set()):
+                    if t.is_cuda:
+                        t.record_stream(consumer)  # allocated on the side stream, used (and freed) on the training stream
+                self._pending, self._has_pending = next(it, None), True
+                if hook_owner is not None:
+                    hook_owner._prefetch_hook = self._prepare_pending
+                yield batch
+                self._prepare_pending()  # the consumer's step did not reach the hook (eval, early exit): prepare now
+        finally:
+            if hook_owner is not None:
+                hook_owner._prefetch_hook = None

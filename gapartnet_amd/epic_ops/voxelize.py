@@ -12,7 +12,6 @@ def _host3(v):
     return [float(x) for x in v]
 
 
-@torch.no_grad()
 def voxelize(points: torch.Tensor, pt_features: torch.Tensor, batch_offsets: torch.Tensor,
              voxel_size: torch.Tensor, points_range_min: torch.Tensor, points_range_max: torch.Tensor,
              reduction: str = "mean") -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -30,5 +29,12 @@ def voxelize(points: torch.Tensor, pt_features: torch.Tensor, batch_offsets: tor
     dev = points.device
     rmin = torch.tensor([mn], dtype=torch.float32, device=dev)
     rmax = torch.tensor([mx], dtype=torch.float32, device=dev)
-    vf, vc, vseg, pid = backend.raw().voxelize(points, pt_features, batch_offsets.to(torch.int64), rmin, rmax, vs, grid)
+    if pt_features.requires_grad and torch.is_grad_enabled():
+        from .. import functional as GF  # mean reduction back-propagates to the point features (GF._VoxelMeanFn)
+        vf, vc, vseg, pid = GF.voxelize_mean(points.detach(), pt_features, batch_offsets.to(torch.int64), rmin, rmax, vs,
+                                             grid)[:4]
+        return vf, vc, vseg, pid
+    with torch.no_grad():
+        vf, vc, vseg, pid = backend.raw().voxelize(points, pt_features, batch_offsets.to(torch.int64), rmin, rmax, vs,
+                                                   grid)
     return vf, vc, vseg, pid

@@ -163,6 +163,40 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor, csr=None) -> torch.Tenso
     return _GatherRowsFn.apply(table, idx, csr)
 
 
+class _VoxelMeanFn(torch.autograd.Function):
+    """kernel V as a differentiable op: voxel_features = mean of the member points' features, so
+    d feats[i] = d voxel_features[pc_voxel_id[i]] / (points in that voxel)   (0 for points outside the grid).
+    The operator the reference calls (epic_ops.voxelize, absent from the reference tree) belongs to the PointGroup
+    family of voxelisation ops, whose mean mode back-propagates exactly this; without it the ScoreNet / NPCS-Net losses
+    would never reach the backbone through the proposal features (network/model.py:300-346 feeds pt_features with
+    their graph attached)."""
+
+    @staticmethod
+    def forward(ctx, feats, points, seg_offsets, rmin, rmax, voxel_size, grid_dims, want_stats):
+        ops = backend.raw()
+        out = ops.voxelize(points, feats.contiguous(), seg_offsets, rmin, rmax, voxel_size, grid_dims, want_csr=True,
+                           want_stats=want_stats)
+        vf, vc, vseg, pid, order, starts = out[:6]
+        ctx.save_for_backward(pid, starts)
+        ctx.mark_non_differentiable(vc, vseg, pid, order, starts)
+        return vf, vc, vseg, pid, order, starts, (out[6] if want_stats else None)
+
+    @staticmethod
+    def backward(ctx, d_vf, *_unused):
+        ops = backend.raw()
+        pid, starts = ctx.saved_tensors
+        counts = (starts[1:] - starts[:-1]).clamp(min=1).to(d_vf.dtype)
+        d_feats = ops.gather_rows((d_vf / counts[:, None]).contiguous(), pid)
+        return d_feats, None, None, None, None, None, None, None
+
+
+def voxelize_mean(points, feats, seg_offsets, rmin, rmax, voxel_size, grid_dims, want_stats=False):
+    """differentiable (w.r.t. ``feats``) form of the raw voxelize op -> (voxel_feats, coords, seg, pc_voxel_id, order,
+    starts, stats or None); order / starts = points grouped by voxel (the CSR the voxel->point gathers use in backward),
+    stats = {"max_coord", "dropped"} from the op's single host read when ``want_stats``."""
+    return _VoxelMeanFn.apply(feats, points, seg_offsets, rmin, rmax, voxel_size, grid_dims, want_stats)
+
+
 class _SegmentedMaxpoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, values, begin, end):

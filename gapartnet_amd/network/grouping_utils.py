@@ -13,6 +13,7 @@ from ..epic_ops.ccl import connected_components_labeling
 from ..epic_ops.nms import nms
 from ..epic_ops.reduce import segmented_reduce
 from .. import backend
+from .. import functional as GF
 from ..structure.instances import Instances
 
 
@@ -152,14 +153,13 @@ def segmented_voxelize(pt_xyz: torch.Tensor, pt_features: torch.Tensor, segment_
     rmin = torch.zeros((1, 3), dtype=torch.float32, device=dev)
     rmax = torch.full((1, 3), full, dtype=torch.float32, device=dev)
     # direct kernel-V call with host-known grid (no sync for the range tensors, unlike the generic wrapper)
-    if with_extras:
-        vf, vc, vseg, pid, order, starts, stats = backend.raw().voxelize(
-            scaled, pt_features, segment_offsets.to(torch.int64), rmin, rmax, [1.0, 1.0, 1.0], [int(full) + 1] * 3,
-            want_csr=True, want_stats=True)
-        return vf, torch.cat([vseg[:, None], vc], dim=1), pid, {"csr": (order, starts), "dropped": stats["dropped"]}
-    vf, vc, vseg, pid = backend.raw().voxelize(scaled, pt_features, segment_offsets.to(torch.int64), rmin, rmax,
-                                               [1.0, 1.0, 1.0], [int(full) + 1] * 3)
+    # kernel V through its differentiable wrapper: the proposal features carry the backbone's graph
+    vf, vc, vseg, pid, order, starts, stats = GF.voxelize_mean(
+        scaled, pt_features, segment_offsets.to(torch.int64), rmin, rmax, [1.0, 1.0, 1.0], [int(full) + 1] * 3,
+        want_stats=with_extras)
     voxel_coords = torch.cat([vseg[:, None], vc], dim=1)
+    if with_extras:
+        return vf, voxel_coords, pid, {"csr": (order, starts), "dropped": stats["dropped"]}
     return vf, voxel_coords, pid
 
 

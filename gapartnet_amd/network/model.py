@@ -116,6 +116,7 @@ class GAPartNet(LightningModule):
         self.npcs_head = nn.Linear(width, 3 * (self.num_part_classes - 1))
 
         self.symmetry_matrix_1, self.symmetry_matrix_2, self.symmetry_matrix_3 = get_symmetry_matrix()
+        self._prefetch_hook = None  # set by dataset.prefetch.DevicePrefetcher while it feeds this model
 
         if ckpt != "":
             print("Loading pretrained model from:", ckpt)
@@ -182,7 +183,7 @@ class GAPartNet(LightningModule):
 
         # one compaction index for every per-point array (each boolean-mask selection would be its own host sync)
         valid_indices = torch.nonzero(valid_mask).squeeze(1)
-        pt_xyz, batch_indices, pt_features = pt_xyz[valid_indices], batch_indices[valid_indices], pt_features[valid_indices]
+        pt_xyz, batch_indices = pt_xyz[valid_indices], batch_indices[valid_indices]
         sem_preds, offset_preds = sem_preds[valid_indices].int(), offset_preds[valid_indices]
         if instance_labels is not None:
             instance_labels = instance_labels[valid_indices]
@@ -221,7 +222,11 @@ class GAPartNet(LightningModule):
         if sorted_indices.shape[0] == 0:
             return None, None, None
 
-        batch_indices, pt_xyz, pt_features = batch_indices[sorted_indices], pt_xyz[sorted_indices], pt_features[sorted_indices]
+        batch_indices, pt_xyz = batch_indices[sorted_indices], pt_xyz[sorted_indices]
+        # the only differentiable selection of the function, done once on the original rows: index_select back-propagates
+        # with an index_add (a point is in at most two proposals, so the sum is order-independent) instead of the sort-based
+        # index_put the advanced-indexing form uses
+        pt_features = pt_features.index_select(0, valid_indices[sorted_indices])
         sem_preds = sem_preds[sorted_indices]
         if instance_labels is not None:
             instance_labels = instance_labels[sorted_indices]
@@ -341,6 +346,12 @@ class GAPartNet(LightningModule):
             raise RuntimeError("batch carries no instance_regions (the reference stops in pdb here, model.py:525)")
         loss_offset_dist, loss_offset_dir = self.loss_offset(offsets_preds, instance_regions[:, :3] - pt_xyz, sem_labels,
                                                              instance_labels)
+
+        # the backbone and the point heads are queued; what follows starts with host reads of device results.  A device
+        # prefetcher (dataset/prefetch.py) uses this moment to prepare the next batch on its own stream
+        hook = self._prefetch_hook
+        if hook is not None:
+            hook()
 
         # proposals
         voxel_tensor = pc_voxel_id = proposals = None

@@ -491,3 +491,34 @@ def test_empty_and_degenerate_inputs(H, cuda):
     for mode in ("sum", "min", "max"):
         assert np.array_equal(host(H.segmented_reduce(v, dev(b, cuda), dev(e, cuda), mode)),
                               O.segmented_reduce(host(v), b, e, mode)), mode
+
+
+def test_voxel_mean_gradient_on_the_gpu(H, cuda):
+    """the differentiable voxelize wrapper on the HIP kernels == on the oracle (forward bit-exact, gradient 1e-6)"""
+    from gapartnet_amd import backend, functional as GF
+    from oracle import torch_ops
+    rng = np.random.default_rng(12)
+    pts = rng.uniform(0, 16, (5000, 3)).astype(np.float32)
+    feats = rng.normal(size=(5000, 16)).astype(np.float32)
+    offs = np.array([0, 1000, 5000], np.int64)
+    res = []
+    for on_gpu in (False, True):
+        d = cuda if on_gpu else torch.device("cpu")
+        f = torch.from_numpy(feats).to(d).requires_grad_(True)
+        args = (torch.from_numpy(pts).to(d), f, torch.from_numpy(offs).to(d), torch.zeros((1, 3), device=d),
+                torch.full((1, 3), 16.0, device=d), [1.0, 1.0, 1.0], [17, 17, 17])
+        if on_gpu:
+            out = GF.voxelize_mean(*args)
+        else:
+            with backend.using(torch_ops):
+                out = GF.voxelize_mean(*args)
+        vf = out[0]
+        w = torch.linspace(-1, 1, vf.numel(), device=d).view_as(vf)
+        if on_gpu:
+            (vf * w).sum().backward()
+        else:
+            with backend.using(torch_ops):
+                (vf * w).sum().backward()
+        res.append((vf.detach().cpu(), out[3].cpu(), f.grad.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.allclose(res[0][2], res[1][2], atol=1e-6)

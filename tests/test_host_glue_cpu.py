@@ -279,3 +279,28 @@ def test_clustering_with_known_batch_size_equals_the_compacting_form():
     assert torch.equal(a[1], b[1])
     for f in ("sorted_indices", "proposal_offsets", "proposal_indices", "batch_indices", "sem_preds"):
         assert torch.equal(getattr(a[2], f), getattr(b[2], f)), f
+
+
+def test_voxel_mean_backpropagates_to_point_features():
+    """d feats[i] = d voxel[pc_voxel_id[i]] / count: checked against a plain torch restatement (index_add mean)"""
+    from oracle import torch_ops
+    rng = np.random.default_rng(11)
+    pts = torch.from_numpy(rng.uniform(0, 4, (300, 3)).astype(np.float32))
+    pts[:5] = 9.0  # outside the grid: no voxel, no gradient
+    feats = torch.from_numpy(rng.normal(size=(300, 5)).astype(np.float32)).requires_grad_(True)
+    offs = torch.tensor([0, 120, 300], dtype=torch.int64)
+    rmin, rmax = torch.zeros((1, 3)), torch.full((1, 3), 4.0)
+    with backend.using(torch_ops):
+        vf, vc, vseg, pid, order, starts, _ = GF.voxelize_mean(pts, feats, offs, rmin, rmax, [1.0, 1.0, 1.0], [5, 5, 5])
+    w = torch.from_numpy(rng.normal(size=tuple(vf.shape)).astype(np.float32))
+    (vf * w).sum().backward()
+    ref_feats = feats.detach().clone().requires_grad_(True)
+    keep = pid >= 0
+    V = vf.shape[0]
+    sums = torch.zeros((V, 5)).index_add(0, pid[keep].long(), ref_feats[keep])
+    cnt = torch.zeros((V,)).index_add(0, pid[keep].long(), torch.ones(int(keep.sum())))
+    ref = sums / cnt[:, None]
+    assert torch.allclose(vf, ref, atol=1e-6)
+    (ref * w).sum().backward()
+    assert torch.allclose(feats.grad, ref_feats.grad, atol=1e-6)
+    assert torch.equal(feats.grad[:5], torch.zeros((5, 5)))
