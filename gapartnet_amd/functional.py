@@ -197,6 +197,40 @@ def voxelize_mean(points, feats, seg_offsets, rmin, rmax, voxel_size, grid_dims,
     return _VoxelMeanFn.apply(feats, points, seg_offsets, rmin, rmax, voxel_size, grid_dims, want_stats)
 
 
+class _PointLossesFn(torch.autograd.Function):
+    """kernel family P: focal + dice + offset-distance + offset-direction losses of all points in one pass"""
+
+    @staticmethod
+    def forward(ctx, logits, offsets, labels, gt_offsets, instance_labels, ignore_index):
+        ops = backend.raw()
+        logits, offsets = logits.contiguous(), offsets.contiguous()
+        labels, gt_offsets = labels.contiguous(), gt_offsets.contiguous()
+        instance_labels = instance_labels.to(torch.int32).contiguous()
+        losses, stats = ops.point_losses_fwd(logits, labels, offsets, gt_offsets, instance_labels, ignore_index)
+        ctx.save_for_backward(logits, offsets, labels, gt_offsets, instance_labels, stats)
+        ctx.ignore_index = ignore_index
+        return losses
+
+    @staticmethod
+    def backward(ctx, grad_losses):
+        ops = backend.raw()
+        logits, offsets, labels, gt_offsets, instance_labels, stats = ctx.saved_tensors
+        d_logits, d_offsets = ops.point_losses_bwd(logits, labels, offsets, gt_offsets, instance_labels, ctx.ignore_index,
+                                                   stats, grad_losses.contiguous())
+        return d_logits, d_offsets, None, None, None, None
+
+
+def point_losses_available(logits: torch.Tensor) -> bool:
+    return backend.raw().name == "hip" and logits.is_cuda and logits.dim() == 2 and logits.shape[1] <= 32 \
+        and logits.shape[0] > 0 and logits.dtype == torch.float32
+
+
+def point_losses(logits, offsets, labels, gt_offsets, instance_labels, ignore_index: int = -100) -> torch.Tensor:
+    """-> [4] = (focal loss, dice loss, offset L1 loss, offset direction loss) exactly as network/model.py:177-226 computes
+    them from ~70 torch ops (focal_loss + dice_loss + loss_offset); one launch forward, one backward"""
+    return _PointLossesFn.apply(logits, offsets, labels, gt_offsets, instance_labels, int(ignore_index))
+
+
 class _SegmentedMaxpoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, values, begin, end):

@@ -306,6 +306,34 @@ def conv_wgrad(features, dout, rb: Rulebook, layout="kio"):
     return dW
 
 
+# ---------------------------------------------------------------------------------------------------- P
+def point_losses_fwd(logits, labels, offsets, gt_offsets, instance_labels, ignore_index):
+    """-> (losses [4] f32 = focal, dice, offset distance, offset direction; stats = opaque device block for the backward)"""
+    dev = _dev(logits, offsets)
+    logits, offsets, gt_offsets = _c(logits, torch.float32), _c(offsets, torch.float32), _c(gt_offsets, torch.float32)
+    labels, instance_labels = _c(labels, torch.int64), _c(instance_labels, torch.int32)
+    M, C = logits.shape
+    losses = torch.empty((4,), dtype=torch.float32, device=dev)
+    stats = torch.empty((4,), dtype=torch.float64, device=dev)
+    L = _C.lib()
+    ws = _ws(L.gpn_point_losses_ws_bytes(i64(M)), dev)
+    check(L.gpn_point_losses_fwd(ptr(logits), ptr(labels), ptr(offsets), ptr(gt_offsets), ptr(instance_labels), i64(M),
+                                 i32(C), i64(ignore_index), ptr(losses), ptr(stats), ptr(ws), szt(ws.numel()), _stream()),
+          "gpn_point_losses_fwd")
+    return losses, stats
+
+
+def point_losses_bwd(logits, labels, offsets, gt_offsets, instance_labels, ignore_index, stats, grad_losses):
+    dev = _dev(logits, offsets)
+    M, C = logits.shape
+    d_logits = torch.empty((M, C), dtype=torch.float32, device=dev)
+    d_offsets = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_point_losses_bwd(ptr(logits), ptr(labels), ptr(offsets), ptr(gt_offsets), ptr(instance_labels),
+                                        i64(M), i32(C), i64(ignore_index), ptr(stats), ptr(_c(grad_losses, torch.float32)),
+                                        ptr(d_logits), ptr(d_offsets), _stream()), "gpn_point_losses_bwd")
+    return d_logits, d_offsets
+
+
 # ---------------------------------------------------------------------------------------------------- BN
 def _p(t):
     return None if t is None else t.data_ptr()

@@ -364,6 +364,22 @@ int gpn_pn2_three_interpolate_grad(int b, int c, int n, int m, const float* grad
                                    const int32_t* idx, const float* weight, float* grad_points,
                                    gpn_stream_t stream);
 
+/* ================================================================================================
+ * P — per-point losses of the training step in one pass (network/model.py:177-226: loss_sem_seg = focal (gamma 2, rows with
+ * label == ignore_index dropped, 0 if none is left) + dice on the 1e-6-smoothed one-hot target; loss_offset = L1 distance
+ * and negative cosine on points with label > 0 and instance label >= 0; network/losses.py:35-64, 111-158).
+ * logits [M,C] (C <= 32), labels [M] i64, offsets / gt_offsets [M,3], instance_labels [M] i32.
+ * fwd -> losses [4] f32 = (focal, dice, offset distance, offset direction) and a 32-byte device block `stats` for bwd;
+ * bwd: grad_losses [4] f32 (device) -> d_logits [M,C], d_offsets [M,3].  Fixed-order reductions (deterministic).
+ * ================================================================================================ */
+size_t gpn_point_losses_ws_bytes(int64_t M);
+int gpn_point_losses_fwd(const float* logits, const int64_t* labels, const float* offsets, const float* gt_offsets,
+                         const int32_t* instance_labels, int64_t M, int C, int64_t ignore_index, float* losses,
+                         void* stats, void* ws, size_t ws_bytes, gpn_stream_t stream);
+int gpn_point_losses_bwd(const float* logits, const int64_t* labels, const float* offsets, const float* gt_offsets,
+                         const int32_t* instance_labels, int64_t M, int C, int64_t ignore_index, const void* stats,
+                         const float* grad_losses, float* d_logits, float* d_offsets, gpn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -522,3 +522,69 @@ def test_voxel_mean_gradient_on_the_gpu(H, cuda):
         res.append((vf.detach().cpu(), out[3].cpu(), f.grad.cpu()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.allclose(res[0][2], res[1][2], atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["normal", "ignored_rows", "no_part_points", "zero_offsets"])
+def test_fused_point_losses_match_the_torch_formulas(H, cuda, case):
+    """kernel family P vs the plain-torch losses it replaces (focal_loss + dice_loss + loss_offset, themselves pinned to
+    the reference by tests/golden): values 1e-5 relative, gradients 1e-4 relative"""
+    from gapartnet_amd import functional as GF
+    from gapartnet_amd.network.losses import dice_loss, focal_loss
+    g = torch.Generator().manual_seed(7)
+    M, C = 30000, 10
+    logits = (torch.randn(M, C, generator=g) * 2).to(cuda).requires_grad_(True)
+    offsets = (torch.randn(M, 3, generator=g) * 0.1).to(cuda)
+    if case == "zero_offsets":
+        offsets[::5] = 0.0
+    offsets.requires_grad_(True)
+    gt = (torch.randn(M, 3, generator=g) * 0.1).to(cuda)
+    labels = torch.randint(0, C, (M,), generator=g).to(cuda)
+    inst = torch.randint(-1, 6, (M,), generator=g).to(torch.int32).to(cuda)
+    if case == "no_part_points":
+        labels.zero_()
+    wts = torch.tensor([0.7, 1.3, 0.9, 1.1], device=cuda)
+
+    def reference(lab_for_focal):
+        on = (labels > 0) & (inst >= 0)
+        cnt = on.sum()
+        zero = offsets.new_zeros(())
+        l_dist = torch.where(on, (offsets - gt).abs().sum(-1), zero).sum() / cnt
+        gdir = gt / (torch.norm(gt, p=2, dim=-1)[:, None] + 1e-8)
+        pdir = offsets / (torch.norm(offsets, p=2, dim=-1)[:, None] + 1e-8)
+        l_dir = torch.where(on, -(gdir * pdir).sum(-1), zero).sum() / cnt
+        return torch.stack([focal_loss(logits, lab_for_focal, gamma=2.0, ignore_index=-100),
+                            dice_loss(logits[:, :, None, None], labels[:, None, None]), l_dist, l_dir])
+
+    lab_focal = labels.clone()
+    if case == "ignored_rows":
+        lab_focal[::3] = -100
+    if case == "ignored_rows":
+        # the fused op takes ONE label vector: ignored rows are also class-less for dice (one-hot = smoothing only)
+        want = reference(lab_focal)
+        keep = lab_focal != -100
+        y = torch.zeros((M, C), device=cuda).scatter_(1, labels[:, None], 1.0) * keep[:, None] + 1e-6
+        p = torch.softmax(logits, 1)
+        want = torch.stack([want[0], (1 - 2 * (p * y).sum(1) / ((p + y).sum(1) + 1e-8)).mean(), want[2], want[3]])
+        # offsets use labels > 0: -100 rows are off-part
+        on = (lab_focal > 0) & (inst >= 0)
+        cnt = on.sum()
+        zero = offsets.new_zeros(())
+        gdir = gt / (torch.norm(gt, p=2, dim=-1)[:, None] + 1e-8)
+        pdir = offsets / (torch.norm(offsets, p=2, dim=-1)[:, None] + 1e-8)
+        want = torch.stack([want[0], want[1], torch.where(on, (offsets - gt).abs().sum(-1), zero).sum() / cnt,
+                            torch.where(on, -(gdir * pdir).sum(-1), zero).sum() / cnt])
+    else:
+        want = reference(lab_focal)
+    got = GF.point_losses(logits, offsets, lab_focal, gt, inst, -100)
+    if case == "no_part_points":
+        assert torch.isnan(got[2]) and torch.isnan(got[3]) and torch.isnan(want[2])
+        assert torch.allclose(got[:2], want[:2], rtol=1e-5, atol=1e-6)
+        gg = torch.autograd.grad((got[:2] * wts[:2]).sum(), [logits])[0]
+        gw = torch.autograd.grad((want[:2] * wts[:2]).sum(), [logits])[0]
+        assert torch.allclose(gg, gw, rtol=1e-4, atol=1e-9)
+        return
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (got, want)
+    gg = torch.autograd.grad((got * wts).sum(), [logits, offsets])
+    gw = torch.autograd.grad((want * wts).sum(), [logits, offsets])
+    assert torch.allclose(gg[0], gw[0], rtol=1e-4, atol=1e-9)
+    assert torch.allclose(gg[1], gw[1], rtol=1e-4, atol=1e-9)
