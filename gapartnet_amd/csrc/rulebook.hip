@@ -327,7 +327,11 @@ extern "C" int gpn_rulebook_tile_order(const int32_t* nbr, int K, int64_t n, int
   const int grid = (int)gpn::cdiv(n, kThreads);
   hipLaunchKernelGGL(tile_order_keys_kernel, dim3(grid), dim3(kThreads), 0, stream, nbr, K, n, block_shift, keys, vals);
   GPN_CHECK_LAUNCH();
-  GPN_CHECK_HIP(rocprim::radix_sort_pairs(prim_tmp, prim_bytes, keys, keys_sorted, vals, perm, (size_t)n, 0, 64, stream));
+  // key = (block << 32) | mask: only K mask bits and the block bits carry information (5 radix passes instead of 8)
+  int block_bits = 1;
+  while (((int64_t)1 << block_bits) <= ((n - 1) >> block_shift)) ++block_bits;
+  GPN_CHECK_HIP(rocprim::radix_sort_pairs(prim_tmp, prim_bytes, keys, keys_sorted, vals, perm, (size_t)n, 0,
+                                          (unsigned)(32 + block_bits), stream));
   const int64_t padded = gpn::cdiv(n, 16) * 16 + 16;
   hipLaunchKernelGGL(tile_order_pad_kernel, dim3((int)gpn::cdiv(padded - n, kThreads)), dim3(kThreads), 0, stream, perm, n,
                      padded);
