@@ -6,7 +6,7 @@ One "step" = one full training step of the perception pipeline on one batch of s
 on-device batched voxelisation + collate, sparse U-Net backbone, semantic / offset heads, dual-set clustering
 (ball query + CCL), proposal re-voxelisation, ScoreNet, NPCS-Net, all five losses, backward, Adam.  Inputs (raw point
 clouds + labels) are resident in HBM before the timed region.  Launch: ``python bench.py`` (1 GPU) or
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (one rank per GPU, DDP over RCCL).
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (one rank per GPU, gradient mean over RCCL).
 
 Prints ONE JSON line on rank 0 with the contract fields plus ``roofline`` (dominant kernel, measured with hipEvents
 inside libgpn_hip.so during an extra instrumented step) and ``cpu_baseline`` (the same train step through the CPU
@@ -43,18 +43,24 @@ def parse():
 
 
 def build_step(model, optimizer, world, device):
-    from gapartnet_amd.trainer import _TrainStep
-    from torch.nn.parallel import DistributedDataParallel as DDP
-    step_module = _TrainStep(model)
-    if world > 1:
-        step_module = DDP(step_module, device_ids=[device.index], find_unused_parameters=True)
+    grad_sync = None
+    if world > 1 or os.environ.get("GPN_BENCH_FORCE_GRAD_SYNC") == "1":  # the switch: exchange cost measurable on one GPU
+        from gapartnet_amd.grad_sync import GradSync
+        if not dist.is_initialized():  # forced on a single rank
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        grad_sync = GradSync(model)
+        grad_sync.broadcast_parameters()
 
     def step(batch, i):
         optimizer.zero_grad(set_to_none=True)
-        loss = step_module(batch, i)
+        loss = model.training_step(batch, i)
         loss.backward()
+        if grad_sync is not None:
+            grad_sync.sync()  # mean of the ranks' gradients: the path's one collective
         optimizer.step()
         return loss
+    step.grad_sync = grad_sync
     return step
 
 
@@ -190,7 +196,7 @@ def main():
                                                        tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0)
                                      for v in prof.values()})
     elif world > 1:
-        step(next(feed), 0)  # keep ranks in lock-step through the extra DDP step
+        step(next(feed), 0)  # keep ranks in lock-step through the extra step's gradient exchange
     if world > 1:
         dist.barrier()
 
@@ -206,6 +212,8 @@ def main():
                        "points_per_scene": args.points, "parallelism": f"dp{world}"},
             "roofline": roof,
         }
+        if step.grad_sync is not None:  # how the gradient exchange ran: buckets all-reduced in place / via one cat / skipped
+            out["grad_exchange"] = dict(step.grad_sync.stats, backend=step.grad_sync.backend)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -1,12 +1,13 @@
 """Minimal trainer for ``GAPartNet`` with Lightning's hook protocol (Lightning itself is absent from the MI355X image;
 the reference runs under ``lightning.pytorch.Trainer`` configured by gapartnet.yaml ``trainer:``).
 
-One process per GPU: launched under ``torch.distributed.run`` every rank reads RANK / LOCAL_RANK / WORLD_SIZE, joins
-a ``nccl`` (= RCCL over xGMI) process group — ``gloo`` on CPU — and wraps the module in DistributedDataParallel.
-Scenes are independent: each rank gets a disjoint shard of scenes (DistributedSampler); the only
-data-path collective is DDP's bucketed gradient all-reduce (31.6 MB fp32 per step for the default config) overlapped
-with backward; BatchNorm statistics stay per rank like the reference (no SyncBN).  ``find_unused_parameters`` is on
-because the training schedule leaves the score / NPCS sub-networks without gradients in early epochs.
+One process per GPU: launched under ``torch.distributed.run`` every rank reads RANK / LOCAL_RANK / WORLD_SIZE and joins
+a ``nccl`` (= RCCL over xGMI) process group — ``gloo`` on CPU.  Scenes are independent: each rank gets a
+disjoint shard of scenes (DistributedSampler); the only data-path collective is the gradient mean all-reduce of
+``grad_sync.GradSync`` (31.6 MB fp32 per step for the default config, one in-place all-reduce per sparse U-Net plus one
+for the small heads) between ``backward()`` and ``optimizer.step()``; BatchNorm statistics stay per rank like the reference
+(no SyncBN).  Sub-networks the training schedule leaves without gradients in early epochs keep
+``grad is None`` on every rank — the behaviour the reference gets from DDP's ``find_unused_parameters``.
 """
 import os
 import time
@@ -16,7 +17,6 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 import torch.nn as nn
-from torch.nn.parallel import DistributedDataParallel as DDP
 
 
 def distributed_env():
@@ -43,7 +43,7 @@ def init_distributed(device_type: str = "cuda"):
 
 
 class _TrainStep(nn.Module):
-    """DDP calls ``forward``; route it to the module's ``training_step`` so gradient hooks see the real graph."""
+    """``forward`` routed to the module's ``training_step`` (the callable a DDP-style wrapper needs; tools/ddp_profile.py)."""
 
     def __init__(self, module):
         super().__init__()
@@ -136,10 +136,11 @@ class Trainer:
             if "optimizer" in state:
                 optimizer.load_state_dict(state["optimizer"])
             start_epoch = int(state.get("epoch", -1)) + 1
-        step_module = _TrainStep(model)
+        grad_sync = None
         if self.world > 1:
-            step_module = DDP(step_module, device_ids=[self.local_rank] if self.device.type == "cuda" else None,
-                              find_unused_parameters=self.find_unused)
+            from .grad_sync import GradSync
+            grad_sync = GradSync(model)
+            grad_sync.broadcast_parameters()
         for epoch in range(start_epoch, self.max_epochs):
             self._set_epoch(model, epoch)
             sampler = getattr(train_dataloaders, "sampler", None)
@@ -156,13 +157,17 @@ class Trainer:
                     break
                 batch = move_batch(batch, self.device)
                 optimizer.zero_grad(set_to_none=True)
-                loss = step_module(batch, batch_idx)
+                loss = model.training_step(batch, batch_idx)
                 loss.backward()
+                if grad_sync is not None:
+                    grad_sync.sync()
                 optimizer.step()
                 self.global_step += 1
             metrics = log.reduce(self.device)
             metrics["epoch_time_s"] = time.time() - t0
             if val_dataloaders is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
+                if grad_sync is not None:
+                    grad_sync.broadcast_buffers()
                 metrics.update(self._eval_loop(model, val_dataloaders, "validation", log))
             metrics["epoch"] = epoch
             self.history.append(metrics)

@@ -1,7 +1,8 @@
-"""N > 1 path on CPU: two processes, gloo backend, the same Trainer / DDP wrapper the GPU path uses (with RCCL there).
-Checks the three things data-parallel training of this model depends on: disjoint scene shards per rank, gradient
-all-reduce (mean) through the DDP-wrapped training_step, and parameters staying identical across ranks after steps —
-including the phase where the score / NPCS sub-networks receive no gradient (find_unused_parameters)."""
+"""N > 1 path on CPU: two processes, gloo backend, the same Trainer / GradSync exchange the GPU path uses (with RCCL there).
+Checks the three things data-parallel training of this model depends on: disjoint scene shards per rank, the gradient
+mean all-reduce between backward and the optimizer step, and parameters staying identical across ranks after steps —
+including the phase where the score / NPCS sub-networks receive no gradient on any rank (they must keep grad None, the
+semantics the reference gets from DDP find_unused_parameters) and a sub-network used by one rank only."""
 import os
 import socket
 import sys
@@ -68,3 +69,52 @@ def test_two_rank_ddp_training(tmp_path, schedule):
     assert res["finite"] and res["loss"] > 0
     a, b = set(res["ids"][0]), set(res["ids"][1])
     assert len(a) == 4 and len(b) == 4 and not (a & b), "ranks must train on disjoint scene shards"
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a, self.b, self.c = torch.nn.Linear(4, 3), torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)
+
+
+def _grad_sync_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gapartnet_amd.grad_sync import GradSync
+    model = _Toy()
+    if rank == 1:
+        with torch.no_grad():
+            model.a.weight.add_(1.0)  # must be overwritten by the rank-0 broadcast
+    sync = GradSync(model)
+    sync.broadcast_parameters()
+    x = torch.arange(8, dtype=torch.float32).view(2, 4) * (rank + 1)
+    h = model.a(x)
+    # rank 0 uses head b, rank 1 uses neither head (h only); head c is used by nobody
+    loss = (model.b(h).sum() + h.sum()) if rank == 0 else (2.0 * h).sum()
+    loss.backward()
+    local = {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}
+    sync.sync()
+    synced = {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}
+    both = [None] * world
+    dist.all_gather_object(both, (local, synced, model.a.weight.detach().clone()))
+    if rank == 0:
+        torch.save(both, os.path.join(out_dir, "toy.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sync_mean_and_unused_semantics(tmp_path):
+    mp.spawn(_grad_sync_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    (l0, s0, w0), (l1, s1, w1) = torch.load(os.path.join(str(tmp_path), "toy.pt"), weights_only=False)
+    assert torch.equal(w0, w1), "parameters were not broadcast from rank 0"
+    for name in l0:
+        if name.startswith("c."):
+            assert s0[name] is None and s1[name] is None, "a sub-network no rank used must keep grad None"
+            continue
+        g0 = l0[name] if l0[name] is not None else torch.zeros_like(s0[name])
+        g1 = l1[name] if l1[name] is not None else torch.zeros_like(s0[name])
+        assert l1[name] is not None or name.startswith("b."), name
+        want = (g0 + g1) / 2
+        assert torch.allclose(s0[name], want, rtol=0, atol=1e-6) and torch.equal(s0[name], s1[name]), name

@@ -210,7 +210,7 @@ def test_device_prefetcher_feeds_identical_steps(cuda):
 
 @pytest.mark.gpu
 def test_two_rank_bench_shares_one_device(cuda):
-    """bench.py's multi-rank path (DDP over the executor's single backward node, device prefetcher, per-rank scene shards,
+    """bench.py's multi-rank path (GradSync over the executor's flat gradient buffers, device prefetcher, per-rank scene shards,
     max-over-ranks timing) with two ranks time-slicing ONE GPU over gloo (GPN_DIST_SHARE_DEVICE): the code path the driver
     runs at N = 2/4/8 over RCCL, minus the performance"""
     import json
@@ -229,6 +229,8 @@ def test_two_rank_bench_shares_one_device(cuda):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["config"]["global_batch"] == 4
+    ex = res["grad_exchange"]  # 4 steps x (3 U-Nets reduced in place in the executor's buffer + the heads via one cat)
+    assert ex["steps"] == 4 and ex["in_place"] >= ex["steps"] and ex["flattened"] >= ex["steps"], ex
 
 
 @pytest.mark.gpu
