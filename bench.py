@@ -46,9 +46,6 @@ def build_step(model, optimizer, world, device):
     grad_sync = None
     if world > 1 or os.environ.get("GPN_BENCH_FORCE_GRAD_SYNC") == "1":  # the switch: exchange cost measurable on one GPU
         from gapartnet_amd.grad_sync import GradSync
-        if not dist.is_initialized():  # forced on a single rank
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
         grad_sync = GradSync(model)
         grad_sync.broadcast_parameters()
 
@@ -135,6 +132,9 @@ def main():
     rank, local_rank, world, device = init_distributed("cuda")
     assert device.type == "cuda", "bench.py needs a GPU (the product has no CPU path)"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world == 1 and os.environ.get("GPN_BENCH_FORCE_GRAD_SYNC") == "1":  # a 1-rank RCCL group: the exchange on one GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
     from gapartnet_amd import _C, functional as GF
     from gapartnet_amd.smoke import make_batch, make_model
     _C.lib()  # fail loudly if the HIP extension is missing

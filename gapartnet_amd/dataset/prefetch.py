@@ -102,4 +102,4 @@ class DevicePrefetcher:
                 self._prepare_pending()  # the consumer's step did not reach the hook (eval, early exit): prepare now
         finally:
             if hook_owner is not None:
-                hook_owner._prefetch_hook = None
+                hook_owner.__dict__["_prefetch_hook"] = None  # plain attribute; safe at interpreter teardown too

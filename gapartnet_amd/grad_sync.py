@@ -16,6 +16,7 @@ tools/ddp_profile.py), so the exchange is done here instead, shaped by what the 
 The payload is 31.6 MB per step for the default model: ~0.2 ms on a 7-link xGMI ring, which is why no overlap with backward
 is attempted.  RCCL ("nccl") averages in the collective (ReduceOp.AVG); gloo sums and the buffer is scaled afterwards.
 """
+import time
 from typing import List, Optional
 
 import torch
@@ -47,7 +48,7 @@ class GradSync:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._buckets: Optional[List[List[int]]] = None
-        self.stats = {"in_place": 0, "flattened": 0, "skipped": 0, "steps": 0}
+        self.stats = {"in_place": 0, "flattened": 0, "skipped": 0, "steps": 0, "host_ms": 0.0}
 
     # ------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
@@ -79,16 +80,20 @@ class GradSync:
 
     @staticmethod
     def _shared_flat(grads) -> Optional[torch.Tensor]:
-        """the 1-D buffer the gradients tile back to back in this order, if there is one (the executor's pgrad)"""
-        base = grads[0]._base
-        if base is None or base.dim() != 1 or not base.is_contiguous():
-            return None
-        ptr = base.data_ptr()
+        """a 1-D alias of the storage the gradients tile back to back in this order, if they do (the executor's buffer:
+        autograd hands its slices to ``.grad`` without copying when ``.grad`` was None)"""
+        g0 = grads[0]
+        store = g0.untyped_storage()
+        sptr, ptr, total = store.data_ptr(), g0.data_ptr(), 0
         for g in grads:
-            if g._base is not base or g.data_ptr() != ptr or not g.is_contiguous():
+            if g.data_ptr() != ptr or g.dtype != g0.dtype or not g.is_contiguous():
                 return None
-            ptr += g.numel() * g.element_size()
-        return base if ptr == base.data_ptr() + base.numel() * base.element_size() else None
+            n = g.numel()
+            ptr += n * 4
+            total += n
+        if g0.dtype != torch.float32 or grads[-1].untyped_storage().data_ptr() != sptr or ptr > sptr + store.nbytes():
+            return None
+        return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(store, g0.storage_offset(), (total,), (1,))
 
     def _all_reduce_mean(self, flat):
         if self.backend == "nccl":
@@ -99,6 +104,7 @@ class GradSync:
 
     @torch.no_grad()
     def sync(self):
+        t0 = time.perf_counter()
         if self._buckets is None:
             self._build_buckets()  # after the first backward: the executors' programs exist by now
         params = self.params
@@ -128,3 +134,4 @@ class GradSync:
             for i, piece in zip(live, flat.split([params[i].numel() for i in live])):
                 params[i].grad = piece.view_as(params[i])
             self.stats["flattened"] += 1
+        self.stats["host_ms"] += (time.perf_counter() - t0) * 1e3  # host time spent issuing the exchange (all steps)
