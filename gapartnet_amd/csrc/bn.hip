@@ -2,10 +2,12 @@
 // it in every block of the reference network (network/backbone.py:40-49: relu(bn(conv(x)) [+ shortcut])).
 //
 // HBM-streaming kernels: [N, C] row-major with C in 16..224, read as float4.  Training forward = statistics pass
-// (per-workgroup partial sums, combined in double for a cancellation-safe variance) + tiny finalize (mean, 1/std,
-// running-stat update) + one apply pass that also adds the residual and applies ReLU.  Backward = one reduction pass
-// (sum g, sum g*xhat with the ReLU mask folded in) + finalize + one apply pass producing dx (and the residual's
-// gradient).  Compared with separate BatchNorm / add / ReLU kernels this removes three full read+write passes per
+// (<= 64 workgroups x 1024 threads, per-workgroup partial sums in double for a cancellation-safe variance) + one apply
+// pass that also adds the residual and applies ReLU.  Backward = one reduction pass (sum g, sum g*xhat with the ReLU
+// mask folded in) + one apply pass producing dx (and the residual's gradient).  There is no finalize launch: every
+// workgroup of the apply pass folds the <= 64 partials itself (L2-resident, ~1 us) and workgroup 0 also stores mean /
+// 1/std / running statistics (forward) or dweight / dbias (backward) - a 64-thread finalize launch between the two
+// passes cost 4.5 us of GPU time and one host launch per layer and pass (176 per training step of the default model).  Compared with separate BatchNorm / add / ReLU kernels this removes three full read+write passes per
 // layer in forward and two in backward.  All reductions are fixed-order (deterministic).
 //
 // Small matrices (N <= kSmallRows: the deep levels of the U-Net, where a layer's kernels run at the
@@ -17,16 +19,38 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 512;
+constexpr int kMaxBlocks = 64;  // statistics-pass workgroups = partials every apply workgroup folds
 
-// thread layout for column-wise reductions: c4 = tid % C4 (float4 column), r = tid / C4 (row lane), R = 256 / C4 rows
+// thread layout for column-wise reductions: c4 = tid % C4 (float4 column), r = tid / C4 (row lane), R = T / C4 rows
+
+// ordered sum of red[q][rr * C4 + c/4][c%4] over rr < R for (q, c) pairs, P sub-lanes per pair (strided partial sums, then
+// a fixed-order shuffle tree): deterministic.  Returns the sum in sub-lane 0 of each pair; e = pair index of this thread.
+template <int T>
+__device__ __forceinline__ double column_total(const double (*red)[T][4], int q, int c, int C4, int R, int part, int P) {
+  double acc = 0.0;
+  const int cc4 = c >> 2, j = c & 3;
+  for (int rr = part; rr < R; rr += P) acc += red[q][rr * C4 + cc4][j];
+  for (int off = P >> 1; off >= 1; off >>= 1) acc += __shfl_down(acc, off, P);
+  return acc;
+}
+
+__host__ __device__ __forceinline__ int sub_lanes(int pairs, int T) {
+  int P = 16;
+  while (P > 1 && pairs * P > T) P >>= 1;
+  return P;
+}
+
+constexpr int kReduceThreads = 1024;
+
 template <bool BWD>
-__global__ __launch_bounds__(kThreads) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                             const float* __restrict__ dy, const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, int64_t N, int C4, int relu,
-                                                             double* __restrict__ partial /* [blocks][2][C] */) {
-  __shared__ double red[2][kThreads][4];
-  const int R = kThreads / C4;
+__global__ __launch_bounds__(kReduceThreads) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                   const float* __restrict__ dy, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, int64_t N, int C4, int relu,
+                                                                   double* __restrict__ partial /* [blocks][2][C] */) {
+  extern __shared__ __attribute__((aligned(16))) double red_raw[];
+  double (*red)[kReduceThreads][4] = reinterpret_cast<double (*)[kReduceThreads][4]>(red_raw);  // [2][T][4]
+  constexpr int T = kReduceThreads;
+  const int R = T / C4;
   const int r = threadIdx.x / C4, c4 = threadIdx.x - r * C4;
   const bool lane_ok = r < R;
   const int C = C4 * 4;
@@ -65,14 +89,45 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_kernel(const float* __rest
     red[1][threadIdx.x][j] = (double)s1[j];
   }
   __syncthreads();
-  // one thread per (quantity, channel): ordered sum over the R row lanes
-  for (int e = threadIdx.x; e < 2 * C; e += kThreads) {
+  const int P = sub_lanes(2 * C, T);
+  const int e = threadIdx.x / P, part = threadIdx.x - e * P;
+  if (e < 2 * C) {  // whole sub-lane groups take this branch together (P divides 64)
     const int q = e / C, c = e - q * C;
-    const int cc4 = c >> 2, j = c & 3;
-    double acc = 0.0;
-    for (int rr = 0; rr < R; ++rr) acc += red[q][rr * C4 + cc4][j];
-    partial[((int64_t)blockIdx.x * 2 + q) * C + c] = acc;
+    const double acc = column_total<T>(red, q, c, C4, R, part, P);
+    if (part == 0) partial[((int64_t)blockIdx.x * 2 + q) * C + c] = acc;
   }
+}
+
+constexpr int kApplyThreads = 512;
+constexpr int kFoldMaxC = 256;
+
+// every workgroup of an apply pass folds the statistics pass's partials [blocks][2][C] itself: row lanes stride over the
+// partials, then the same ordered column sum as above.  s / ss (both quantities of channel c) land in sums[0][c] / [1][c].
+__device__ __forceinline__ void fold_partials(const double* __restrict__ partial, int blocks, int C4,
+                                              double (*red)[kApplyThreads][4], double (*sums)[kFoldMaxC]) {
+  constexpr int T = kApplyThreads;
+  const int C = C4 * 4, R = T / C4;
+  const int r = threadIdx.x / C4, c4 = threadIdx.x - r * C4;
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (r < R) {
+    for (int b = r; b < blocks; b += R) {
+      const double* p = partial + (int64_t)b * 2 * C + c4 * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += p[j], a[4 + j] += p[C + j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[0][threadIdx.x][j] = a[j], red[1][threadIdx.x][j] = a[4 + j];
+  __syncthreads();
+  const int P = sub_lanes(2 * C, T);
+  const int e = threadIdx.x / P, part = threadIdx.x - e * P;
+  const int Rb = R < blocks ? R : blocks;  // row lanes past the partial count hold zeros
+  if (e < 2 * C) {
+    const int q = e / C, c = e - q * C;
+    const double acc = column_total<T>(red, q, c, C4, Rb, part, P);
+    if (part == 0) sums[q][c] = acc;
+  }
+  __syncthreads();
 }
 
 // one 64-thread workgroup per channel sums the per-workgroup partials: strided per-lane sums, then a fixed-order
@@ -167,6 +222,103 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ x, const float* __
       v = g - db * inv_n - xhat * (dw * inv_n);
     }
     reinterpret_cast<f32x4*>(dx)[t] = v * is * w;
+  }
+}
+
+// ---- apply passes that fold the finalize (training; C <= kFoldMaxC) ------------------------------------------------------
+// thread t walks elements t, t + G*T, ...: its float4 column advances by (G*T) % C4 per step (no 64-bit modulo in the loop)
+__global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const double* __restrict__ partial, int blocks, int64_t N,
+    const float* __restrict__ weight, const float* __restrict__ bias, int64_t total4, int C4, float eps, float momentum,
+    int relu, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ invstd,
+    float* __restrict__ running_mean, float* __restrict__ running_var) {
+  __shared__ double red[2][kApplyThreads][4];
+  __shared__ double sums[2][kFoldMaxC];
+  __shared__ __attribute__((aligned(16))) float stat[2][kFoldMaxC];
+  fold_partials(partial, blocks, C4, red, sums);
+  const int C = C4 * 4;
+  for (int c = threadIdx.x; c < C; c += kApplyThreads) {
+    const double m = sums[0][c] / (double)N;
+    double var = sums[1][c] / (double)N - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+    stat[0][c] = mu;
+    stat[1][c] = is;
+    if (blockIdx.x == 0) {
+      mean[c] = mu;
+      invstd[c] = is;
+      if (running_mean) {
+        const double unbiased = N > 1 ? var * ((double)N / (double)(N - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kApplyThreads;
+  const int step = (int)(stride % C4);
+  int64_t t = (int64_t)blockIdx.x * kApplyThreads + threadIdx.x;
+  int c4 = (int)(t % C4);
+#pragma unroll 4
+  for (; t < total4; t += stride) {
+    const f32x4 mu = reinterpret_cast<const f32x4*>(stat[0])[c4], is = reinterpret_cast<const f32x4*>(stat[1])[c4];
+    const f32x4 w = reinterpret_cast<const f32x4*>(weight)[c4], b = reinterpret_cast<const f32x4*>(bias)[c4];
+    f32x4 v = (reinterpret_cast<const f32x4*>(x)[t] - mu) * is * w + b;
+    if (res) v += reinterpret_cast<const f32x4*>(res)[t];
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(y)[t] = v;
+    c4 += step;
+    c4 = c4 >= C4 ? c4 - C4 : c4;
+  }
+}
+
+__global__ __launch_bounds__(kApplyThreads) void bn_apply_bwd_fold_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+    const double* __restrict__ partial, int blocks, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ weight, int64_t total4, int C4, float inv_n, int relu, int training,
+    float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dweight, float* __restrict__ dbias) {
+  __shared__ double red[2][kApplyThreads][4];
+  __shared__ double sums[2][kFoldMaxC];
+  __shared__ __attribute__((aligned(16))) float grad[2][kFoldMaxC];  // dbias, dweight
+  fold_partials(partial, blocks, C4, red, sums);
+  const int C = C4 * 4;
+  for (int c = threadIdx.x; c < C; c += kApplyThreads) {
+    const float db = (float)sums[0][c], dw = (float)sums[1][c];
+    grad[0][c] = db;
+    grad[1][c] = dw;
+    if (blockIdx.x == 0) {
+      dbias[c] = db;
+      dweight[c] = dw;
+    }
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kApplyThreads;
+  const int step = (int)(stride % C4);
+  int64_t t = (int64_t)blockIdx.x * kApplyThreads + threadIdx.x;
+  int c4 = (int)(t % C4);
+#pragma unroll 4
+  for (; t < total4; t += stride) {
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+    const f32x4 w = reinterpret_cast<const f32x4*>(weight)[c4];
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[t];
+    if (relu) {
+      const f32x4 yv = reinterpret_cast<const f32x4*>(y)[t];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+    }
+    if (dres) reinterpret_cast<f32x4*>(dres)[t] = g;
+    f32x4 v = g;
+    if (training) {
+      const f32x4 db = reinterpret_cast<const f32x4*>(grad[0])[c4], dw = reinterpret_cast<const f32x4*>(grad[1])[c4];
+      const f32x4 xhat = (reinterpret_cast<const f32x4*>(x)[t] - mu) * is;
+      v = g - db * inv_n - xhat * (dw * inv_n);
+    }
+    reinterpret_cast<f32x4*>(dx)[t] = v * is * w;
+    c4 += step;
+    c4 = c4 >= C4 ? c4 - C4 : c4;
   }
 }
 
@@ -307,12 +459,20 @@ __global__ __launch_bounds__(kThreads) void bn_small_bwd_kernel(
 }
 
 int reduce_blocks(int64_t N, int C4) {
-  const int R = kThreads / C4;
+  const int R = kReduceThreads / C4;
   int64_t b = gpn::cdiv(N, (int64_t)R * 8);
   if (b > kMaxBlocks) b = kMaxBlocks;
   if (b < 1) b = 1;
   return (int)b;
 }
+
+int fold_grid(int64_t total4) {
+  int64_t g = gpn::cdiv(total4, (int64_t)kApplyThreads * 4);
+  if (g > 256) g = 256;
+  return (int)(g < 1 ? 1 : g);
+}
+
+constexpr size_t kReduceLds = (size_t)2 * kReduceThreads * 4 * sizeof(double);
 
 int apply_grid(int64_t total4) {
   int64_t g = gpn::cdiv(total4, kThreads);
@@ -350,13 +510,20 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
   }
   const int blocks = reduce_blocks(N, C4);
   double* partial = static_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(blocks), dim3(kThreads), 0, stream, x, nullptr, nullptr, nullptr,
-                     nullptr, N, C4, 0, partial);
+  hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(blocks), dim3(kReduceThreads), kReduceLds, stream, x, nullptr, nullptr,
+                     nullptr, nullptr, N, C4, 0, partial);
   GPN_CHECK_LAUNCH();
+  const int64_t total4 = N * C4;
+  if (C <= kFoldMaxC) {
+    hipLaunchKernelGGL(bn_apply_fwd_fold_kernel, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, res, partial,
+                       blocks, N, weight, bias, total4, C4, eps, momentum, relu, y, mean, invstd, running_mean,
+                       running_var);
+    GPN_CHECK_LAUNCH();
+    return GPN_OK;
+  }
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, stream, partial, blocks, N, C,
                      eps, momentum, mean, invstd, running_mean, running_var);
   GPN_CHECK_LAUNCH();
-  const int64_t total4 = N * C4;
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, res, mean, invstd,
                      weight, bias, total4, C4, relu, y);
   GPN_CHECK_LAUNCH();
@@ -399,13 +566,20 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
   }
   const int blocks = reduce_blocks(N, C4);
   double* partial = static_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(blocks), dim3(kThreads), 0, stream, x, y, dy, mean, invstd, N, C4, relu,
-                     partial);
+  hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(blocks), dim3(kReduceThreads), kReduceLds, stream, x, y, dy, mean, invstd,
+                     N, C4, relu, partial);
   GPN_CHECK_LAUNCH();
+  const int64_t total4 = N * C4;
+  if (C <= kFoldMaxC) {
+    hipLaunchKernelGGL(bn_apply_bwd_fold_kernel, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, y, dy, partial,
+                       blocks, mean, invstd, weight, total4, C4, 1.0f / (float)N, relu, training, dx, dres, dweight,
+                       dbias);
+    GPN_CHECK_LAUNCH();
+    return GPN_OK;
+  }
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, stream, partial, blocks, C,
                      dweight, dbias);
   GPN_CHECK_LAUNCH();
-  const int64_t total4 = N * C4;
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, y, dy, mean, invstd,
                      weight, dweight, dbias, total4, C4, 1.0f / (float)N, relu, training, dx, dres);
   GPN_CHECK_LAUNCH();
