@@ -24,11 +24,16 @@ import torch.distributed as dist
 
 
 def _unet_buckets(model) -> List[List[torch.nn.Parameter]]:
-    """one list per SparseUNet whose executor program exists, in the executor's flat-gradient order"""
+    """one list per SparseUNet the native executor can express, in the executor's flat-gradient order.  Derived from the
+    module tree alone (the program is built here if the net has not run yet), so every rank gets the same buckets even
+    when a sub-network ran on some ranks only (no proposals on the others)."""
+    from .network import net_exec
     out = []
     for m in model.modules():
-        prog = m.__dict__.get("_net_program") if hasattr(m, "use_native_executor") else None
-        if prog:
+        if not getattr(m, "use_native_executor", False):
+            continue
+        prog = net_exec.program_for(m)
+        if prog is not None:
             order = list(prog.params())
             if order and all(p.requires_grad for p in order):
                 out.append(order)
@@ -43,8 +48,16 @@ class GradSync:
         self.model, self.group = model, group
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        # host-side consensus channel: the default group when it is gloo already, else a gloo twin of it
-        self.host_group = group if self.backend == "gloo" else dist.new_group(backend="gloo")
+        # host-side consensus channel: the default group when it is gloo already, else a gloo twin of it; if gloo cannot
+        # be brought up (no usable interface), the consensus goes over the device group and costs one device sync per step
+        self.host_group = group
+        if self.backend != "gloo":
+            try:
+                self.host_group = dist.new_group(backend="gloo")
+            except Exception as exc:  # noqa: BLE001 - any transport failure means "fall back", every rank fails alike
+                print(f"[grad_sync] gloo side channel unavailable ({type(exc).__name__}: {exc}); using the device group",
+                      flush=True)
+                self.host_group = None
         self.params = [p for p in model.parameters() if p.requires_grad]
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._buckets: Optional[List[List[int]]] = None
@@ -106,10 +119,15 @@ class GradSync:
     def sync(self):
         t0 = time.perf_counter()
         if self._buckets is None:
-            self._build_buckets()  # after the first backward: the executors' programs exist by now
+            self._build_buckets()
         params = self.params
         used = torch.tensor([p.grad is not None for p in params], dtype=torch.uint8)
-        dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.host_group)
+        if self.host_group is not None or self.backend == "gloo":
+            dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.host_group)
+        else:
+            on_dev = used.to(params[0].device, torch.int32)
+            dist.all_reduce(on_dev, op=dist.ReduceOp.MAX, group=self.group)
+            used = on_dev.cpu()
         used = used.tolist()
         self.stats["steps"] += 1
         for ids in self._buckets:
