@@ -139,7 +139,7 @@ class GAPartNetDataset(torch.utils.data.Dataset):
                  voxel_size: Tuple[float, float, float] = (1 / 100, 1 / 100, 1 / 100), few_shot: bool = False,
                  few_shot_num: int = 512, pos_jitter: float = 0., color_jitter: float = 0., flip_prob: float = 0.,
                  rotate_prob: float = 0., nopart_path: str = "data/nopart.txt", no_label: bool = False,
-                 voxelize_on_load: bool = False, device: Optional[torch.device] = None):
+                 voxelize_on_load: bool = False, device: Optional[torch.device] = None, device_pipeline: bool = False):
         paths = sorted(glob(os.path.join(str(root_dir), "*.pth")))
         self.nopart_files = []
         if os.path.exists(nopart_path):
@@ -155,6 +155,9 @@ class GAPartNetDataset(torch.utils.data.Dataset):
         self.max_points, self.augmentation, self.voxel_size = max_points, augmentation, tuple(voxel_size)
         self.aug = dict(pos_jitter=pos_jitter, color_jitter=color_jitter, flip_prob=flip_prob, rotate_prob=rotate_prob)
         self.no_label, self.voxelize_on_load, self.device = no_label, voxelize_on_load, device
+        # device_pipeline: hand over RAW scenes; compaction / augmentation / instance statistics / voxelisation then run
+        # per batch on the GPU (dataset/device_pipeline.py) instead of per scene in this worker
+        self.device_pipeline = device_pipeline
 
     def __len__(self):
         return len(self.pc_paths)
@@ -162,6 +165,8 @@ class GAPartNetDataset(torch.utils.data.Dataset):
     def _prepare(self, pc: PointCloud) -> PointCloud:
         if not bool((pc.instance_labels != -100).any()):
             raise ValueError(f"scene {pc.pc_id} has no labelled instance (the reference stops in ipdb, dataset/gapartnet.py:69-70)")
+        if self.device_pipeline:
+            return downsample(pc, max_points=self.max_points).to_tensor()
         pc = compact_instance_labels(downsample(pc, max_points=self.max_points))
         if self.augmentation:
             pc = apply_augmentations(pc, **self.aug)
@@ -198,7 +203,8 @@ class GAPartNetInst(LightningDataModule):
                  train_batch_size: int = 32, val_batch_size: int = 32, test_batch_size: int = 32, num_workers: int = 16,
                  pos_jitter: float = 0., color_jitter: float = 0., flip_prob: float = 0., rotate_prob: float = 0.,
                  train_few_shot: bool = False, val_few_shot: bool = False, intra_few_shot: bool = False,
-                 inter_few_shot: bool = False, few_shot_num: int = 256, train_with_all: bool = False):
+                 inter_few_shot: bool = False, few_shot_num: int = 256, train_with_all: bool = False,
+                 device_pipeline: bool = False):
         super().__init__()
         self.save_hyperparameters()
         self.root_dir, self.max_points, self.voxel_size = root_dir, max_points, tuple(voxel_size)
@@ -207,6 +213,7 @@ class GAPartNetInst(LightningDataModule):
         self.aug = dict(pos_jitter=pos_jitter, color_jitter=color_jitter, flip_prob=flip_prob, rotate_prob=rotate_prob)
         self.few = dict(train=train_few_shot, val=val_few_shot, intra=intra_few_shot, inter=inter_few_shot)
         self.few_shot_num, self.train_with_all = few_shot_num, train_with_all
+        self.device_pipeline = device_pipeline  # not a reference kwarg: per-batch scene preparation on the GPU
 
     def _dataset(self, split: str, sub: str, augmentation: bool, shuffle: bool):
         few = self.few[split]
@@ -215,10 +222,11 @@ class GAPartNetInst(LightningDataModule):
             n = min(n, self.few_shot_num) if few else n
             seed0 = {"train": 1000, "val": 2000, "intra": 3000, "inter": 4000}[split]
             return SyntheticGAPartNetDataset(n, self.max_points, seed0, augmentation=augmentation, voxel_size=self.voxel_size,
-                                             **(self.aug if augmentation else {}))
+                                             device_pipeline=self.device_pipeline, **(self.aug if augmentation else {}))
         return GAPartNetDataset(os.path.join(self.root_dir, sub, "pth"), shuffle=shuffle, max_points=self.max_points,
                                 augmentation=augmentation, voxel_size=self.voxel_size, few_shot=few,
-                                few_shot_num=self.few_shot_num, **(self.aug if augmentation else {}))
+                                few_shot_num=self.few_shot_num, device_pipeline=self.device_pipeline,
+                                **(self.aug if augmentation else {}))
 
     def setup(self, stage: Optional[str] = None):
         if stage in (None, "fit", "validate"):

@@ -48,9 +48,10 @@ class DevicePrefetcher:
     """``for batch in DevicePrefetcher(loader, model, device)``: batches come out collated, voxelised and with the
     backbone's rulebooks built, each prepared on a side stream while the previous one trains."""
 
-    def __init__(self, batches: Iterable, model, device: torch.device):
+    def __init__(self, batches: Iterable, model, device: torch.device, augmentation: Optional[dict] = None):
         assert device.type == "cuda", "batch preparation runs on the GPU (the product has no CPU path)"
         self.batches, self.model, self.device = batches, model, device
+        self.augmentation = augmentation  # for raw scenes (dataset device_pipeline=True): drawn per batch, applied on the GPU
         self.stream = torch.cuda.Stream(device=device)
 
     def _prepare(self, raw):
@@ -61,7 +62,9 @@ class DevicePrefetcher:
                 batch = raw
             else:
                 pcs = [pc.to(self.device) if hasattr(pc, "to") else pc for pc in raw]
-                batch = PointCloud.collate(pcs, voxel_size=self.model.voxel_size)
+                raw_scenes = pcs[0].num_instances is None and pcs[0].instance_labels is not None
+                batch = PointCloud.collate(pcs, voxel_size=self.model.voxel_size,
+                                           augmentation=self.augmentation if raw_scenes else None)
             backbone = getattr(self.model, "backbone", None)
             if backbone is not None and getattr(backbone, "use_native_executor", False) and batch.voxel_tensor is not None:
                 from ..network import net_exec

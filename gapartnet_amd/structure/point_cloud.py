@@ -74,9 +74,17 @@ class PointCloud:
 
     # -------------------------------------------------------------------------------------------------
     @staticmethod
-    def collate(point_clouds: Sequence["PointCloud"], voxel_size: Optional[Sequence[float]] = None) -> PointCloudBatch:
+    def collate(point_clouds: Sequence["PointCloud"], voxel_size: Optional[Sequence[float]] = None,
+                augmentation: Optional[Dict[str, float]] = None) -> PointCloudBatch:
         n_scenes = len(point_clouds)
         first = point_clouds[0]
+        if first.num_instances is None and first.instance_labels is not None and first.voxel_coords is None:
+            # raw scenes (GAPartNetDataset(device_pipeline=True)): label compaction, augmentation and the per-instance
+            # statistics run here, per batch, on the scenes' device
+            from ..dataset.device_pipeline import prepare_batch
+            assert voxel_size is not None, "un-voxelised scenes need voxel_size"
+            return prepare_batch(point_clouds, voxel_size, augmentation)
+        assert not augmentation, "augmentation at collate time needs raw scenes (GAPartNetDataset(device_pipeline=True))"
         device = first.points.device
         counts = [int(pc.points.shape[0]) for pc in point_clouds]
 

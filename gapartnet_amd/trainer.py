@@ -151,7 +151,9 @@ class Trainer:
             feed = train_dataloaders
             if self.device.type == "cuda" and hasattr(model, "voxel_size"):
                 from .dataset.prefetch import DevicePrefetcher
-                feed = DevicePrefetcher(train_dataloaders, model, self.device)  # batch i+1 prepared while batch i trains
+                aug = getattr(datamodule, "aug", None) if getattr(datamodule, "device_pipeline", False) else None
+                # batch i+1 prepared while batch i trains (raw scenes are also augmented there, per batch, on the GPU)
+                feed = DevicePrefetcher(train_dataloaders, model, self.device, augmentation=aug)
             for batch_idx, batch in enumerate(feed):
                 if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
                     break

@@ -286,3 +286,42 @@ def test_validation_epoch_on_the_gpu_matches_the_oracle_path(cuda):
     for key in cpu:
         assert np.isfinite(gpu[key]), key
         assert abs(cpu[key] - gpu[key]) <= 1e-3 * max(1.0, abs(cpu[key])), (key, cpu[key], gpu[key])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("augment", [False, True])
+def test_prefetcher_prepares_raw_scenes_on_the_gpu(cuda, augment):
+    """a device_pipeline dataset hands over raw scenes; label compaction, augmentation, per-instance
+    statistics and voxelisation run per batch on the prefetch stream.  Checked against the per-scene CPU loader functions
+    (dataset/gapartnet.py, the restatement of the reference loader), then trained on for one step."""
+    from gapartnet_amd.dataset import gapartnet as ds
+    from gapartnet_amd.dataset import synthetic
+    from gapartnet_amd.dataset.prefetch import DevicePrefetcher
+    aug = dict(pos_jitter=0.05, color_jitter=0.1, flip_prob=0.5, rotate_prob=0.5) if augment else None
+    scenes = [synthetic.make_scene(5100 + i, 6000) for i in range(3)]
+    np.random.seed(5)
+    want = []
+    for pc in scenes:
+        pc = ds.compact_instance_labels(pc)
+        if aug:
+            pc = ds.apply_augmentations(pc, **aug)
+        want.append(ds.generate_inst_info(pc).to_tensor())
+    model = make_model((0, 0), channels=[16, 32, 48]).to(cuda)
+    np.random.seed(5)
+    feed = iter(DevicePrefetcher([[pc.to_tensor() for pc in scenes]], model, cuda, augmentation=aug))
+    batch = next(feed)
+    torch.cuda.synchronize()
+    assert batch.points.is_cuda and batch.num_instances == [pc.num_instances for pc in want]
+    assert torch.equal(batch.instance_labels.cpu(), torch.cat([pc.instance_labels for pc in want]))
+    assert torch.allclose(batch.points.cpu(), torch.cat([pc.points for pc in want]), rtol=0, atol=2e-6)
+    assert torch.allclose(batch.instance_regions.cpu(), torch.cat([pc.instance_regions for pc in want]), rtol=0, atol=3e-6)
+    for s, pc in enumerate(want):
+        assert torch.equal(batch.num_points_per_instance[s, :pc.num_instances].cpu(), pc.num_points_per_instance)
+        assert torch.equal(batch.instance_sem_labels[s, :pc.num_instances].cpu(), pc.instance_sem_labels)
+    if not augment:  # identical coordinates => identical voxels as the per-scene-prepared batch
+        ref = PointCloud.collate([pc.to(cuda) for pc in want], voxel_size=model.voxel_size)
+        assert torch.equal(batch.voxel_tensor.indices, ref.voxel_tensor.indices)
+        assert torch.equal(batch.pc_voxel_id, ref.pc_voxel_id)
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    assert torch.isfinite(loss)
