@@ -76,10 +76,10 @@ def test_raw_scenes_collate_like_prepared_scenes():
     from gapartnet_amd import backend
     from gapartnet_amd.structure.point_cloud import PointCloud
     from oracle import torch_ops
-    backend.use(torch_ops)
     scenes = _scenes()
-    a = PointCloud.collate([pc.to_tensor() for pc in scenes], voxel_size=(0.01, 0.01, 0.01))
-    b = PointCloud.collate(_per_scene_reference(scenes, None), voxel_size=(0.01, 0.01, 0.01))
+    with backend.using(torch_ops):
+        a = PointCloud.collate([pc.to_tensor() for pc in scenes], voxel_size=(0.01, 0.01, 0.01))
+        b = PointCloud.collate(_per_scene_reference(scenes, None), voxel_size=(0.01, 0.01, 0.01))
     assert a.num_instances == b.num_instances
     for name in ("points", "batch_indices", "sem_labels", "instance_labels", "pc_voxel_id", "num_points_per_instance",
                  "instance_sem_labels", "gt_npcs"):
