@@ -284,38 +284,50 @@ def _compute_ap_per_class(tp: torch.Tensor, fp: torch.Tensor, num_gt_instances) 
 
 
 def compute_ap(proposals: List[Instances], num_classes: int = 9, iou_threshold: float = 0.5, device="cpu") -> List[float]:
-    """per-class AP over a list of per-batch proposal sets (grouping_utils.py:360-454): proposals visited by
-    descending confidence; a proposal is a true positive if its best-IoU ground-truth instance of the same class
-    exceeds the threshold and is still unmatched.  The greedy matching is inherently sequential; here it runs on host
-    copies of the small per-batch tables (no per-proposal device round trips)."""
+    """per-class AP over a list of per-batch proposal sets (grouping_utils.py:360-454).
+
+    The reference walks the proposals in descending confidence, one Python iteration (and several device round trips) each:
+    a proposal is a true positive if its best-IoU ground-truth instance of the same class exceeds the threshold and is
+    still unmatched.  A proposal's best instance does not depend on the matching state, and an instance is matched
+    exactly when the FIRST proposal (in confidence order) that clears the threshold on it is reached - so the walk is
+    equivalent to: candidates = proposals whose best same-class IoU > threshold; true positives = the first candidate of
+    every (set, scene, instance) key in confidence order.  That form is evaluated here with array operations
+    (SURVEY.md §8f rank 2); oracle/eval_ap.py keeps the sequential walk as the checker."""
+    n_total = sum(int(p.score_preds.shape[0]) for p in proposals)
+    inst_labels = [p.instance_sem_labels.detach().cpu().numpy() for p in proposals]
+    gt_classes = np.concatenate([l.reshape(-1) for l in inst_labels]) if inst_labels else np.zeros((0,), np.int32)
+    if n_total == 0:
+        return [0.0 for _ in range(1, num_classes)]
     conf = torch.cat([p.score_preds for p in proposals]).detach().cpu()
     classes = torch.cat([p.pt_sem_classes for p in proposals]).detach().cpu().numpy()
     order = torch.argsort(conf, descending=True).numpy()
-    n_total = conf.shape[0]
-    set_of = np.concatenate([np.full(p.score_preds.shape[0], i, np.int64) for i, p in enumerate(proposals)]) \
-        if n_total else np.zeros((0,), np.int64)
-    sample_of = np.concatenate([p.batch_indices[p.proposal_offsets[:-1].long()].long().cpu().numpy()
-                                for p in proposals]) if n_total else np.zeros((0,), np.int64)
-    local_of = np.concatenate([np.arange(p.score_preds.shape[0]) for p in proposals]) if n_total else np.zeros((0,), np.int64)
-    inst_labels = [p.instance_sem_labels.detach().cpu().numpy() for p in proposals]
-    ious = [p.ious.detach().cpu().numpy() for p in proposals]
-    matched = [np.zeros(l.shape, dtype=bool) for l in inst_labels]
 
+    best_iou = np.zeros(n_total, np.float64)
+    key = np.zeros(n_total, np.int64)
+    start, key_base = 0, 0
+    for s, p in enumerate(proposals):
+        n = int(p.score_preds.shape[0])
+        labels = inst_labels[s]                                   # [scenes, W]
+        width = labels.shape[1] if labels.ndim == 2 else 0
+        if n and width:
+            sample = p.batch_indices[p.proposal_offsets[:-1].long()].long().cpu().numpy()
+            ious = p.ious.detach().cpu().numpy()                      # [n, W]
+            row = np.where(labels[sample] == classes[start:start + n, None], ious, 0.0)
+            best = row.argmax(1)                                      # first maximum, like the sequential walk
+            best_iou[start:start + n] = row[np.arange(n), best]
+            key[start:start + n] = key_base + sample * width + best
+        key_base += int(labels.shape[0]) * max(width, 1)
+        start += n
+
+    ranked_key, ranked_iou = key[order], best_iou[order]
+    cand = np.nonzero(ranked_iou > iou_threshold)[0]                  # ranks of the candidates, ascending
     tp = np.zeros(n_total, np.float32)
-    fp = np.zeros(n_total, np.float32)
-    for rank, idx in enumerate(order):
-        s, smp, loc, cls = set_of[idx], sample_of[idx], local_of[idx], classes[idx]
-        row = np.where(inst_labels[s][smp] == cls, ious[s][loc], 0.0)
-        best = int(row.argmax()) if row.shape[0] else 0
-        best_iou = float(row[best]) if row.shape[0] else 0.0
-        if best_iou > iou_threshold and not matched[s][smp, best]:
-            tp[rank] = 1.0
-            matched[s][smp, best] = True
-        else:
-            fp[rank] = 1.0
+    if cand.shape[0]:
+        _, first = np.unique(ranked_key[cand], return_index=True)     # first candidate of every instance key
+        tp[cand[first]] = 1.0
+    fp = 1.0 - tp
 
     sorted_classes = classes[order]
-    gt_classes = np.concatenate([l.reshape(-1) for l in inst_labels]) if inst_labels else np.zeros((0,), np.int32)
     tp_t, fp_t = torch.from_numpy(tp), torch.from_numpy(fp)
     aps: List[float] = []
     for c in range(1, num_classes):
