@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-end measurement on the GPU box: GPU tests, default bench line, per-kernel rooflines, rocprofv3 kernel stats of the
+# bench, and the two PMC passes behind profiles/traffic.json.  Every step is bounded by `timeout`; nothing reads stdin.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/final
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+timeout 400 python -m pytest "$R/tests" -m gpu -q > "$O/pytest_gpu.txt" 2>&1 < /dev/null; tail -2 "$O/pytest_gpu.txt"
+timeout 240 python "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err" < /dev/null; cut -c1-260 "$O/bench_default.json"
+timeout 200 python "$R/tools/kernel_rooflines.py" > "$O/kernel_rooflines.txt" 2>&1 < /dev/null; tail -3 "$O/kernel_rooflines.txt"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o t -- python "$R/bench.py" --steps 16 --warmup 4 --no-cpu-baseline > "$O/bench_under_rocprof.log" 2>&1 < /dev/null
+f=$(find /tmp/p1 -name "*kernel_stats.csv" 2>/dev/null | head -1)
+if [ -n "$f" ]; then cp "$f" "$O/kernel_stats.csv"; python "$R/tools/gpu_categories.py" "$f" 21 > "$O/gpu_time_by_category.txt" 2>&1 < /dev/null; fi
+f=$(find /tmp/p1 -name "*kernel_trace.csv" 2>/dev/null | head -1)
+if [ -n "$f" ]; then python "$R/tools/summarize_trace.py" "$f" "$O/conv_kernels_by_grid.csv" "spconv,wgrad,bn_,ccl_" > /dev/null 2>&1 < /dev/null; fi
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+  f=$(find /tmp/p_$c -name "*counter_collection.csv" 2>/dev/null | head -1)
+  if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_$c.txt" 2>&1 < /dev/null; fi
+done
+ls -la "$O"
