@@ -94,12 +94,17 @@ __device__ __forceinline__ int32_t uf_find(int32_t* parent, int32_t x) {
   }
   return x;
 }
-// union of two ROOT candidates (either may have been hooked meanwhile); larger under smaller
+// union of two ROOT candidates (either may have been hooked meanwhile); larger under smaller.  The word a CAS targets is
+// first read coherently: thousands of lanes of neighbouring vertices want the same link, one CAS makes it, and the rest
+// must not queue read-modify-writes on that word just to learn that it is done.
 __device__ __forceinline__ void uf_union(int32_t* parent, int32_t ra, int32_t rb) {
   while (ra != rb) {
     if (ra < rb) { const int32_t tmp = ra; ra = rb; rb = tmp; }
-    const int32_t old = atomicCAS(parent + ra, ra, rb);
-    if (old == ra) break;
+    int32_t old = __hip_atomic_load(parent + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == ra) {
+      old = atomicCAS(parent + ra, ra, rb);
+      if (old == ra) break;
+    }
     ra = uf_find(parent, old);
     rb = uf_find(parent, rb);
   }
@@ -126,6 +131,16 @@ __global__ void ccl_init_kernel(const int32_t* __restrict__ begin_end, const int
   if (lane == 0) parent[v] = m;
 }
 
+// the initial forest follows index gradients through space: chains of dozens of hops.  Climbing them once per VERTEX here
+// (with halving, so that concurrent climbers shorten each other's way) instead of once per EDGE in the hook step is
+// what makes the hook step's "same parent" test hit for almost every edge inside a tree.
+__global__ void ccl_compress_kernel(int32_t* parent, int64_t Q) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  const int32_t r = uf_find(parent, (int32_t)i);
+  if (r != (int32_t)i) __hip_atomic_store(parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __global__ void ccl_hook_kernel(const int32_t* __restrict__ begin_end, const int32_t* __restrict__ edges,
                                 int64_t Q, int32_t* parent) {
   const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -148,7 +163,14 @@ __global__ void ccl_hook_kernel(const int32_t* __restrict__ begin_end, const int
       const int32_t o = __shfl_xor(m, off, 64);
       m = o < m ? o : m;
     }
-    uf_union(parent, r, m);
+    // one union per DISTINCT root in the wave (the lanes of a vertex mostly see one or two neighbouring trees)
+    uint64_t todo = __builtin_amdgcn_ballot_w64(r != m);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const int32_t rl = __builtin_amdgcn_readlane(r, leader);
+      if (lane == leader) uf_union(parent, rl, m);
+      todo &= ~__builtin_amdgcn_ballot_w64(r == rl);
+    }
   }
 }
 
@@ -340,6 +362,8 @@ extern "C" int gpn_ccl(const int32_t* begin_end, const int32_t* edges, int64_t Q
   gpn::ProfScope prof(GPN_K_CCL, stream, 0.0, 4.0 * ((double)E + 2.0 * (double)Q) + 4.0 * (double)Q);
   hipLaunchKernelGGL(ccl_init_kernel, dim3((int)gpn::cdiv(Q * 64, kThreads)), dim3(kThreads), 0, stream, begin_end, edges,
                      Q, parent);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ccl_compress_kernel, dim3(grid), dim3(kThreads), 0, stream, parent, Q);
   GPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(ccl_hook_kernel, dim3((int)gpn::cdiv(Q * 64, kThreads)), dim3(kThreads), 0, stream,
                      begin_end, edges, Q, parent);
