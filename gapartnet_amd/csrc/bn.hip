@@ -2,10 +2,10 @@
 // it in every block of the reference network (network/backbone.py:40-49: relu(bn(conv(x)) [+ shortcut])).
 //
 // HBM-streaming kernels: [N, C] row-major with C in 16..224, read as float4.  Training forward = statistics pass
-// (<= 64 workgroups x 1024 threads, per-workgroup partial sums in double for a cancellation-safe variance) + one apply
+// (<= 128 workgroups x 1024 threads, per-workgroup partial sums in double for a cancellation-safe variance) + one apply
 // pass that also adds the residual and applies ReLU.  Backward = one reduction pass (sum g, sum g*xhat with the ReLU
 // mask folded in) + one apply pass producing dx (and the residual's gradient).  There is no finalize launch: every
-// workgroup of the apply pass folds the <= 64 partials itself (L2-resident, ~1 us) and workgroup 0 also stores mean /
+// workgroup of the apply pass folds the <= 128 partials itself (L2-resident, ~1 us) and workgroup 0 also stores mean /
 // 1/std / running statistics (forward) or dweight / dbias (backward) - a 64-thread finalize launch between the two
 // passes cost 4.5 us of GPU time and one host launch per layer and pass (176 per training step of the default model).  Compared with separate BatchNorm / add / ReLU kernels this removes three full read+write passes per
 // layer in forward and two in backward.  All reductions are fixed-order (deterministic).
@@ -19,7 +19,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 64;  // statistics-pass workgroups = partials every apply workgroup folds
+constexpr int kMaxBlocks = 128;  // statistics-pass workgroups = partials every apply workgroup folds
 
 // thread layout for column-wise reductions: c4 = tid % C4 (float4 column), r = tid / C4 (row lane), R = T / C4 rows
 
@@ -460,7 +460,9 @@ __global__ __launch_bounds__(kThreads) void bn_small_bwd_kernel(
 
 int reduce_blocks(int64_t N, int C4) {
   const int R = kReduceThreads / C4;
-  int64_t b = gpn::cdiv(N, (int64_t)R * 8);
+  // two rows per thread: the mid-size levels are latency-bound (a thread's rows are a serial chain of loads), the large
+  // ones need every CU they can get; 8 rows per thread made both ~2x slower (rocprofv3, profiles/r01_kernels_by_grid.csv)
+  int64_t b = gpn::cdiv(N, (int64_t)R * 2);
   if (b > kMaxBlocks) b = kMaxBlocks;
   if (b < 1) b = 1;
   return (int)b;
