@@ -328,8 +328,9 @@ constexpr int kSmallRows = 1024;
 // lanes; thread t -> column t % CG, row lane t / CG.
 // fixed-order sums of eight values per thread over the threads that share a column, all eight in one tree (one pair
 // of barriers); results valid in every thread of that column
-template <int CG>
-__device__ __forceinline__ void column_sum8(double (&v)[8], double (*scratch)[CG][8] /* [4][CG][8] */) {
+template <int CG, int T>
+__device__ __forceinline__ void column_sum8(double (&v)[8], double (*scratch)[CG][8] /* [T / 64][CG][8] */) {
+  constexpr int W = T / 64;
 #pragma unroll
   for (int off = 32; off >= CG; off >>= 1) {
 #pragma unroll
@@ -342,18 +343,28 @@ __device__ __forceinline__ void column_sum8(double (&v)[8], double (*scratch)[CG
   __syncthreads();
   const int cg = threadIdx.x % CG;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) v[q] = (scratch[0][cg][q] + scratch[1][cg][q]) + (scratch[2][cg][q] + scratch[3][cg][q]);
+  for (int q = 0; q < 8; ++q) {
+    double t[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) t[w] = scratch[w][cg][q];
+#pragma unroll
+    for (int step = 1; step < W; step <<= 1) {  // fixed pairwise tree over the waves
+#pragma unroll
+      for (int w = 0; w + step < W; w += 2 * step) t[w] += t[w + step];
+    }
+    v[q] = t[0];
+  }
 }
 
 // single-launch training forward for small N
-template <int CG>
-__global__ __launch_bounds__(kThreads) void bn_small_fwd_kernel(
+template <int CG, int T>
+__global__ __launch_bounds__(T) void bn_small_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ weight,
     const float* __restrict__ bias, int N, int C4, float eps, float momentum, int relu, float* __restrict__ y,
     float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
     float* __restrict__ running_var) {
-  __shared__ double scratch[4][CG][8];
-  constexpr int R = kThreads / CG;
+  __shared__ double scratch[T / 64][CG][8];
+  constexpr int R = T / CG;
   const int c4 = blockIdx.x * CG + threadIdx.x % CG;
   const int rl = threadIdx.x / CG;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void bn_small_fwd_kernel(
   double sums[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) sums[j] = (double)s0[j], sums[4 + j] = (double)s1[j];
-  column_sum8<CG>(sums, scratch);
+  column_sum8<CG, T>(sums, scratch);
   f32x4 mu, is;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -402,14 +413,14 @@ __global__ __launch_bounds__(kThreads) void bn_small_fwd_kernel(
 }
 
 // single-launch backward for small N (same layout): dweight / dbias, then dx (and dres)
-template <int CG>
-__global__ __launch_bounds__(kThreads) void bn_small_bwd_kernel(
+template <int CG, int T>
+__global__ __launch_bounds__(T) void bn_small_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
     const float* __restrict__ weight, const float* __restrict__ mean, const float* __restrict__ invstd, int N, int C4,
     int relu, int training, float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dweight,
     float* __restrict__ dbias) {
-  __shared__ double scratch[4][CG][8];
-  constexpr int R = kThreads / CG;
+  __shared__ double scratch[T / 64][CG][8];
+  constexpr int R = T / CG;
   const int c4 = blockIdx.x * CG + threadIdx.x % CG;
   const int rl = threadIdx.x / CG;
   const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
@@ -429,7 +440,7 @@ __global__ __launch_bounds__(kThreads) void bn_small_bwd_kernel(
   double sums[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) sums[j] = (double)s0[j], sums[4 + j] = (double)s1[j];
-  column_sum8<CG>(sums, scratch);
+  column_sum8<CG, T>(sums, scratch);
   f32x4 db, dw;
 #pragma unroll
   for (int j = 0; j < 4; ++j) db[j] = (float)sums[j], dw[j] = (float)sums[4 + j];
@@ -501,11 +512,13 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
   GPN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   const int C4 = C / 4;
   if (N <= kSmallRows) {
+    // (the forward kernel stays at 256 threads: at 1024 it measured 51 us instead of 10 - every thread carries the
+    // double-precision mean / 1/sqrt epilogue; the backward kernel, three streams and no epilogue, gains from 1024)
     if (C4 % 4 == 0)
-      hipLaunchKernelGGL(bn_small_fwd_kernel<4>, dim3(C4 / 4), dim3(kThreads), 0, stream, x, res, weight, bias, (int)N,
+      hipLaunchKernelGGL((bn_small_fwd_kernel<4, 256>), dim3(C4 / 4), dim3(256), 0, stream, x, res, weight, bias, (int)N,
                          C4, eps, momentum, relu, y, mean, invstd, running_mean, running_var);
     else
-      hipLaunchKernelGGL(bn_small_fwd_kernel<1>, dim3(C4), dim3(kThreads), 0, stream, x, res, weight, bias, (int)N, C4,
+      hipLaunchKernelGGL((bn_small_fwd_kernel<1, 256>), dim3(C4), dim3(256), 0, stream, x, res, weight, bias, (int)N, C4,
                          eps, momentum, relu, y, mean, invstd, running_mean, running_var);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
@@ -557,11 +570,15 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
   GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
   const int C4 = C / 4;
   if (N <= kSmallRows) {
-    if (C4 % 4 == 0)
-      hipLaunchKernelGGL(bn_small_bwd_kernel<4>, dim3(C4 / 4), dim3(kThreads), 0, stream, x, y, dy, weight, mean, invstd,
+    // few workgroups, each a serial chain of row loads: 1024 threads per workgroup keep the chain one batch long
+    if (C4 % 4 == 0 && N > 256)
+      hipLaunchKernelGGL((bn_small_bwd_kernel<4, 1024>), dim3(C4 / 4), dim3(1024), 0, stream, x, y, dy, weight, mean, invstd,
+                         (int)N, C4, relu, training, dx, dres, dweight, dbias);
+    else if (C4 % 4 == 0)
+      hipLaunchKernelGGL((bn_small_bwd_kernel<4, 256>), dim3(C4 / 4), dim3(256), 0, stream, x, y, dy, weight, mean, invstd,
                          (int)N, C4, relu, training, dx, dres, dweight, dbias);
     else
-      hipLaunchKernelGGL(bn_small_bwd_kernel<1>, dim3(C4), dim3(kThreads), 0, stream, x, y, dy, weight, mean, invstd,
+      hipLaunchKernelGGL((bn_small_bwd_kernel<1, 256>), dim3(C4), dim3(256), 0, stream, x, y, dy, weight, mean, invstd,
                          (int)N, C4, relu, training, dx, dres, dweight, dbias);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
