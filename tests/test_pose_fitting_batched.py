@@ -41,7 +41,13 @@ def test_batched_fit_equals_the_sequential_fit_for_the_same_picks(seed, monkeypa
     npcs = torch.from_numpy(np.concatenate([c[1] for c in clouds]))
     got = estimate_pose_from_npcs_batched(xyz, npcs, offsets, picks=picks)
     for p, (cx, cn) in enumerate(clouds):
-        bbox, scale, rot, trans, transform, idx = _sequential_with_picks(cx, cn, picks[p].numpy(), monkeypatch)
+        try:
+            bbox, scale, rot, trans, transform, idx = _sequential_with_picks(cx, cn, picks[p].numpy(), monkeypatch)
+        except IndexError:
+            # a duplicated single point whose mean is not exact gives a finite garbage fit, and the reference then indexes
+            # its one-row xyz with inlier index 1 (pose_fitting.py:141 there): it crashes; the batched form reports no pose
+            assert cx.shape[0] == 1 and not bool(got["valid"][p])
+            continue
         if scale[0] is None:
             assert not bool(got["valid"][p]), p
             assert bool(torch.isnan(got["bbox"][p]).all())
