@@ -66,3 +66,23 @@ def test_batched_fit_equals_the_sequential_fit_for_the_same_picks(seed, monkeypa
     # (the reference scores a hypothesis with transform @ source although the fit is in the row-vector convention
     # target = source @ (sR) + t, so even exact data has a non-zero "residual": reproduced, not repaired)
     assert bool(got["valid"][0])
+
+
+@pytest.mark.gpu
+def test_batched_fit_on_the_gpu_matches_the_cpu(cuda):
+    rng = np.random.default_rng(11)
+    specs = [(400, 0.01, 0.2)] * 6 + [(30, 0.0, 0.0), (1, 0.0, 0.0), (900, 0.02, 0.4)]
+    clouds = [_proposal(rng, *sp) for sp in specs]
+    sizes = [c[0].shape[0] for c in clouds]
+    np.random.seed(3)
+    picks = draw_picks(sizes, 100)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]))
+    xyz = torch.from_numpy(np.concatenate([c[0] for c in clouds])).float()
+    npcs = torch.from_numpy(np.concatenate([c[1] for c in clouds])).float()
+    want = estimate_pose_from_npcs_batched(xyz, npcs, offsets, picks=picks)
+    got = estimate_pose_from_npcs_batched(xyz.to(cuda), npcs.to(cuda), offsets.to(cuda), picks=picks.to(cuda))
+    assert torch.equal(got["valid"].cpu(), want["valid"]) and int(want["valid"].sum()) >= 7
+    assert torch.equal(got["inlier_mask"].cpu(), want["inlier_mask"])
+    ok = want["valid"]
+    for name in ("scale", "rotation", "translation", "transform", "bbox"):
+        assert torch.allclose(got[name].cpu()[ok], want[name][ok], atol=1e-8), name
