@@ -90,7 +90,7 @@ def test_modules_on_the_gpu_match_the_oracle_path(cuda):
     results = []
     for dev, ops in (("cpu", torch_ops), (cuda, None)):
         sa_d, fp_d = sa.to(dev).train(), fp.to(dev).train()
-        x, f = xyz.to(dev), feats.to(dev).requires_grad_(True)
+        x, f = xyz.to(dev), feats.detach().clone().to(dev).requires_grad_(True)
         ctx = backend.using(ops) if ops is not None else backend.using(backend.raw())
         with ctx:
             centres, coarse = sa_d(x, f)
