@@ -246,16 +246,34 @@ int dispatch_wgrad_nt(int nt, const float* in, const float* dout, const int32_t*
 }
 
 // ------------------------------------------------------------------------------------------------ G
-__global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, int64_t n,
-                                   int C4, float* __restrict__ out) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * C4) return;
-  const int64_t i = t / C4;
-  const int c = (int)(t - i * C4);
-  const int32_t r = idx[i];
-  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (r >= 0) v = reinterpret_cast<const f32x4*>(table)[(int64_t)r * C4 + c];
-  reinterpret_cast<f32x4*>(out)[t] = v;
+// U float4 elements per thread, the U index loads issued together and then the U row loads together: two memory round
+// trips per U elements (one element per thread ran at half the bandwidth of a copy of the same size - every wave was a
+// serial idx -> row chain and the launch needed two rounds of waves); 32-bit element arithmetic
+template <int U>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx,
+                                                          uint32_t total4, uint32_t C4, float* __restrict__ out) {
+  const uint32_t T = gridDim.x * blockDim.x;
+  const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t r[U];
+  uint32_t c[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const uint32_t t = t0 + (uint32_t)k * T;
+    const uint32_t row = t < total4 ? t / C4 : 0u;
+    c[k] = t - row * C4;
+    r[k] = t < total4 ? idx[row] : -1;
+  }
+  f32x4 v[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (r[k] >= 0) v[k] = reinterpret_cast<const f32x4*>(table)[(uint64_t)(uint32_t)r[k] * C4 + c[k]];
+  }
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const uint32_t t = t0 + (uint32_t)k * T;
+    if (t < total4) reinterpret_cast<f32x4*>(out)[t] = v[k];
+  }
 }
 __global__ void gather_rows_scalar_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx,
                                           int64_t n, int C, float* __restrict__ out) {
@@ -277,6 +295,29 @@ __global__ void scatter_rows_csr_kernel(const float* __restrict__ dout, const in
   float acc = 0.f;
   for (int32_t j = starts[r]; j < starts[r + 1]; ++j) acc += dout[(int64_t)order[j] * C + c];
   dtable[t] = acc;
+}
+// float4 form (C % 4 == 0): same order of additions per channel; the first two points of a row are fetched together
+// (rows hold 1.1 points on average: the common case is one order -> row chain, not a loop)
+__global__ __launch_bounds__(256) void scatter_rows_csr_v4_kernel(const float* __restrict__ dout,
+                                                                   const int32_t* __restrict__ order,
+                                                                   const int32_t* __restrict__ starts, uint32_t total4,
+                                                                   uint32_t C4, float* __restrict__ dtable) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total4) return;
+  const uint32_t r = t / C4, c = t - r * C4;
+  const int32_t b = starts[r], e = starts[r + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (b < e) {
+    const int32_t p0 = order[b];
+    const int32_t p1 = b + 1 < e ? order[b + 1] : -1;
+    const f32x4 v0 = reinterpret_cast<const f32x4*>(dout)[(uint64_t)(uint32_t)p0 * C4 + c];
+    f32x4 v1 = {0.f, 0.f, 0.f, 0.f};
+    if (p1 >= 0) v1 = reinterpret_cast<const f32x4*>(dout)[(uint64_t)(uint32_t)p1 * C4 + c];
+    acc = acc + v0;
+    if (p1 >= 0) acc = acc + v1;
+    for (int32_t j = b + 2; j < e; ++j) acc = acc + reinterpret_cast<const f32x4*>(dout)[(uint64_t)(uint32_t)order[j] * C4 + c];
+  }
+  reinterpret_cast<f32x4*>(dtable)[t] = acc;
 }
 
 }  // namespace
@@ -343,9 +384,14 @@ extern "C" int gpn_gather_rows(const float* table, const int32_t* idx, int64_t n
   GPN_CHECK_ARG(n >= 0 && C >= 1);
   if (n == 0) return GPN_OK;
   GPN_CHECK_ARG(table && idx && out);
-  if (C % 4 == 0) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((int)gpn::cdiv(n * (C / 4), 256)), dim3(256), 0, stream, table,
-                       idx, n, C / 4, out);
+  if (C % 4 == 0 && n * (C / 4) < (int64_t)0x7fffffff) {
+    const int64_t total4 = n * (C / 4);
+    if (total4 >= 4 * 256 * 256)  // enough elements to keep every CU busy with 4 per thread
+      hipLaunchKernelGGL(gather_rows_kernel<4>, dim3((int)gpn::cdiv(total4, 4 * 256)), dim3(256), 0, stream, table, idx,
+                         (uint32_t)total4, (uint32_t)(C / 4), out);
+    else
+      hipLaunchKernelGGL(gather_rows_kernel<1>, dim3((int)gpn::cdiv(total4, 256)), dim3(256), 0, stream, table, idx,
+                         (uint32_t)total4, (uint32_t)(C / 4), out);
   } else {
     hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((int)gpn::cdiv(n * C, 256)), dim3(256), 0, stream, table,
                        idx, n, C, out);
@@ -360,8 +406,12 @@ extern "C" int gpn_scatter_rows_csr(const float* dout, const int32_t* order, con
   GPN_CHECK_ARG(n_rows >= 0 && C >= 1);
   if (n_rows == 0) return GPN_OK;
   GPN_CHECK_ARG(starts && dtable);  // dout / order may be NULL when no point exists (every starts[r] is then 0)
-  hipLaunchKernelGGL(scatter_rows_csr_kernel, dim3((int)gpn::cdiv(n_rows * C, 256)), dim3(256), 0, stream, dout,
-                     order, starts, n_rows, C, dtable);
+  if (C % 4 == 0 && n_rows * (C / 4) < (int64_t)0x7fffffff)
+    hipLaunchKernelGGL(scatter_rows_csr_v4_kernel, dim3((int)gpn::cdiv(n_rows * (C / 4), 256)), dim3(256), 0, stream, dout,
+                       order, starts, (uint32_t)(n_rows * (C / 4)), (uint32_t)(C / 4), dtable);
+  else
+    hipLaunchKernelGGL(scatter_rows_csr_kernel, dim3((int)gpn::cdiv(n_rows * C, 256)), dim3(256), 0, stream, dout,
+                       order, starts, n_rows, C, dtable);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

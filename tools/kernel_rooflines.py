@@ -35,14 +35,25 @@ t = timeit(lambda: dst.copy_(src), iters=10)
 COPY_BW = 2 * src.numel() * 4 / t / 1e3
 del src, dst
 print(f"measured float4 copy bandwidth: {COPY_BW:.0f} GB/s ({COPY_BW / HBM_PEAK:.2f} of the 8 TB/s peak)\n")
-print(f"{'kernel family (row of SURVEY 8a)':58s} {'us':>8s} {'alg MB':>8s} {'GB/s':>7s} {'/peak':>6s} {'/copy':>6s} {'TF':>6s} {'/mfma':>6s}")
+print("(/copy = fraction of the 1 GiB copy bandwidth; /same = fraction of what a float4 copy moving the SAME number of bytes\n"
+      " achieves in this run - the bandwidth a kernel of this size can reach at all: launch + ramp are a fixed ~4 us)\n")
+print(f"{'kernel family (row of SURVEY 8a)':58s} {'us':>8s} {'alg MB':>8s} {'GB/s':>7s} {'/peak':>6s} {'/copy':>6s} {'/same':>6s} {'TF':>6s} {'/mfma':>6s}")
+_copy_cache = {}
+
+
+def same_size_copy_us(nbytes):
+    n = max(int(nbytes) // 8 // 4 * 4, 4)  # floats read = floats written = nbytes / 8
+    if n not in _copy_cache:
+        a, b = torch.empty(n, dtype=torch.float32, device=dev).normal_(), torch.empty(n, dtype=torch.float32, device=dev)
+        _copy_cache[n] = timeit(lambda: b.copy_(a))
+    return _copy_cache[n]
 
 
 def row(name, us, nbytes, flops=0.0):
     gbs = nbytes / us / 1e3
     tf = flops / us / 1e6
     print(f"{name:58s} {us:8.1f} {nbytes / 1e6:8.2f} {gbs:7.0f} {gbs / HBM_PEAK:6.3f} {gbs / COPY_BW:6.3f} "
-          f"{tf:6.2f} {tf / MFMA_PEAK:6.3f}")
+          f"{same_size_copy_us(nbytes) / us:6.3f} {tf:6.2f} {tf / MFMA_PEAK:6.3f}")
 
 
 pcs = [pc.to(dev) for pc in make_batch(8, 20000)]
