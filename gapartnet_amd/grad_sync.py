@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 
-def _unet_buckets(model) -> List[List[torch.nn.Parameter]]:
+def _unet_buckets(model):
     """one list per SparseUNet the native executor can express, in the executor's flat-gradient order.  Derived from the
     module tree alone (the program is built here if the net has not run yet), so every rank gets the same buckets even
     when a sub-network ran on some ranks only (no proposals on the others)."""
@@ -36,7 +36,7 @@ def _unet_buckets(model) -> List[List[torch.nn.Parameter]]:
         if prog is not None:
             order = list(prog.params())
             if order and all(p.requires_grad for p in order):
-                out.append(order)
+                out.append((order, prog))
     return out
 
 
@@ -80,16 +80,30 @@ class GradSync:
 
     # ------------------------------------------------------------------------------------------------
     def _build_buckets(self):
-        taken, buckets = set(), []
-        for order in _unet_buckets(self.model):
+        taken, buckets, progs = set(), [], []
+        for order, prog in _unet_buckets(self.model):
             ids = [self._index[id(p)] for p in order if id(p) in self._index]
             if len(ids) == len(order) and not (taken & set(ids)):
                 buckets.append(ids)
+                progs.append(prog)
                 taken.update(ids)
         rest = [i for i in range(len(self.params)) if i not in taken]
         if rest:
             buckets.append(rest)
-        self._buckets = buckets
+            progs.append(None)
+        self._buckets, self._progs = buckets, progs
+
+    def _executor_flat(self, prog, first_grad, last_grad, total) -> Optional[torch.Tensor]:
+        """the executor's own gradient buffer of this step if ``.grad`` of the bucket's first and last parameter are its
+        first and last slice (autograd hands the slices over without copying when ``.grad`` was None): an O(1) test in
+        place of walking all ~100 gradients"""
+        flat = getattr(prog, "last_pgrad", None)
+        if flat is None or flat.numel() != total or first_grad is None or last_grad is None:
+            return None
+        base = flat.data_ptr()
+        if first_grad.data_ptr() != base or last_grad.data_ptr() + last_grad.numel() * 4 != base + total * 4:
+            return None
+        return flat
 
     @staticmethod
     def _shared_flat(grads) -> Optional[torch.Tensor]:
@@ -130,7 +144,13 @@ class GradSync:
             used = on_dev.cpu()
         used = used.tolist()
         self.stats["steps"] += 1
-        for ids in self._buckets:
+        for ids, prog in zip(self._buckets, self._progs):
+            if prog is not None and used[ids[0]] and used[ids[-1]]:
+                flat = self._executor_flat(prog, params[ids[0]].grad, params[ids[-1]].grad, prog.grad_total)
+                if flat is not None:
+                    self._all_reduce_mean(flat)
+                    self.stats["in_place"] += 1
+                    continue
             live = [i for i in ids if used[i]]
             if not live:
                 self.stats["skipped"] += 1

@@ -101,6 +101,8 @@ class NetProgram:
         self.conv_off = np.concatenate([[0], np.cumsum(self.conv_numel)])
         self.conv_ops = [(i, op) for i, op in enumerate(self.ops) if op[0] == OP_CONV]
         self.grad_sizes = [int(v) for v in self.conv_numel] + [int(v) for v in self.bn_C] * 2  # flat gradient buffer layout
+        self.grad_total = int(sum(self.grad_sizes))
+        self.last_pgrad = None
         self.signature = self._signature(unet)
 
     # ------------------------------------------------------------------ program construction
@@ -344,6 +346,7 @@ class _NetFn(torch.autograd.Function):
         din = garena[:features.numel()].view_as(features) if need_in else None
         # one split for all 3 x n tensors (a slice + view per parameter costs ~600 dispatches per pass)
         pieces = pgrad.split(prog.grad_sizes)
+        prog.last_pgrad = pgrad  # grad_sync all-reduces this buffer in place (the slices below become .grad)
         grads = [pieces[i].view_as(params[i]) for i in range(n_conv)] + list(pieces[n_conv:])
         ctx.state = None
         return (din, None, None, None, *grads)
