@@ -184,8 +184,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int part = threadIdx.x & 15;
   const int64_t e = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   float acc = 0.f;
-  if (e < elems)
-    for (int s = part; s < S; s += 16) acc += partial[(int64_t)s * elems + e];
+  if (e < elems) {
+    // four slices in flight per lane (same order of additions): with one load per iteration the loop was a chain of
+    // S / 16 memory round trips
+    const float* __restrict__ p = partial + e;
+    int s = part;
+    for (; s + 48 < S; s += 64) {
+      const float v0 = p[(int64_t)s * elems], v1 = p[(int64_t)(s + 16) * elems];
+      const float v2 = p[(int64_t)(s + 32) * elems], v3 = p[(int64_t)(s + 48) * elems];
+      acc += v0;
+      acc += v1;
+      acc += v2;
+      acc += v3;
+    }
+    for (; s < S; s += 16) acc += p[(int64_t)s * elems];
+  }
 #pragma unroll
   for (int off = 8; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 16);
   if (part == 0 && e < elems) {

@@ -366,7 +366,16 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int sp
   if (t >= elems4) return;
   const f32x4* p = reinterpret_cast<const f32x4*>(partial);
   f32x4 acc = p[t];
-  for (int s = 1; s < splits; ++s) acc += p[(int64_t)s * elems4 + t];
+  int s = 1;
+  for (; s + 3 < splits; s += 4) {  // four slices in flight, added in slice order
+    const f32x4 v0 = p[(int64_t)s * elems4 + t], v1 = p[(int64_t)(s + 1) * elems4 + t];
+    const f32x4 v2 = p[(int64_t)(s + 2) * elems4 + t], v3 = p[(int64_t)(s + 3) * elems4 + t];
+    acc += v0;
+    acc += v1;
+    acc += v2;
+    acc += v3;
+  }
+  for (; s < splits; ++s) acc += p[(int64_t)s * elems4 + t];
   reinterpret_cast<f32x4*>(out)[t] = acc;
 }
 

@@ -8,6 +8,7 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python -m pytest "$R/tests" -m gpu -q > "$O/pytest_gpu.txt" 2>&1 < /dev/null; tail -2 "$O/pytest_gpu.txt"
 timeout 240 python "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err" < /dev/null; cut -c1-260 "$O/bench_default.json"
+GPN_BENCH_FORCE_GRAD_SYNC=1 timeout 240 python "$R/bench.py" --no-cpu-baseline > "$O/bench_forced_grad_sync.json" 2> /dev/null < /dev/null
 timeout 200 python "$R/tools/kernel_rooflines.py" > "$O/kernel_rooflines.txt" 2>&1 < /dev/null; tail -3 "$O/kernel_rooflines.txt"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o t -- python "$R/bench.py" --steps 16 --warmup 4 --no-cpu-baseline > "$O/bench_under_rocprof.log" 2>&1 < /dev/null
 f=$(find /tmp/p1 -name "*kernel_stats.csv" 2>/dev/null | head -1)
