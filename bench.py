@@ -134,7 +134,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world == 1 and os.environ.get("GPN_BENCH_FORCE_GRAD_SYNC") == "1":  # a 1-rank RCCL group: the exchange on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        from gapartnet_amd.trainer import native_stdout_to_stderr
+        with native_stdout_to_stderr():
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
     from gapartnet_amd import _C, functional as GF
     from gapartnet_amd.smoke import make_batch, make_model
     _C.lib()  # fail loudly if the HIP extension is missing

@@ -53,7 +53,9 @@ class GradSync:
         self.host_group = group
         if self.backend != "gloo":
             try:
-                self.host_group = dist.new_group(backend="gloo")
+                from .trainer import native_stdout_to_stderr
+                with native_stdout_to_stderr():  # gloo announces its connections on stdout
+                    self.host_group = dist.new_group(backend="gloo")
             except Exception as exc:  # noqa: BLE001 - any transport failure means "fall back", every rank fails alike
                 print(f"[grad_sync] gloo side channel unavailable ({type(exc).__name__}: {exc}); using the device group",
                       flush=True)
@@ -66,7 +68,8 @@ class GradSync:
     # ------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
         """what DDP does at construction: every rank starts from rank ``src``'s parameters and buffers"""
-        with torch.no_grad():
+        from .trainer import native_stdout_to_stderr
+        with torch.no_grad(), native_stdout_to_stderr():  # the first collective may be what brings the communicator up
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
                     dist.broadcast(t.data, src, group=self.group)

@@ -9,7 +9,9 @@ for the small heads) between ``backward()`` and ``optimizer.step()``; BatchNorm 
 (no SyncBN).  Sub-networks the training schedule leaves without gradients in early epochs keep
 ``grad is None`` on every rank — the behaviour the reference gets from DDP's ``find_unused_parameters``.
 """
+import contextlib
 import os
+import sys
 import time
 from collections import defaultdict
 from typing import Dict, List, Optional
@@ -17,6 +19,21 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+
+@contextlib.contextmanager
+def native_stdout_to_stderr():
+    """RCCL and gloo print banners ("RCCL version : ...", "[Gloo] Rank 0 is connected ...") on the C-level stdout when a
+    communicator comes up; callers whose stdout is a protocol (bench.py: ONE JSON line) wrap communicator creation in this"""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def distributed_env():
@@ -37,8 +54,9 @@ def init_distributed(device_type: str = "cuda"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         nccl = use_cuda and not share
-        dist.init_process_group(backend="nccl" if nccl else "gloo", rank=rank, world_size=world,
-                                **({"device_id": device} if nccl else {}))
+        with native_stdout_to_stderr():
+            dist.init_process_group(backend="nccl" if nccl else "gloo", rank=rank, world_size=world,
+                                    **({"device_id": device} if nccl else {}))
     return rank, local_rank, world, device
 
 
