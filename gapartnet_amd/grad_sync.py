@@ -148,7 +148,9 @@ class GradSync:
         used = used.tolist()
         self.stats["steps"] += 1
         for ids, prog in zip(self._buckets, self._progs):
-            if prog is not None and used[ids[0]] and used[ids[-1]]:
+            # (every rank must reduce the same number of elements: the whole-buffer path only when the consensus says every
+            # parameter of the bucket has a gradient somewhere - which is always the case for a net that ran)
+            if prog is not None and all(used[i] for i in ids):
                 flat = self._executor_flat(prog, params[ids[0]].grad, params[ids[-1]].grad, prog.grad_total)
                 if flat is not None:
                     self._all_reduce_mean(flat)
