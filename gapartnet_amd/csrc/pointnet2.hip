@@ -323,6 +323,94 @@ extern "C" int gpn_pn2_gather_points_grad(int b, int c, int n, int npoints, cons
   return GPN_OK;
 }
 
+// ---- the same sampling for big clouds (pre-processing: N ~ 1e5..1e6 -> 20 000 samples) -------------------------------
+// One workgroup streams all N points through one CU every iteration (16 MB per iteration at N = 1e6: ~200 us, x 20 000).
+// Here G workgroups share a cloud: each owns a contiguous chunk of the points (and of `temp`), reduces its chunk to one
+// candidate, publishes it, and all G meet at a counter barrier; every workgroup then reduces the G candidates itself, so
+// the winner never has to be broadcast.  The candidate order is the single-workgroup kernel's (fps_better: distance, then
+// the reference's thread-id tie-break, then index), so the samples are identical.  All b * G workgroups must be resident
+// at once (b * G <= number of CUs; the host picks G accordingly).
+__global__ __launch_bounds__(1024) void pn2_fps_multi_kernel(int n, int m, int bmask, int G,
+                                                             const float* __restrict__ dataset, float* __restrict__ temp,
+                                                             int32_t* __restrict__ idxs, float* cand_v /* [b][2][G] */,
+                                                             int* cand_k /* [b][2][G] */, unsigned* arrived /* [b] */) {
+  __shared__ float wv[16];
+  __shared__ int wk[16];
+  __shared__ int s_old;
+  const int bs = blockIdx.x / G, w = blockIdx.x - bs * G;
+  const float* d = dataset + (int64_t)bs * n * 3;
+  float* t = temp + (int64_t)bs * n;
+  int32_t* out = idxs + (int64_t)bs * m;
+  float* cv = cand_v + (int64_t)bs * 2 * G;
+  int* ck = cand_k + (int64_t)bs * 2 * G;
+  unsigned* counter = arrived + bs;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = (n + G - 1) / G;
+  const int lo = w * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  int old = 0;
+  if (w == 0 && tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = d[old * 3], y1 = d[old * 3 + 1], z1 = d[old * 3 + 2];
+    float best = -1.f;
+    int besti = 0x7fffffff;
+    for (int k = lo + tid; k < hi; k += 1024) {
+      const float dd = dist2_nofma(d[k * 3], d[k * 3 + 1], d[k * 3 + 2], x1, y1, z1);
+      const float tk = t[k];
+      const float d2 = dd < tk ? dd : tk;
+      t[k] = d2;
+      if (fps_better(d2, k, best, besti, bmask)) { best = d2; besti = k; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float ov = __shfl_down(best, off, 64);
+      const int ok = __shfl_down(besti, off, 64);
+      if (lane + off < 64 && fps_better(ov, ok, best, besti, bmask)) { best = ov; besti = ok; }
+    }
+    if (lane == 0) { wv[wave] = best; wk[wave] = besti; }
+    __syncthreads();
+    const int slot = (j & 1) * G;
+    if (wave == 0) {
+      float v = lane < 16 ? wv[lane] : -2.f;
+      int k = lane < 16 ? wk[lane] : 0x7fffffff;
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const float ov = __shfl_down(v, off, 64);
+        const int ok = __shfl_down(k, off, 64);
+        if (fps_better(ov, ok, v, k, bmask)) { v = ov; k = ok; }
+      }
+      if (lane == 0) {
+        __hip_atomic_store(cv + slot + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ck + slot + w, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)G * (unsigned)j;  // j-th meeting of G workgroups (m * G < 2^32: host-checked)
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+        __threadfence();
+      }
+      // lane 0 has passed the barrier; the wave re-converges here and reads every workgroup's candidate (G <= 64)
+      __threadfence();  // every lane: the candidate reads below stay behind lane 0's acquire
+      float gv = -2.f;
+      int gk = 0x7fffffff;
+      if (lane < G) {
+        gv = __hip_atomic_load(cv + slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gk = __hip_atomic_load(ck + slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_down(gv, off, 64);
+        const int ok = __shfl_down(gk, off, 64);
+        if (lane + off < 64 && fps_better(ov, ok, gv, gk, bmask)) { gv = ov; gk = ok; }
+      }
+      if (lane == 0) {
+        s_old = gk;
+        if (w == 0) out[j] = gk;
+      }
+    }
+    __syncthreads();
+    old = s_old;
+  }
+}
+
 extern "C" int gpn_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
                                                int32_t* idxs, gpn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -331,6 +419,47 @@ extern "C" int gpn_pn2_furthest_point_sampling(int b, int n, int m, const float*
   GPN_CHECK_ARG(dataset && temp && idxs);
   const int bref = opt_n_threads(n);
   hipLaunchKernelGGL(pn2_fps_kernel, dim3(b), dim3(1024), 0, stream, n, m, bref - 1, dataset, temp, idxs);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+// workgroups per cloud of the multi-workgroup form: as many as fit on the chip together, at most 64 (one wave reduces the
+// candidates), none for clouds a single workgroup handles faster than a chip-wide barrier per sample costs
+static int fps_groups(int b, int n) {
+  if (n < 65536 || b < 1) return 1;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 1;
+  int g = cus / b;
+  if (g > 64) g = 64;
+  return g < 2 ? 1 : g;
+}
+
+extern "C" size_t gpn_pn2_furthest_point_sampling_ws_bytes(int b, int n) {
+  const int G = fps_groups(b, n);
+  if (G == 1) return 0;
+  return gpn::align_up((size_t)b * 2 * G * sizeof(float)) + gpn::align_up((size_t)b * 2 * G * sizeof(int)) +
+         gpn::align_up((size_t)b * sizeof(unsigned));
+}
+
+extern "C" int gpn_pn2_furthest_point_sampling_ws(int b, int n, int m, const float* dataset, float* temp, int32_t* idxs,
+                                                  void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(b >= 0 && n >= 1 && m >= 0);
+  if (b == 0 || m == 0) return GPN_OK;
+  const int G = fps_groups(b, n);
+  if (G == 1) return gpn_pn2_furthest_point_sampling(b, n, m, dataset, temp, idxs, stream_);
+  GPN_CHECK_ARG(dataset && temp && idxs);
+  GPN_CHECK_ARG((int64_t)m * G < (int64_t)0x7fffffff);
+  gpn::WsCarver carve(ws, ws_bytes);
+  float* cand_v = carve.take<float>((size_t)b * 2 * G);
+  int* cand_k = carve.take<int>((size_t)b * 2 * G);
+  unsigned* arrived = carve.take<unsigned>((size_t)b);
+  GPN_CHECK_WS(carve);
+  GPN_CHECK_HIP(hipMemsetAsync(arrived, 0, (size_t)b * sizeof(unsigned), stream));
+  const int bref = opt_n_threads(n);
+  hipLaunchKernelGGL(pn2_fps_multi_kernel, dim3(b * G), dim3(1024), 0, stream, n, m, bref - 1, G, dataset, temp, idxs,
+                     cand_v, cand_k, arrived);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

@@ -574,8 +574,10 @@ def pn2_furthest_point_sampling(xyz, npoint):
     b, n, _ = xyz.shape
     temp = torch.full((b, n), 1e10, dtype=torch.float32, device=dev)
     idx = torch.zeros((b, npoint), dtype=torch.int32, device=dev)
-    check(_C.lib().gpn_pn2_furthest_point_sampling(i32(b), i32(n), i32(npoint), ptr(xyz), ptr(temp), ptr(idx), _stream()),
-          "gpn_pn2_furthest_point_sampling")
+    L = _C.lib()
+    ws = _ws(L.gpn_pn2_furthest_point_sampling_ws_bytes(i32(b), i32(n)), dev)  # non-empty only for clouds of >= 65536 points
+    check(L.gpn_pn2_furthest_point_sampling_ws(i32(b), i32(n), i32(npoint), ptr(xyz), ptr(temp), ptr(idx), ptr(ws),
+                                               szt(ws.numel()), _stream()), "gpn_pn2_furthest_point_sampling_ws")
     return idx
 
 

@@ -353,6 +353,12 @@ int gpn_pn2_gather_points_grad(int b, int c, int n, int npoints, const float* gr
  * opt_n_threads(n) (cuda_utils.h:10-14). */
 int gpn_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
                                     int32_t* idxs, gpn_stream_t stream);
+/* same samples; clouds of >= 65536 points are shared by several workgroups (the pre-processing call,
+ * dataset/process_tools/convert_rendered_into_input.py:115 of the reference: N ~ 1e5..1e6 -> 20 000). ws may be NULL when
+ * gpn_pn2_furthest_point_sampling_ws_bytes returns 0. */
+size_t gpn_pn2_furthest_point_sampling_ws_bytes(int b, int n);
+int gpn_pn2_furthest_point_sampling_ws(int b, int n, int m, const float* dataset, float* temp, int32_t* idxs,
+                                       void* ws, size_t ws_bytes, gpn_stream_t stream);
 /* interpolate_gpu.cu:81-124 / :9-57 / :149-169 / :192-214 */
 int gpn_pn2_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
                      int32_t* idx, gpn_stream_t stream);

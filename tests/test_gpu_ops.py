@@ -2,6 +2,7 @@
 CPU oracle on the same seeded inputs.  Integer outputs (voxel ids, rulebooks, neighbour lists, labels, argmax,
 NMS keep lists, FPS / kNN indices) must be bit-exact; floating-point outputs are compared with the tolerance
 written next to each check (north_star: 1e-4 for features)."""
+import ctypes
 import os
 
 import numpy as np
@@ -588,3 +589,26 @@ def test_fused_point_losses_match_the_torch_formulas(H, cuda, case):
     gw = torch.autograd.grad((want * wts).sum(), [logits, offsets])
     assert torch.allclose(gg[0], gw[0], rtol=1e-4, atol=1e-9)
     assert torch.allclose(gg[1], gw[1], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_fps_big_cloud_shared_by_workgroups(H, cuda):
+    """>= 65536 points: several workgroups share a cloud (counter barrier per sample); the samples are those of the
+    single-workgroup kernel and of the oracle, including ties (a grid of points has many equal distances)"""
+    rng = np.random.default_rng(3)
+    n = 70000
+    cloud = rng.random((n, 3)).astype(np.float32)
+    side = int(round(n ** (1 / 3))) + 1
+    gx = np.stack(np.meshgrid(*[np.arange(side, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n] * 0.25
+    xyz = np.stack([cloud, gx])
+    got = host(H.pn2_furthest_point_sampling(dev(xyz, cuda), 300))
+    assert np.array_equal(got, O.pn2_furthest_point_sampling(xyz, 300))
+    # the plain entry point (one workgroup per cloud) on the same input
+    t = torch.from_numpy(xyz).to(cuda)
+    temp = torch.full((2, n), 1e10, dtype=torch.float32, device=cuda)
+    idx = torch.zeros((2, 300), dtype=torch.int32, device=cuda)
+    from gapartnet_amd import _C
+    rc = _C.lib().gpn_pn2_furthest_point_sampling(2, n, 300, ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(temp.data_ptr()),
+                                                  ctypes.c_void_p(idx.data_ptr()),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and np.array_equal(idx.cpu().numpy(), got)
