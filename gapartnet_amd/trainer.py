@@ -61,7 +61,7 @@ def init_distributed(device_type: str = "cuda"):
 
 
 class _TrainStep(nn.Module):
-    """``forward`` routed to the module's ``training_step`` (the callable a DDP-style wrapper needs; tools/ddp_profile.py)."""
+    """``forward`` routed to the module's ``training_step`` (the callable a DDP-style wrapper needs; tools/exchange_profile.py)."""
 
     def __init__(self, module):
         super().__init__()
