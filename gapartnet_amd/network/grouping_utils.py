@@ -164,6 +164,27 @@ def segmented_voxelize(pt_xyz: torch.Tensor, pt_features: torch.Tensor, segment_
 
 
 # ------------------------------------------------------------------------------------------------- clustering
+_SIZE_LADDER_WARMED = set()
+
+
+def warm_size_dependent_kernels(device: torch.device) -> None:
+    """torch's sort / scan / select pick a different rocPRIM kernel family per input-size class, and HIP loads a kernel's code
+    the first time it is launched: the first step whose foreground-point count falls into a new class stalled 40-50 ms in
+    ``aten::sort`` (tools/hiccup_probe.py: step 23 of a cold run, when the half-trained network's foreground set shrinks).
+    Touch every size class once, up front, per device."""
+    if device.type != "cuda" or device.index in _SIZE_LADDER_WARMED:
+        return
+    _SIZE_LADDER_WARMED.add(device.index)
+    for p in range(6, 22):
+        n = (1 << p) - 3
+        for dtype in (torch.int32, torch.int64):
+            keys = torch.arange(n, device=device, dtype=dtype).flip(0) // 3
+            torch.sort(keys, stable=True)
+            torch.cumsum(keys, 0)
+            torch.unique_consecutive(keys, return_inverse=True, return_counts=True)
+        torch.nonzero(keys > (n // 6))
+
+
 def cluster_proposals(pt_xyz: torch.Tensor, batch_indices: torch.Tensor, batch_offsets: torch.Tensor,
                       sem_preds: torch.Tensor, ball_query_radius: float, max_num_points_per_query: int
                       ) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -171,6 +192,7 @@ def cluster_proposals(pt_xyz: torch.Tensor, batch_indices: torch.Tensor, batch_o
     (grouping_utils.py:108-140).  Components are labelled by their minimum point index and the sort is stable, so
     proposals come out ordered by first member and members in ascending point order."""
     K = int(max_num_points_per_query)
+    warm_size_dependent_kernels(pt_xyz.device)
     neighbours, counts = ball_query(pt_xyz, pt_xyz, batch_indices, batch_offsets, ball_query_radius, K,
                                     point_labels=sem_preds, query_labels=sem_preds)
     begin = torch.arange(pt_xyz.shape[0], dtype=torch.int32, device=pt_xyz.device) * K

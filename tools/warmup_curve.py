@@ -12,11 +12,15 @@ pool = [[pc.to(dev) for pc in make_batch(8, 20000, seed0=1000 + 8 * j)] for j in
 N = int(os.environ.get("STEPS", 200))
 feed = iter(DevicePrefetcher((pool[i % 2] for i in range(N)), model, dev))
 torch.cuda.synchronize()
-t0 = time.perf_counter()
+t0 = t_step = time.perf_counter()
 for i in range(N):
     opt.zero_grad(set_to_none=True)
     loss = model.training_step(next(feed), i)
     loss.backward(); opt.step()
+    if os.environ.get("PER_STEP") and 18 <= i < 32:
+        torch.cuda.synchronize()
+        print(f"  step {i}: {(time.perf_counter() - t_step) * 1e3:.1f} ms", flush=True)
+    t_step = time.perf_counter()
     if i % 10 == 9:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
