@@ -90,8 +90,8 @@ __global__ __launch_bounds__(kReduceThreads) void bn_reduce_kernel(const float* 
   }
   __syncthreads();
   const int P = sub_lanes(2 * C, T);
-  const int e = threadIdx.x / P, part = threadIdx.x - e * P;
-  if (e < 2 * C) {  // whole sub-lane groups take this branch together (P divides 64)
+  const int part = threadIdx.x % P;
+  for (int e = threadIdx.x / P; e < 2 * C; e += T / P) {  // whole sub-lane groups iterate together (P divides 64); C > T / 2: several rounds
     const int q = e / C, c = e - q * C;
     const double acc = column_total<T>(red, q, c, C4, R, part, P);
     if (part == 0) partial[((int64_t)blockIdx.x * 2 + q) * C + c] = acc;

@@ -298,7 +298,9 @@ def test_fps_tie_break_small_cloud(H, cuda):
 @pytest.mark.parametrize("N,C,relu,with_res,training", [(20000, 16, True, True, True), (777, 48, True, False, True),
                                                           (136, 112, False, False, True), (5000, 32, True, True, False),
                                                           (3, 16, True, False, True), (1024, 64, True, True, True),
-                                                          (1025, 16, True, True, True), (900, 20, True, True, True)])
+                                                          (1025, 16, True, True, True), (900, 20, True, True, True),
+                                                          (3000, 224, True, True, True), (2000, 320, True, False, True),
+                                                          (1500, 768, True, True, True)])
 def test_fused_batchnorm_matches_torch(H, cuda, N, C, relu, with_res, training):
     """fp32 torch.nn.functional.batch_norm (+ add + relu) is the reference for this floating-point kernel family;
     tolerance 1e-4 (north_star) on outputs, 1e-3 relative on the reduced parameter gradients."""
