@@ -118,3 +118,13 @@ def test_grad_sync_mean_and_unused_semantics(tmp_path):
         assert l1[name] is not None or name.startswith("b."), name
         want = (g0 + g1) / 2
         assert torch.allclose(s0[name], want, rtol=0, atol=1e-6) and torch.equal(s0[name], s1[name]), name
+
+
+def test_four_rank_training_keeps_ranks_identical(tmp_path):
+    """the same trainer path at world_size 4 (the driver's N = 4 launch): every collective of GradSync - parameter broadcast,
+    host-side used-set consensus, bucket all-reduces - with more than two participants"""
+    mp.spawn(_worker, args=(4, _free_port(), (5, 10), str(tmp_path)), nprocs=4, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "result.pt"), weights_only=False)
+    assert res["params_equal"] and res["finite"] and res["loss"] > 0
+    seen = [set(i) for i in res["ids"]]
+    assert [len(s) for s in seen] == [2, 2, 2, 2] and len(set().union(*seen)) == 8, "4 disjoint shards of the 8 scenes"
