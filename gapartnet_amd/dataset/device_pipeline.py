@@ -18,7 +18,7 @@ float32 summation by at most an ulp (summed in float64 here); augmented coordina
 3-term float64 dot product.  Every function is plain torch and also runs on CPU tensors (that is how the CPU tests pin
 it against the per-scene functions in dataset/gapartnet.py).
 """
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch

@@ -9,7 +9,7 @@ with the reference's signature for per-scene use on device tensors.
 import copy
 import os
 from glob import glob
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import torch

@@ -8,7 +8,7 @@ A scene is a partial scan of a cuboid "object" (its three camera-facing faces) c
 rotation, then centred and scaled into the unit ball exactly like convert_rendered_into_input.py:71-87.
 Semantic label 0 = "others" (instance -100), parts get a class in 1..9 and NPCS coordinates in [-0.5, 0.5]^3.
 """
-from typing import List, Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 

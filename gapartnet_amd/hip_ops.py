@@ -5,7 +5,7 @@ raises if given non-CUDA tensors — there is no CPU path in the product (the CP
 and is test infrastructure).
 """
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

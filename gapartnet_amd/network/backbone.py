@@ -15,7 +15,6 @@ from typing import Callable, List, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import backend
 from .. import functional as GF

@@ -2,8 +2,7 @@
 (reference: gapartnet/network/grouping_utils.py:14-454) — same function names and results, written over the
 HIP operators (epic_ops mirrors) and restructured to stay on the device.
 """
-from dataclasses import fields, replace
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -12,7 +11,6 @@ from ..epic_ops.ball_query import ball_query
 from ..epic_ops.ccl import connected_components_labeling
 from ..epic_ops.nms import nms
 from ..epic_ops.reduce import segmented_reduce
-from .. import backend
 from .. import functional as GF
 from ..structure.instances import Instances
 
