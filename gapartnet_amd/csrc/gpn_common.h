@@ -21,6 +21,9 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// per-device caches (occupancy, side streams, helper threads) are arrays indexed by the HIP device ordinal
+constexpr int kMaxDevices = 64;
+
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }

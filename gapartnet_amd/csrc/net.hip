@@ -184,9 +184,9 @@ struct SideStream {
 };
 
 SideStream* side_stream() {
-  static SideStream per_device[64];
+  static SideStream per_device[gpn::kMaxDevices];
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= gpn::kMaxDevices) return nullptr;
   SideStream& s = per_device[dev];
   if (!s.stream) {
     int lo = 0, hi = 0;
@@ -413,9 +413,19 @@ class WgradWorker {
   std::string err_;
 };
 
-WgradWorker& wgrad_worker() {
-  static WgradWorker* w = new WgradWorker();  // leaked on purpose: the detached thread may outlive static destructors
-  return *w;
+// one worker (thread + pass lock) per device: passes on different devices of one process do not serialise, and nothing
+// here is keyed by "the" device of the process
+struct DeviceWorker {
+  std::mutex pass_mu;  // one backward pass at a time per device (a worker serves a single pass)
+  WgradWorker worker;
+};
+
+DeviceWorker& device_worker(int dev) {
+  static std::mutex mu;
+  static DeviceWorker* per_device[gpn::kMaxDevices] = {};  // leaked on purpose: detached threads may outlive static destructors
+  std::lock_guard<std::mutex> lk(mu);
+  if (!per_device[dev]) per_device[dev] = new DeviceWorker();
+  return *per_device[dev];
 }
 
 // hand a gradient buffer to a producer: the slot's own buffer if nothing was written there yet, else the staging buffer
@@ -478,9 +488,10 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
   bool forked = false;
   int device = 0;
   GPN_CHECK_HIP(hipGetDevice(&device));
-  static std::mutex pass_mu;  // one backward pass at a time per process (the worker serves a single pass)
-  std::lock_guard<std::mutex> pass_lock(pass_mu);
-  WgradWorker& worker = wgrad_worker();
+  GPN_CHECK_ARG(device >= 0 && device < gpn::kMaxDevices);
+  DeviceWorker& dw = device_worker(device);
+  std::lock_guard<std::mutex> pass_lock(dw.pass_mu);
+  WgradWorker& worker = dw.worker;
   worker.begin(device, side->stream, wgrad_ws, wgrad_ws_bytes, (size_t)n_ops);
   // every exit below must close the pass, or the worker would spin forever
   struct PassGuard {

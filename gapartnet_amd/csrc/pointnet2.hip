@@ -423,14 +423,19 @@ extern "C" int gpn_pn2_furthest_point_sampling(int b, int n, int m, const float*
   return GPN_OK;
 }
 
-// workgroups per cloud of the multi-workgroup form: as many as fit on the chip together, at most 64 (one wave reduces the
-// candidates), none for clouds a single workgroup handles faster than a chip-wide barrier per sample costs
+// workgroups per cloud of the multi-workgroup form: as many as are guaranteed to be resident together (occupancy query x
+// CU count; the kernel meets at a counter barrier, so every workgroup of a cloud must be running), at most 64 (one wave
+// reduces the candidates), none for clouds a single workgroup handles faster than a chip-wide barrier per sample costs
 static int fps_groups(int b, int n) {
   if (n < 65536 || b < 1) return 1;
-  int dev = 0, cus = 0;
+  int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 1;
-  int g = cus / b;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pn2_fps_multi_kernel, 1024, 0) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  int g = cus / b;  // one workgroup per CU: the point chunks stream through a CU's own L1/LDS path
   if (g > 64) g = 64;
   return g < 2 ? 1 : g;
 }
@@ -458,9 +463,16 @@ extern "C" int gpn_pn2_furthest_point_sampling_ws(int b, int n, int m, const flo
   GPN_CHECK_WS(carve);
   GPN_CHECK_HIP(hipMemsetAsync(arrived, 0, (size_t)b * sizeof(unsigned), stream));
   const int bref = opt_n_threads(n);
-  hipLaunchKernelGGL(pn2_fps_multi_kernel, dim3(b * G), dim3(1024), 0, stream, n, m, bref - 1, G, dataset, temp, idxs,
-                     cand_v, cand_k, arrived);
-  GPN_CHECK_LAUNCH();
+  // cooperative launch: the runtime starts the grid only when ALL its workgroups can be resident at once (and refuses a
+  // grid that cannot be), which is what the in-kernel counter barrier needs - a plain launch next to other streams' kernels,
+  // other ranks sharing the device or a CU mask could leave some workgroups unscheduled while the resident ones spin.
+  int bmask = bref - 1, groups = G;
+  void* args[] = {&n, &m, &bmask, &groups, &dataset, &temp, &idxs, &cand_v, &cand_k, &arrived};
+  const hipError_t err = hipLaunchCooperativeKernel((const void*)pn2_fps_multi_kernel, dim3(b * G), dim3(1024), args, 0, stream);
+  if (err != hipSuccess) {  // not co-schedulable here (too large for this device / partition): single-workgroup form
+    (void)hipGetLastError();
+    return gpn_pn2_furthest_point_sampling(b, n, m, dataset, temp, idxs, stream_);
+  }
   return GPN_OK;
 }
 

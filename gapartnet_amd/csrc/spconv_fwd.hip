@@ -22,6 +22,7 @@
 // is fixed (tap-major), so results are deterministic.  Small layers split their taps over grid.z into partial outputs
 // that a fixed-order kernel sums.
 #include <algorithm>
+#include <atomic>
 
 #include "gpn_common.h"
 
@@ -477,18 +478,23 @@ template <int NTW, int KT, int D, int CW>
 int launch_stream(const StreamPlan& sp, const float* in, const float* packed, const int32_t* nbr, const int32_t* perm,
                   int64_t n_dst, int cin, int nt_total, float* out, hipStream_t stream) {
   constexpr size_t lds = (size_t)KT * CW * NTW * 64 * 16;
-  // persistent grid = (workgroups that are resident at once) x CUs: asked from the runtime once per instantiation
-  static int wgs = 0;
+  // persistent grid = (workgroups that are resident at once) x CUs: asked from the runtime once per instantiation AND
+  // device (a process may drive several devices; occupancy and CU count are properties of the device)
+  static std::atomic<int> wgs_of_device[gpn::kMaxDevices] = {};
+  int dev = 0;
+  GPN_CHECK_HIP(hipGetDevice(&dev));
+  GPN_CHECK_ARG(dev >= 0 && dev < gpn::kMaxDevices);
+  int wgs = wgs_of_device[dev].load(std::memory_order_acquire);
   if (wgs == 0) {
     GPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_fwd_stream_kernel<NTW, KT, D, CW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0, dev = 0, cus = 0;
+    int per_cu = 0, cus = 0;
     GPN_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_stream_kernel<NTW, KT, D, CW>, 512, lds));
-    GPN_CHECK_HIP(hipGetDevice(&dev));
     GPN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
     wgs = (cus * per_cu + 7) / 8 * 8;
+    wgs_of_device[dev].store(wgs, std::memory_order_release);  // idempotent: racing threads compute the same value
   }
   const dim3 grid((unsigned)wgs, (unsigned)sp.groups, (unsigned)sp.cb_splits);
   hipLaunchKernelGGL((spconv_fwd_stream_kernel<NTW, KT, D, CW>), grid, dim3(512), lds, stream, in, packed, nbr, n_dst, cin,

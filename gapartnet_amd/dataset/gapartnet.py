@@ -9,7 +9,7 @@ with the reference's signature for per-scene use on device tensors.
 import copy
 import os
 from glob import glob
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -135,12 +135,15 @@ class GAPartNetDataset(torch.utils.data.Dataset):
     """``*.pth`` scenes under ``root_dir`` (reference class of the same name, dataset/gapartnet.py:22-82).
     ``voxelize_on_load=False`` (default) leaves voxelisation to the batched device path in ``PointCloud.collate``."""
 
-    def __init__(self, root_dir: str = "", shuffle: bool = False, max_points: int = 20000, augmentation: bool = False,
+    def __init__(self, root_dir: Union[str, Sequence[str]] = "", shuffle: bool = False, max_points: int = 20000,
+                 augmentation: bool = False,
                  voxel_size: Tuple[float, float, float] = (1 / 100, 1 / 100, 1 / 100), few_shot: bool = False,
                  few_shot_num: int = 512, pos_jitter: float = 0., color_jitter: float = 0., flip_prob: float = 0.,
                  rotate_prob: float = 0., nopart_path: str = "data/nopart.txt", no_label: bool = False,
                  voxelize_on_load: bool = False, device: Optional[torch.device] = None, device_pipeline: bool = False):
-        paths = sorted(glob(os.path.join(str(root_dir), "*.pth")))
+        # a list of directories is accepted like in the reference (dataset/gapartnet.py:39-44: train_with_all passes four)
+        roots = list(root_dir) if isinstance(root_dir, (list, tuple)) else [root_dir]
+        paths = sorted(p for rt in roots for p in glob(os.path.join(str(rt), "*.pth")))
         self.nopart_files = []
         if os.path.exists(nopart_path):
             with open(nopart_path) as fh:
@@ -223,7 +226,13 @@ class GAPartNetInst(LightningDataModule):
             seed0 = {"train": 1000, "val": 2000, "intra": 3000, "inter": 4000}[split]
             return SyntheticGAPartNetDataset(n, self.max_points, seed0, augmentation=augmentation, voxel_size=self.voxel_size,
                                              device_pipeline=self.device_pipeline, **(self.aug if augmentation else {}))
-        return GAPartNetDataset(os.path.join(self.root_dir, sub, "pth"), shuffle=shuffle, max_points=self.max_points,
+        if split == "train" and self.train_with_all:
+            # the reference trains on train + val + test_intra + test_inter when train_with_all is set
+            # (dataset/gapartnet.py:339-355 there)
+            root = [os.path.join(self.root_dir, d, "pth") for d in ("train", "val", "test_intra", "test_inter")]
+        else:
+            root = os.path.join(self.root_dir, sub, "pth")
+        return GAPartNetDataset(root, shuffle=shuffle, max_points=self.max_points,
                                 augmentation=augmentation, voxel_size=self.voxel_size, few_shot=few,
                                 few_shot_num=self.few_shot_num, device_pipeline=self.device_pipeline,
                                 **(self.aug if augmentation else {}))

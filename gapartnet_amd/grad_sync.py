@@ -16,6 +16,7 @@ tools/ddp_profile.py), so the exchange is done here instead, shaped by what the 
 The payload is 31.6 MB per step for the default model: ~0.2 ms on a 7-link xGMI ring, which is why no overlap with backward
 is attempted.  RCCL ("nccl") averages in the collective (ReduceOp.AVG); gloo sums and the buffer is scaled afterwards.
 """
+import os
 import time
 from typing import List, Optional
 
@@ -55,7 +56,8 @@ class GradSync:
             try:
                 from .trainer import native_stdout_to_stderr
                 with native_stdout_to_stderr():  # gloo announces its connections on stdout
-                    self.host_group = dist.new_group(backend="gloo")
+                    ranks = dist.get_process_group_ranks(group) if group is not None else None
+                    self.host_group = dist.new_group(ranks=ranks, backend="gloo")  # the twin spans the SAME ranks
             except Exception as exc:  # noqa: BLE001 - any transport failure means "fall back", every rank fails alike
                 print(f"[grad_sync] gloo side channel unavailable ({type(exc).__name__}: {exc}); using the device group",
                       flush=True)
@@ -64,6 +66,7 @@ class GradSync:
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._buckets: Optional[List[List[int]]] = None
         self.stats = {"in_place": 0, "flattened": 0, "skipped": 0, "steps": 0, "host_ms": 0.0}
+        self._verify_always = os.environ.get("GPN_GRAD_SYNC_VERIFY") == "1"
 
     # ------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
@@ -96,16 +99,31 @@ class GradSync:
             progs.append(None)
         self._buckets, self._progs = buckets, progs
 
-    def _executor_flat(self, prog, first_grad, last_grad, total) -> Optional[torch.Tensor]:
-        """the executor's own gradient buffer of this step if ``.grad`` of the bucket's first and last parameter are its
-        first and last slice (autograd hands the slices over without copying when ``.grad`` was None): an O(1) test in
-        place of walking all ~100 gradients"""
+    # steps on which the whole-buffer shortcut is verified gradient by gradient (then it is trusted: the aliasing is a
+    # property of how the step is written - zero_grad(set_to_none=True), no tied parameters, no gradient hooks - and does not
+    # change from step to step); GPN_GRAD_SYNC_VERIFY=1 keeps the full walk on every step
+    VERIFY_STEPS = 3
+
+    def _executor_flat(self, prog, grads, total) -> Optional[torch.Tensor]:
+        """the executor's own gradient buffer of this step if the bucket's ``.grad`` tensors are exactly its slices, back
+        to back (autograd hands the slices over without copying when ``.grad`` was None).  First and last slice are checked
+        on every step (O(1)); every slice on the first VERIFY_STEPS steps, because a middle parameter whose ``.grad`` is
+        NOT a slice (tied parameter, accumulation into an existing ``.grad``, a hook that made AccumulateGrad clone) would
+        otherwise be left un-averaged without any error."""
         flat = getattr(prog, "last_pgrad", None)
-        if flat is None or flat.numel() != total or first_grad is None or last_grad is None:
+        if flat is None or flat.numel() != total or grads[0] is None or grads[-1] is None:
             return None
         base = flat.data_ptr()
-        if first_grad.data_ptr() != base or last_grad.data_ptr() + last_grad.numel() * 4 != base + total * 4:
+        if grads[0].data_ptr() != base or grads[-1].data_ptr() + grads[-1].numel() * 4 != base + total * 4:
             return None
+        if self.stats["steps"] <= self.VERIFY_STEPS or self._verify_always:
+            ptr = base
+            for g in grads:
+                if g is None or g.data_ptr() != ptr or g.dtype != torch.float32 or not g.is_contiguous():
+                    return None
+                ptr += g.numel() * 4
+            if ptr != base + total * 4:
+                return None
         return flat
 
     @staticmethod
@@ -151,7 +169,7 @@ class GradSync:
             # (every rank must reduce the same number of elements: the whole-buffer path only when the consensus says every
             # parameter of the bucket has a gradient somewhere - which is always the case for a net that ran)
             if prog is not None and all(used[i] for i in ids):
-                flat = self._executor_flat(prog, params[ids[0]].grad, params[ids[-1]].grad, prog.grad_total)
+                flat = self._executor_flat(prog, [params[i].grad for i in ids], prog.grad_total)
                 if flat is not None:
                     self._all_reduce_mean(flat)
                     self.stats["in_place"] += 1

@@ -36,6 +36,19 @@ def native_stdout_to_stderr():
         os.close(saved)
 
 
+def seed_everything(seed: int) -> int:
+    """Lightning's ``seed_everything`` (gapartnet.yaml ``seed_everything: 23333``): python, numpy and torch generators,
+    the SAME seed on every rank — the dataset shuffles its file list with the global generators at construction, and all
+    ranks must hold the same order for DistributedSampler's index shards to be disjoint."""
+    import random
+    import numpy as np
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    os.environ["PL_GLOBAL_SEED"] = str(seed)
+    return seed
+
+
 def distributed_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
@@ -78,29 +91,44 @@ def move_batch(batch, device):
 
 
 class MetricLog:
-    """epoch means of everything the module ``log``s (weighted by batch_size, all-reduced when sync_dist)."""
+    """epoch means of everything the module ``log``s (weighted by batch_size, summed over ranks).
+
+    Nothing is read back while an epoch runs: tensor values are accumulated as device tensors (a ``float(value)`` per key
+    would be eight device->host waits per training step, the first of which holds the host until the whole forward has
+    finished); ``reduce`` does ONE all-reduce and ONE host read per epoch.  The set of keys can differ between ranks
+    (per-class AP keys exist only where an epoch had proposals), so ranks first agree on the union of names."""
 
     def __init__(self):
-        self.sum = defaultdict(float)
+        self.sum: Dict[str, object] = {}
         self.weight = defaultdict(float)
-        self.sync = {}
 
     def __call__(self, name, value, batch_size=None, sync_dist=False):
-        v = float(value.detach()) if isinstance(value, torch.Tensor) else float(value)
         w = float(batch_size or 1)
-        self.sum[name] += v * w
+        if isinstance(value, torch.Tensor):
+            v = value.detach().to(torch.float64) * w
+        else:
+            v = float(value) * w
+        prev = self.sum.get(name)
+        self.sum[name] = v if prev is None else prev + v
         self.weight[name] += w
-        self.sync[name] = sync_dist
 
     def reduce(self, device) -> Dict[str, float]:
         names = sorted(self.sum)
+        distributed = dist.is_initialized() and dist.get_world_size() > 1
+        if distributed:
+            gathered = [None] * dist.get_world_size()
+            dist.all_gather_object(gathered, names)
+            names = sorted(set().union(*gathered))
         if not names:
             return {}
-        t = torch.tensor([[self.sum[n], self.weight[n]] for n in names], dtype=torch.float64, device=device)
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            t = t.to(torch.float32) if device.type == "cuda" else t
+        zero = torch.zeros((), dtype=torch.float64, device=device)
+        sums = torch.stack([torch.as_tensor(self.sum.get(n, 0.0), dtype=torch.float64).to(device) + zero for n in names])
+        weights = torch.tensor([self.weight.get(n, 0.0) for n in names], dtype=torch.float64, device=device)
+        t = torch.stack([sums, weights], dim=1)
+        if distributed:
             dist.all_reduce(t)
-        out = {n: float(t[i, 0] / max(float(t[i, 1]), 1e-12)) for i, n in enumerate(names)}
+        host = t.cpu()
+        out = {n: float(host[i, 0] / max(float(host[i, 1]), 1e-12)) for i, n in enumerate(names)}
         self.sum.clear(); self.weight.clear()
         return out
 
@@ -110,7 +138,7 @@ class Trainer:
                  limit_train_batches: Optional[int] = None, limit_val_batches: Optional[int] = None,
                  check_val_every_n_epoch: int = 1, monitor: str = "monitor_metrics/mean_mAP", save_top_k: int = 5,
                  log_every_n_steps: int = 10, find_unused_parameters: bool = True, enable_checkpointing: bool = True,
-                 **_ignored):
+                 seed: Optional[int] = 23333, **_ignored):
         self.max_epochs, self.root = max_epochs, default_root_dir
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.check_val_every_n_epoch, self.monitor, self.save_top_k = check_val_every_n_epoch, monitor, save_top_k
@@ -118,6 +146,8 @@ class Trainer:
         self.enable_checkpointing = enable_checkpointing
         self.device_type = "cuda" if accelerator in ("gpu", "cuda", "auto") else "cpu"
         self.rank, self.local_rank, self.world, self.device = init_distributed(self.device_type)
+        # before any datamodule.setup(): identical generators on all ranks (gapartnet.yaml seed_everything; None = leave them)
+        self.seed = seed_everything(seed) if seed is not None else None
         self.current_epoch = 0
         self.global_step = 0
         self.history: List[Dict[str, float]] = []
@@ -135,11 +165,18 @@ class Trainer:
         if hasattr(model, "_current_epoch"):
             model._current_epoch = epoch
 
+    def _setup(self, datamodule, stage: str):
+        """datamodule.setup under the agreed seed: the datasets shuffle their file lists with the global generators
+        (dataset/gapartnet.py:49-50 of the reference), and every rank must end up with the same order"""
+        if self.seed is not None:
+            seed_everything(self.seed)
+        datamodule.setup(stage)
+
     def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None, ckpt_path: Optional[str] = None):
         log = MetricLog()
         self._attach(model, log)
         if datamodule is not None:
-            datamodule.setup("fit")
+            self._setup(datamodule, "fit")
             sampler = None
             if self.world > 1:
                 sampler = torch.utils.data.distributed.DistributedSampler(
@@ -215,7 +252,7 @@ class Trainer:
         log = MetricLog()
         self._attach(model, log)
         if datamodule is not None:
-            datamodule.setup("validate")
+            self._setup(datamodule, "validate")
             dataloaders = datamodule.val_dataloader()
         return self._eval_loop(model, dataloaders, "validation", log)
 
@@ -223,7 +260,7 @@ class Trainer:
         log = MetricLog()
         self._attach(model, log)
         if datamodule is not None:
-            datamodule.setup("test")
+            self._setup(datamodule, "test")
             dataloaders = datamodule.test_dataloader()
         return self._eval_loop(model, dataloaders, "test", log)
 

@@ -128,3 +128,30 @@ def test_four_rank_training_keeps_ranks_identical(tmp_path):
     assert res["params_equal"] and res["finite"] and res["loss"] > 0
     seen = [set(i) for i in res["ids"]]
     assert [len(s) for s in seen] == [2, 2, 2, 2] and len(set().union(*seen)) == 8, "4 disjoint shards of the 8 scenes"
+
+
+def test_every_rank_holds_the_same_file_order_after_setup(tmp_path):
+    """the dataset shuffles its ``.pth`` list with the process-global generator; ranks whose generators have
+    diverged (here: different amounts of random numbers consumed before setup) must still end up with ONE order, or
+    DistributedSampler's index shards overlap.  Trainer._setup re-seeds (gapartnet.yaml seed_everything) before setup."""
+    import numpy as np
+    import torch
+    from gapartnet_amd.dataset.gapartnet import GAPartNetInst
+    from gapartnet_amd.trainer import Trainer
+    for split in ("train", "val", "test_intra", "test_inter"):
+        d = tmp_path / split / "pth"
+        d.mkdir(parents=True)
+        for i in range(12):
+            torch.save((np.zeros((4, 3), np.float32),) * 2, str(d / f"Box_{split}_{i:02d}.pth"))
+    orders = []
+    for consumed in (0, 17):
+        trainer = Trainer(accelerator="cpu", enable_checkpointing=False)
+        np.random.rand(consumed)
+        dm = GAPartNetInst(str(tmp_path))
+        trainer._setup(dm, "fit")
+        orders.append([p.split("/")[-1] for p in dm.train_data_files.pc_paths + dm.val_data_files.pc_paths])
+    assert orders[0] == orders[1] and sorted(orders[0]) != orders[0]
+    assert len(dm.train_data_files) == 12
+    dm_all = GAPartNetInst(str(tmp_path), train_with_all=True)
+    dm_all.setup("fit")
+    assert len(dm_all.train_data_files) == 48, "train_with_all trains on all four splits (dataset/gapartnet.py:354-372 there)"
