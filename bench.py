@@ -61,13 +61,30 @@ def build_step(model, optimizer, world, device):
     return step
 
 
+def kernel_source_fingerprint():
+    """sha256 over the HIP sources the conv kernels are built from: identifies WHICH kernels a PMC pass measured"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "gapartnet_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic():
     """HBM bytes per launch of the conv kernel family from the committed PMC passes (profiles/traffic.json, produced by
-    tools/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this command); None if absent"""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    tools/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this command).  Counters cannot
+    be collected inside this process, so the figure is only reported when the passes were taken on EXACTLY the kernel
+    sources this run is built from (fingerprint recorded by the tool); otherwise null - never a stale constant."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
-            return float(json.load(fh)["traffic_bytes_per_launch"])
+            rec = json.load(fh)
+        if rec.get("kernel_source_fingerprint") != kernel_source_fingerprint():
+            return None
+        return float(rec["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -105,25 +122,46 @@ def roofline_from_profile(device):
     return out
 
 
-def cpu_baseline(args):
-    """the same train step through the CPU oracle (C restatement, 1 thread) on a bounded sample."""
+def _cpu_steps(args, n_scenes, threads, timed):
+    """median seconds of `timed` full train steps (after one warm-up step) through the CPU oracle with `threads` threads"""
+    import statistics
+    import oracle
     from gapartnet_amd import backend
     from gapartnet_amd.smoke import make_batch, make_model
     from oracle import torch_ops as oracle_ops
-    torch.set_num_threads(1)
+    torch.set_num_threads(threads)
+    oracle.set_threads(threads)
     model = make_model(tuple(int(s) for s in args.schedule.split(",")))
     opt = model.configure_optimizers()
-    batch = make_batch(args.cpu_scenes, args.points, seed0=5000)
+    batches = [make_batch(n_scenes, args.points, seed0=5000 + 100 * j) for j in range(2)]
+    times = []
     with backend.using(oracle_ops):
-        t0 = time.perf_counter()
-        opt.zero_grad(set_to_none=True)
-        loss = model.training_step(batch, 0)
-        loss.backward()
-        opt.step()
-        dt = time.perf_counter() - t0
-    return dict(value=args.cpu_scenes / dt, unit="point-clouds/sec", cores=1, kind="port",
-                sample=f"1 full train step (fwd+bwd+Adam), {args.cpu_scenes} synthetic scene(s) x {args.points} pts, "
-                       f"CPU oracle (oracle/gpn_oracle.c, single thread), {dt:.1f} s")
+        for i in range(1 + timed):
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            loss = model.training_step(batches[i % 2], i)
+            loss.backward()
+            opt.step()
+            if i > 0:
+                times.append(time.perf_counter() - t0)
+    return statistics.median(times), sum(times)
+
+
+def cpu_baseline(args):
+    """the same train step through the CPU oracle (oracle/gpn_oracle.c, kind "port": the reference's spconv / epic_ops CPU
+    path cannot be installed here) on a bounded sample: one warm-up step, then the median of 3 timed steps - with one
+    thread, and with every host core (OpenMP over the rule pairs of a tap in the conv loops and over queries in the ball
+    query, torch's own threads for the glue).  The reported value is the all-cores run."""
+    cores = os.cpu_count() or 1
+    single_n = 1
+    t1, spent1 = _cpu_steps(args, single_n, 1, 3)
+    tn, spentn = _cpu_steps(args, args.cpu_scenes, cores, 3)
+    return dict(value=args.cpu_scenes / tn, unit="point-clouds/sec", cores=cores, kind="port",
+                single_thread=dict(value=single_n / t1, cores=1, scenes_per_step=single_n, median_step_s=t1),
+                sample=f"median of 3 full train steps (fwd+bwd+Adam) after 1 warm-up, {args.cpu_scenes} synthetic scene(s) x "
+                       f"{args.points} pts per step, CPU oracle (oracle/gpn_oracle.c) with {cores} OpenMP/torch threads: "
+                       f"{tn:.2f} s/step ({spentn:.0f} s timed); single thread on {single_n} scene: {t1:.2f} s/step "
+                       f"({spent1:.0f} s timed)")
 
 
 def main():

@@ -53,17 +53,33 @@ def run_smoke(device: torch.device, n_scenes: int = 2, n_points: int = 4000, tol
 
     got, want = float(loss), float(ref_loss)
     assert abs(got - want) <= tol * max(1.0, abs(want)), f"smoke: loss {got} vs oracle {want}"
+    worst, worst_name = compare_gradients(model, ref_model, rel=1e-3)
+    print(f"smoke ok: loss {got:.6f} (oracle {want:.6f}), worst gradient error {worst:.2e} x max|g| at {worst_name}")
+    return dict(loss=got, oracle_loss=want, worst_grad_rel_err=worst)
+
+
+def compare_gradients(model, ref_model, rel: float = 1e-3):
+    """per parameter tensor: max|g - g_ref| <= rel * max|g_ref| (north_star asks 1e-4 on features; gradients pass through
+    ~200 BatchNorm layers in training mode, whose batch statistics on the tiny deep levels amplify fp32 summation-order
+    noise, hence 1e-3 on gradients).  A tensor whose reference gradient is structurally zero - a bias in front of a
+    BatchNorm: the mean subtraction removes it - is not divided by its own noise: it must be ~zero on both sides,
+    measured against the largest gradient entry of the whole model.  -> (worst ratio, its parameter name)"""
+    ref = {n: q.grad for n, q in ref_model.named_parameters()}
+    top = max(float(g.abs().max()) for g in ref.values() if g is not None)
     worst, worst_name = 0.0, ""
-    for (name, p), (_, q) in zip(model.named_parameters(), ref_model.named_parameters()):
-        if q.grad is None:
+    for name, p in model.named_parameters():
+        g_ref = ref[name]
+        if g_ref is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
-        err = float((p.grad.cpu() - q.grad).abs().max())
-        scale = float(q.grad.abs().max()) + 1e-6
-        if err / scale > worst:
-            worst, worst_name = err / scale, name
-    # fp32 summation order differs between the MFMA kernels and the scalar oracle; BatchNorm (eps 1e-4 on tiny
-    # deep-level batches) amplifies it, hence the loose bound on the worst parameter
-    assert worst < 1e-1, f"smoke: gradient mismatch vs oracle, worst relative error {worst} at {worst_name}"
-    print(f"smoke ok: loss {got:.6f} (oracle {want:.6f}), worst relative grad error {worst:.2e} at {worst_name}")
-    return dict(loss=got, oracle_loss=want, worst_grad_rel_err=worst)
+        assert p.grad is not None, f"{name}: no gradient on the HIP path"
+        g = p.grad.detach().cpu()
+        scale = float(g_ref.abs().max())
+        if scale <= 1e-6 * top:
+            assert float(g.abs().max()) <= 1e-5 * top, f"{name}: structurally zero gradient is {float(g.abs().max()):.3e}"
+            continue
+        ratio = float((g - g_ref).abs().max()) / scale
+        if ratio > worst:
+            worst, worst_name = ratio, name
+    assert worst <= rel, f"gradient mismatch vs oracle: {worst:.3e} x max|g| at {worst_name} (bound {rel})"
+    return worst, worst_name

@@ -35,6 +35,11 @@ def lib():
     return _lib
 
 
+def set_threads(n: int) -> int:
+    """OpenMP threads of the conv / ball-query loops (results do not depend on it); -> the count now in effect"""
+    return int(lib().orc_set_threads(ctypes.c_int(int(n))))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 

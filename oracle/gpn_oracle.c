@@ -199,6 +199,15 @@ int64_t orc_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* ta
   return P;
 }
 
+/* bench.py's cpu_baseline times the restatement with 1 thread and with all host cores ("OpenMP over pairs",
+ * SURVEY.md §8d); every parallel loop below is over independent outputs, so results do not depend on the thread count */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int orc_set_threads(int n) { (void)n; return 1; }
+#endif
+
 /* C — sparse conv (gather-GEMM-scatter), W canonical [K,cin,cout].  out fully overwritten. */
 void orc_spconv_fwd(const float* in, const float* W, const int32_t* pair_src, const int32_t* pair_dst,
                     const int32_t* tile_off, int K, int64_t n_dst, int cin, int cout, float* out) {
@@ -207,6 +216,8 @@ void orc_spconv_fwd(const float* in, const float* W, const int32_t* pair_src, co
   for (int k = 0; k < K; ++k) {
     const float* Wk = W + (int64_t)k * cin * cout;
     int64_t p0 = tile_off[k * (n_tiles + 1)], p1 = tile_off[k * (n_tiles + 1) + n_tiles];
+    /* pairs of one tap have distinct destinations: threads own disjoint output rows, per-row order stays tap-major */
+#pragma omp parallel for schedule(static)
     for (int64_t p = p0; p < p1; ++p) {
       const float* a = in + (int64_t)pair_src[p] * cin;
       float* o = out + (int64_t)pair_dst[p] * cout;
@@ -228,6 +239,8 @@ void orc_spconv_dgrad(const float* dout, const float* W, const int32_t* pair_src
   for (int k = 0; k < K; ++k) {
     const float* Wk = W + (int64_t)k * cin * cout;
     int64_t p0 = tile_off[k * (n_tiles + 1)], p1 = tile_off[k * (n_tiles + 1) + n_tiles];
+    /* pairs of one tap have distinct sources as well (src = dst + offset_k) */
+#pragma omp parallel for schedule(static)
     for (int64_t p = p0; p < p1; ++p) {
       const float* g = dout + (int64_t)pair_dst[p] * cout;
       float* d = din + (int64_t)pair_src[p] * cin;
@@ -246,6 +259,8 @@ void orc_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_sr
                       int cout, float* dW) {
   int64_t n_tiles = (n_dst + TILE_ROWS - 1) / TILE_ROWS;
   memset(dW, 0, sizeof(float) * (size_t)((int64_t)K * cin * cout));
+  /* one tap's weight block per thread: every block is summed by one thread in pair order */
+#pragma omp parallel for schedule(dynamic, 1)
   for (int k = 0; k < K; ++k) {
     float* Wk = dW + (int64_t)k * cin * cout;
     int64_t p0 = tile_off[k * (n_tiles + 1)], p1 = tile_off[k * (n_tiles + 1) + n_tiles];
@@ -282,6 +297,7 @@ void orc_ball_query(const float* points, const float* query, const int32_t* batc
                     int32_t* indices, int32_t* count) {
   (void)Np; (void)S;
   float r2 = radius * radius;
+#pragma omp parallel for schedule(dynamic, 64)
   for (int64_t i = 0; i < Q; ++i) {
     int32_t b = batch_indices[i];
     int cnt = 0;

@@ -125,7 +125,8 @@ def test_subm_conv_fwd_dgrad_wgrad(H, cuda, cin, cout):
     assert np.allclose(din, O.spconv_dgrad(g, W, rb_ref, N, N), atol=FP_TOL, rtol=1e-4)
     dW = host(H.conv_wgrad(dev(f, cuda), dev(g, cuda), rb))
     ref_dW = O.spconv_wgrad(f, g, rb_ref, N, 27)
-    assert np.allclose(dW, ref_dW, atol=1e-3, rtol=1e-4), np.abs(dW - ref_dW).max()
+    # sums over ~1500 pairs per tap of O(1) products: entries are O(40); bound relative to the tensor's scale (north_star 1e-4)
+    assert np.abs(dW - ref_dW).max() <= 1e-4 * np.abs(ref_dW).max(), (np.abs(dW - ref_dW).max(), np.abs(ref_dW).max())
 
 
 @pytest.mark.parametrize("cin,cout", [(16, 32), (32, 48), (96, 112)])
@@ -145,7 +146,8 @@ def test_down_and_inverse_conv(H, cuda, cin, cout):
     g = rng.normal(size=(No, cout)).astype(np.float32)
     din = host(H.conv_dgrad(dev(g, cuda), dev(W, cuda), rb_f, rb_b, False))
     assert np.allclose(din, O.spconv_dgrad(g, W, d["fwd"], No, N), atol=FP_TOL, rtol=1e-4)
-    assert np.allclose(host(H.conv_wgrad(dev(f, cuda), dev(g, cuda), rb_f)), O.spconv_wgrad(f, g, d["fwd"], No, 8), atol=1e-3, rtol=1e-4)
+    dW, ref_dW = host(H.conv_wgrad(dev(f, cuda), dev(g, cuda), rb_f)), O.spconv_wgrad(f, g, d["fwd"], No, 8)
+    assert np.abs(dW - ref_dW).max() <= 1e-4 * np.abs(ref_dW).max(), (np.abs(dW - ref_dW).max(), np.abs(ref_dW).max())
     # inverse conv: coarse -> fine over the bwd lists
     Wi = (rng.normal(size=(8, cout, cin)) / np.sqrt(cout)).astype(np.float32)
     up = host(H.conv_fwd(dev(ref, cuda), dev(Wi, cuda), rb_b))
