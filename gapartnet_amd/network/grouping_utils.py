@@ -2,7 +2,7 @@
 (reference: gapartnet/network/grouping_utils.py:14-454) — same function names and results, written over the
 HIP operators (epic_ops mirrors) and restructured to stay on the device.
 """
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -303,54 +303,75 @@ def _compute_ap_per_class(tp: torch.Tensor, fp: torch.Tensor, num_gt_instances) 
     return voc_ap(tp / num_gt_instances, tp / (tp + fp + 1e-8))
 
 
-def compute_ap(proposals: List[Instances], num_classes: int = 9, iou_threshold: float = 0.5, device="cpu") -> List[float]:
-    """per-class AP over a list of per-batch proposal sets (grouping_utils.py:360-454).
+def compute_ap_multi(proposals: List[Instances], num_classes: int, iou_thresholds: Sequence[float]) -> torch.Tensor:
+    """per-class AP at several IoU thresholds over a list of per-batch proposal sets -> [T, num_classes - 1] float32 tensor
+    on the proposals' device (grouping_utils.py:360-454 is the per-threshold form; model.py:734-745 calls it ten times).
 
     The reference walks the proposals in descending confidence, one Python iteration (and several device round trips) each:
     a proposal is a true positive if its best-IoU ground-truth instance of the same class exceeds the threshold and is
     still unmatched.  A proposal's best instance does not depend on the matching state, and an instance is matched
     exactly when the FIRST proposal (in confidence order) that clears the threshold on it is reached - so the walk is
     equivalent to: candidates = proposals whose best same-class IoU > threshold; true positives = the first candidate of
-    every (set, scene, instance) key in confidence order.  That form is evaluated here with array operations
-    (SURVEY.md §8f rank 2); oracle/eval_ap.py keeps the sequential walk as the checker."""
+    every (set, scene, instance) key in confidence order.  Everything here is array operations ON THE DEVICE that holds the
+    proposals: one sort, one min-scatter per threshold, and the per-class precision / recall curves
+    of all classes as [classes, proposals] prefix sums and a reversed running maximum (the VOC precision envelope) - no
+    host read until the caller takes the result.  oracle/eval_ap.py keeps the sequential walk as the checker and
+    tests/golden/eval_ap.npz holds the reference implementation's own results."""
+    thresholds = [float(t) for t in iou_thresholds]
+    n_cls = num_classes - 1
+    dev = proposals[0].score_preds.device if proposals else torch.device("cpu")
     n_total = sum(int(p.score_preds.shape[0]) for p in proposals)
-    inst_labels = [p.instance_sem_labels.detach().cpu().numpy() for p in proposals]
-    gt_classes = np.concatenate([l.reshape(-1) for l in inst_labels]) if inst_labels else np.zeros((0,), np.int32)
     if n_total == 0:
-        return [0.0 for _ in range(1, num_classes)]
-    conf = torch.cat([p.score_preds for p in proposals]).detach().cpu()
-    classes = torch.cat([p.pt_sem_classes for p in proposals]).detach().cpu().numpy()
-    order = torch.argsort(conf, descending=True).numpy()
+        return torch.zeros((len(thresholds), n_cls), dtype=torch.float32, device=dev)
+    conf = torch.cat([p.score_preds for p in proposals]).detach().float()
+    classes = torch.cat([p.pt_sem_classes for p in proposals]).detach().long()
+    order = torch.argsort(conf, descending=True)
 
-    best_iou = np.zeros(n_total, np.float64)
-    key = np.zeros(n_total, np.int64)
-    start, key_base = 0, 0
-    for s, p in enumerate(proposals):
+    best_iou, key, gt = [], [], []
+    key_base = 0
+    for p in proposals:
         n = int(p.score_preds.shape[0])
-        labels = inst_labels[s]                                   # [scenes, W]
-        width = labels.shape[1] if labels.ndim == 2 else 0
+        labels = p.instance_sem_labels.to(dev)                                  # [scenes, W]
+        width = int(labels.shape[1]) if labels.dim() == 2 else 0
+        gt.append(labels.reshape(-1).long())
         if n and width:
-            sample = p.batch_indices[p.proposal_offsets[:-1].long()].long().cpu().numpy()
-            ious = p.ious.detach().cpu().numpy()                      # [n, W]
-            row = np.where(labels[sample] == classes[start:start + n, None], ious, 0.0)
-            best = row.argmax(1)                                      # first maximum, like the sequential walk
-            best_iou[start:start + n] = row[np.arange(n), best]
-            key[start:start + n] = key_base + sample * width + best
+            sample = p.batch_indices[p.proposal_offsets[:-1].long()].long()
+            cls = p.pt_sem_classes.long()
+            row = torch.where(labels[sample].long() == cls[:, None], p.ious.detach().float(), p.ious.new_zeros(()).float())
+            top, arg = row.max(dim=1)                                           # first maximum, like the sequential walk
+            best_iou.append(top)
+            key.append(key_base + sample * width + arg)
+        else:
+            best_iou.append(torch.zeros(n, dtype=torch.float32, device=dev))
+            key.append(torch.full((n,), key_base, dtype=torch.int64, device=dev))
         key_base += int(labels.shape[0]) * max(width, 1)
-        start += n
+    ranked_iou = torch.cat(best_iou)[order]
+    ranked_key = torch.cat(key)[order]
+    ranked_cls = classes[order]
+    gt_classes = torch.cat(gt) if gt else torch.zeros(0, dtype=torch.int64, device=dev)
 
-    ranked_key, ranked_iou = key[order], best_iou[order]
-    cand = np.nonzero(ranked_iou > iou_threshold)[0]                  # ranks of the candidates, ascending
-    tp = np.zeros(n_total, np.float32)
-    if cand.shape[0]:
-        _, first = np.unique(ranked_key[cand], return_index=True)     # first candidate of every instance key
-        tp[cand[first]] = 1.0
-    fp = 1.0 - tp
+    cls_ids = torch.arange(1, num_classes, device=dev)
+    of_class = ranked_cls[None, :] == cls_ids[:, None]                          # [C, n]
+    num_gt = (gt_classes[None, :] == cls_ids[:, None]).sum(1)                   # [C] int64, as the reference divides
+    has_proposals = of_class.any(1)
+    rank = torch.arange(n_total, device=dev)
+    big = torch.full((max(key_base, 1),), n_total, dtype=torch.int64, device=dev)
+    out = []
+    for thr in thresholds:
+        cand = ranked_iou > thr
+        first = big.scatter_reduce(0, ranked_key, torch.where(cand, rank, rank.new_full((), n_total)), "amin")
+        tp = cand & (first[ranked_key] == rank)
+        tp_c = (of_class & tp[None, :]).float().cumsum(1)
+        fp_c = (of_class & ~tp[None, :]).float().cumsum(1)
+        rec = tp_c / num_gt[:, None]
+        prec = tp_c / (tp_c + fp_c + 1e-8)
+        env = torch.flip(torch.cummax(torch.flip(prec, dims=[1]), dim=1)[0], dims=[1])     # precision envelope
+        step = rec - torch.cat([torch.zeros_like(rec[:, :1]), rec[:, :-1]], dim=1)          # recall increments
+        ap = (step * env).sum(1)
+        out.append(torch.where(has_proposals, ap, torch.zeros_like(ap)))        # a class without proposals scores 0
+    return torch.stack(out)
 
-    sorted_classes = classes[order]
-    tp_t, fp_t = torch.from_numpy(tp), torch.from_numpy(fp)
-    aps: List[float] = []
-    for c in range(1, num_classes):
-        sel = torch.from_numpy(sorted_classes == c)
-        aps.append(_compute_ap_per_class(tp_t[sel], fp_t[sel], int((gt_classes == c).sum())))
-    return aps
+
+def compute_ap(proposals: List[Instances], num_classes: int = 9, iou_threshold: float = 0.5, device="cpu") -> List[float]:
+    """per-class AP at one IoU threshold (grouping_utils.py:420-454) - ``compute_ap_multi`` and one host read."""
+    return [float(v) for v in compute_ap_multi(proposals, num_classes, [iou_threshold])[0].cpu()]

@@ -53,15 +53,15 @@ def run_smoke(device: torch.device, n_scenes: int = 2, n_points: int = 4000, tol
 
     got, want = float(loss), float(ref_loss)
     assert abs(got - want) <= tol * max(1.0, abs(want)), f"smoke: loss {got} vs oracle {want}"
-    worst, worst_name = compare_gradients(model, ref_model, rel=1e-3)
+    worst, worst_name = compare_gradients(model, ref_model, rel=5e-4)
     print(f"smoke ok: loss {got:.6f} (oracle {want:.6f}), worst gradient error {worst:.2e} x max|g| at {worst_name}")
     return dict(loss=got, oracle_loss=want, worst_grad_rel_err=worst)
 
 
-def compare_gradients(model, ref_model, rel: float = 1e-3):
+def compare_gradients(model, ref_model, rel: float = 5e-4):
     """per parameter tensor: max|g - g_ref| <= rel * max|g_ref| (north_star asks 1e-4 on features; gradients pass through
     ~200 BatchNorm layers in training mode, whose batch statistics on the tiny deep levels amplify fp32 summation-order
-    noise, hence 1e-3 on gradients).  A tensor whose reference gradient is structurally zero - a bias in front of a
+    noise, hence 5e-4 on gradients - measured: 5e-6).  A tensor whose reference gradient is structurally zero - a bias in front of a
     BatchNorm: the mean subtraction removes it - is not divided by its own noise: it must be ~zero on both sides,
     measured against the largest gradient entry of the whole model.  -> (worst ratio, its parameter name)"""
     ref = {n: q.grad for n, q in ref_model.named_parameters()}

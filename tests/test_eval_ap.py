@@ -37,8 +37,9 @@ def test_array_form_equals_the_sequential_walk(seed, quantised):
     for thr in (0.25, 0.5, 0.75):
         want = eval_ap.compute_ap_sequential(sets, 9, thr)
         got = gu.compute_ap(sets, 9, thr)
-        # a class without ground truth gives 0/0 = nan in the reference as well
-        assert np.array_equal(np.asarray(got), np.asarray(want), equal_nan=True), (thr, got, want)
+        # a class without ground truth gives 0/0 = nan in the reference as well; the fp32 sum over ALL ranks (zeros where
+        # the recall does not move) rounds differently from the reference's sum over the recall steps only: <= 1e-6
+        assert np.allclose(np.asarray(got), np.asarray(want), rtol=0, atol=1e-6, equal_nan=True), (thr, got, want)
 
 
 def test_no_proposals_at_all():

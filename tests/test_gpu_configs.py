@@ -18,6 +18,7 @@ from gapartnet_amd.dataset import synthetic
 from gapartnet_amd.dataset.gapartnet import compact_instance_labels, generate_inst_info
 from gapartnet_amd.smoke import make_batch, make_model
 from gapartnet_amd.structure.point_cloud import PointCloud
+from tests.golden import recipe
 
 pytestmark = pytest.mark.gpu
 VOXEL = (0.01, 0.01, 0.01)
@@ -54,6 +55,9 @@ def test_config2_eval_batch4_full_pipeline(cuda):
     """config 2: full pipeline, 4 x 20k-point scenes, eval mode (release.ckpt is absent: seeded weights)."""
     from oracle import torch_ops
     model = make_model((0, 0)).eval()
+    # seeded weights with non-trivial BatchNorm statistics (torch's default init predicts one class almost everywhere in
+    # eval mode, and then there is nothing to cluster)
+    model.load_state_dict(recipe.name_keyed_state(model))
     scenes = make_batch(4, 20000, seed0=2200)
     gpu_model = copy.deepcopy(model).to(cuda)
     gpu_model.revoxelize_jitter = tuple(j.to(cuda) for j in JITTER)
@@ -103,6 +107,7 @@ def test_config4_dense_50k_train_step(cuda):
     from oracle import torch_ops
     scenes = make_batch(1, 50000, seed0=4400)
     model = make_model((0, 0))
+    model.load_state_dict(recipe.name_keyed_state(model))
     # fp stage vs the oracle in eval mode (fixed BatchNorm statistics)
     with torch.no_grad():
         gbatch = PointCloud.collate([pc.to(cuda) for pc in scenes], voxel_size=VOXEL)
