@@ -76,11 +76,17 @@ __device__ __forceinline__ uint64_t pack_key(int seg, int cx, int cy, int cz) {
 }
 
 __global__ __launch_bounds__(kThreads) void bq_keys_kernel(const float* __restrict__ points,
+                                                           const int32_t* __restrict__ point_labels,
                                                            const int32_t* __restrict__ batch_offsets, int64_t Np, int64_t S,
                                                            float inv_cell, GridHeader* hdr, uint64_t* __restrict__ keys,
                                                            int32_t* __restrict__ vals) {
   const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (j >= Np) return;
+  if (point_labels && point_labels[j] < 0) {  // inactive point (negative label): binned behind every searched cell range
+    keys[j] = ~0ull;
+    vals[j] = (int32_t)j;
+    return;
+  }
   // segment of point j: last s with batch_offsets[s] <= j
   int64_t lo = 0, hi = S;
   while (hi - lo > 1) {
@@ -132,6 +138,10 @@ __global__ __launch_bounds__(kThreads) void bq_query_kernel(
   const int32_t lo = batch_offsets[b], hi = batch_offsets[b + 1];
   const bool use_labels = point_labels != nullptr && query_labels != nullptr;
   const int32_t ql = use_labels ? query_labels[q] : 0;
+  if (ql < 0) {  // inactive query (negative label): no neighbours
+    if (lane == 0) count[q] = 0;
+    return;
+  }
   int32_t* out = indices + q * K;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
 
@@ -260,6 +270,8 @@ extern "C" int gpn_ball_query_grid(const float* points, const float* query, cons
                                    const int32_t* query_labels, int64_t Np, int64_t Q, int64_t S, float radius, int K,
                                    int32_t* indices, int32_t* count, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const bool pad = !(K & GPN_BQ_NO_PAD);  // callers that only read the first count[q] entries of a row skip the -1 fill
+  K &= ~GPN_BQ_NO_PAD;
   GPN_CHECK_ARG(Q >= 0 && Np >= 0 && S >= 0 && K >= 1 && radius > 0.f);
   if (Q == 0) return GPN_OK;
   GPN_CHECK_ARG(points && query && batch_indices && batch_offsets && indices && count);
@@ -272,15 +284,15 @@ extern "C" int gpn_ball_query_grid(const float* points, const float* query, cons
   const float r2 = radius * radius;
   const float inv_cell = 1.0f / (1.05f * radius);
   gpn::ProfScope prof(GPN_K_BALL_QUERY, stream, 0.0, 12.0 * (double)Np + 4.0 * (double)Q * K);
-  GPN_CHECK_HIP(hipMemsetAsync(indices, 0xff, sizeof(int32_t) * (size_t)Q * K, stream));
+  if (pad) GPN_CHECK_HIP(hipMemsetAsync(indices, 0xff, sizeof(int32_t) * (size_t)Q * K, stream));
   hipLaunchKernelGGL(bq_init_kernel, dim3(1), dim3(1), 0, stream, o.hdr);
   GPN_CHECK_LAUNCH();
   if (Np > 0) {
     const int pgrid = (int)gpn::cdiv(Np, kThreads);
     hipLaunchKernelGGL(bq_min_kernel, dim3(pgrid < 256 ? pgrid : 256), dim3(kThreads), 0, stream, points, Np, o.hdr);
     GPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bq_keys_kernel, dim3(pgrid), dim3(kThreads), 0, stream, points, batch_offsets, Np, S, inv_cell,
-                       o.hdr, o.keys, o.vals);
+    hipLaunchKernelGGL(bq_keys_kernel, dim3(pgrid), dim3(kThreads), 0, stream, points, point_labels, batch_offsets, Np, S,
+                       inv_cell, o.hdr, o.keys, o.vals);
     GPN_CHECK_LAUNCH();
     size_t tmp = o.prim_bytes;
     GPN_CHECK_HIP(rocprim::radix_sort_pairs(o.prim_tmp, tmp, o.keys, o.keys_sorted, o.vals, o.order, (size_t)Np, 0, 64,

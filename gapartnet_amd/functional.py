@@ -197,6 +197,31 @@ def voxelize_mean(points, feats, seg_offsets, rmin, rmax, voxel_size, grid_dims,
     return _VoxelMeanFn.apply(feats, points, seg_offsets, rmin, rmax, voxel_size, grid_dims, want_stats)
 
 
+class _ProposalVoxelMeanFn(torch.autograd.Function):
+    """voxel features of the proposal grids = ordered mean of the member points' backbone features (kernel V's mean on
+    ``pt_features[point_indices]``), differentiable w.r.t. the per-point features: each point collects d voxel / count from
+    the (at most two) proposals it belongs to.  The index structure comes from ``hip_ops.proposals_build``."""
+
+    @staticmethod
+    def forward(ctx, feats, point_indices, point_order, voxel_point_start, member_slot, pc_voxel_id, n_voxels):
+        ops = backend.raw()
+        ctx.save_for_backward(member_slot, pc_voxel_id, voxel_point_start)
+        ctx.n_points = feats.shape[0]
+        return ops.proposals_voxel_mean(feats.contiguous(), point_indices, point_order, voxel_point_start, n_voxels)
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops = backend.raw()
+        member_slot, pc_voxel_id, voxel_point_start = ctx.saved_tensors
+        return (ops.proposals_voxel_mean_bwd(dout.contiguous(), member_slot, pc_voxel_id, voxel_point_start, ctx.n_points),
+                None, None, None, None, None, None)
+
+
+def proposal_voxel_mean(feats, built) -> torch.Tensor:
+    return _ProposalVoxelMeanFn.apply(feats, built["point_indices"], built["point_order"], built["voxel_point_start"],
+                                      built["member_slot"], built["pc_voxel_id"], built["V"])
+
+
 class _PointLossesFn(torch.autograd.Function):
     """kernel family P: focal + dice + offset-distance + offset-direction losses of all points in one pass"""
 

@@ -624,3 +624,71 @@ def pn2_three_interpolate_grad(grad_out, idx, weight, m):
     check(_C.lib().gpn_pn2_three_interpolate_grad(i32(b), i32(c), i32(n), i32(m), ptr(grad_out), ptr(idx),
                                                   ptr(weight), ptr(gp), _stream()), "gpn_pn2_three_interpolate_grad")
     return gp
+
+
+# ---------------------------------------------------------------------------------------------------- PR
+def proposals_build(points_xyz, offset_preds, sem_preds, instance_labels, batch_indices, batch_size, radius, K1, K2,
+                    min_points, fullscale, max_scale, jitter):
+    """Section PR of include/gpn.h: the whole proposal stage (model.py:228-346 of the reference) in one library call and ONE
+    host read.  ``points_xyz`` = [N,3] view of the [N,6] point matrix (row stride passed through).  -> dict of tensors
+    sliced to their actual sizes, or None when no proposal survives."""
+    dev = _dev(points_xyz, offset_preds, sem_preds, batch_indices)
+    N = int(points_xyz.shape[0])
+    assert points_xyz.dtype == torch.float32 and points_xyz.stride(1) == 1 and sem_preds.dtype == torch.int64
+    stride = int(points_xyz.stride(0))
+    offset_preds = _c(offset_preds.detach(), torch.float32)
+    sem_preds = sem_preds.contiguous()
+    batch_indices = _c(batch_indices, torch.int32)
+    inst = _c(instance_labels, torch.int32) if instance_labels is not None else None
+    jit = torch.cat([jitter[0].reshape(3), jitter[1].reshape(3)]).to(device=dev, dtype=torch.float32).contiguous()
+    L = _C.lib()
+    L.gpn_proposals_max_proposals.restype = _C.ctypes.c_int64
+    P_ub = int(L.gpn_proposals_max_proposals(i64(N), i32(min_points)))
+    T2 = 2 * N
+
+    def new(shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=dev)
+    counts = new((8,), torch.int64)
+    valid_mask = new((N,), torch.bool)
+    valid_indices = new((N,), torch.int64)
+    sorted_indices, point_indices, proposal_indices = new((T2,), torch.int64), new((T2,), torch.int64), new((T2,), torch.int64)
+    batch_p, sem_p, inst_p = new((T2,), torch.int32), new((T2,), torch.int32), new((T2,), torch.int32)
+    xyz_p = new((T2, 3), torch.float32)
+    sizes, offsets = new((P_ub + 1,), torch.int64), new((P_ub + 1,), torch.int32)
+    member_slot = new((T2,), torch.int32)
+    coords4 = new((T2, 4), torch.int32)
+    pid, order, vstart = new((T2,), torch.int32), new((T2,), torch.int32), new((T2 + 1,), torch.int32)
+    ws = _ws(L.gpn_proposals_build_ws_bytes(i64(N), i64(batch_size), i32(K1), i32(K2), i32(min_points)), dev)
+    check(L.gpn_proposals_build(ptr(points_xyz), i32(stride), ptr(offset_preds), ptr(sem_preds), ptr(inst), ptr(batch_indices),
+                                i64(N), i64(batch_size), f32(radius), i32(K1), i32(K2), i32(min_points), f32(fullscale),
+                                f32(max_scale), ptr(jit), ptr(counts), ptr(valid_mask), ptr(valid_indices), ptr(sorted_indices),
+                                ptr(point_indices), ptr(proposal_indices), ptr(batch_p), ptr(xyz_p), ptr(sem_p), ptr(inst_p),
+                                ptr(sizes), ptr(offsets), ptr(member_slot), ptr(coords4), ptr(pid), ptr(order), ptr(vstart),
+                                ptr(ws), szt(ws.numel()), _stream()), "gpn_proposals_build")
+    Q, M, P, V, dropped = counts.tolist()[:5]  # the stage's single device -> host read
+    if M == 0:
+        return None
+    return dict(Q=Q, M=M, P=P, V=V, dropped=dropped, valid_mask=valid_mask, valid_indices=valid_indices[:Q],
+                sorted_indices=sorted_indices[:M], point_indices=point_indices[:M], proposal_indices=proposal_indices[:M],
+                batch_indices=batch_p[:M], pt_xyz=xyz_p[:M], sem_preds=sem_p[:M],
+                instance_labels=inst_p[:M] if instance_labels is not None else None, sizes=sizes[:P],
+                proposal_offsets=offsets[:P + 1], member_slot=member_slot, voxel_coords=coords4[:V], pc_voxel_id=pid[:M],
+                point_order=order[:M], voxel_point_start=vstart[:V + 1])
+
+
+def proposals_voxel_mean(feats, point_indices, point_order, voxel_point_start, V):
+    dev = _dev(feats)
+    feats = _c(feats, torch.float32)
+    out = torch.empty((V, feats.shape[1]), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_proposals_voxel_mean(ptr(feats), ptr(point_indices), ptr(point_order), ptr(voxel_point_start), i64(V),
+                                            i32(feats.shape[1]), ptr(out), _stream()), "gpn_proposals_voxel_mean")
+    return out
+
+
+def proposals_voxel_mean_bwd(dout, member_slot, pc_voxel_id, voxel_point_start, N):
+    dev = _dev(dout)
+    dout = _c(dout, torch.float32)
+    dfeats = torch.empty((N, dout.shape[1]), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_proposals_voxel_mean_bwd(ptr(dout), ptr(member_slot), ptr(pc_voxel_id), ptr(voxel_point_start), i64(N),
+                                                i32(dout.shape[1]), ptr(dfeats), _stream()), "gpn_proposals_voxel_mean_bwd")
+    return dfeats

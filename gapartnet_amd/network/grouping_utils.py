@@ -222,7 +222,8 @@ def _keep_proposals(proposals: Instances, keep_proposal: torch.Tensor) -> Instan
 
     return Instances(
         valid_mask=proposals.valid_mask, valid_indices=proposals.valid_indices,
-        sorted_indices=pts(proposals.sorted_indices), pt_xyz=pts(proposals.pt_xyz),
+        sorted_indices=pts(proposals.sorted_indices), point_indices=pts(proposals.point_indices),
+        pt_xyz=pts(proposals.pt_xyz),
         batch_indices=pts(proposals.batch_indices), proposal_offsets=offsets_from_counts(counts),
         proposal_indices=new_indices, num_points_per_proposal=counts, sem_preds=pts(proposals.sem_preds),
         score_preds=proposals.score_preds[keep_proposal], npcs_preds=pts(proposals.npcs_preds, npcs_keep),

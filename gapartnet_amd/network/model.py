@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import backend
 from .. import functional as GF
 from ..epic_ops.iou import batch_instance_seg_iou
 from ..epic_ops.reduce import segmented_maxpool
@@ -90,6 +91,7 @@ class GAPartNet(LightningModule):
         self.symmetry_indices = torch.as_tensor(symmetry_indices, dtype=torch.int64)
         self.voxel_size = [float(v) for v in voxel_size]
         self.revoxelize_jitter = None  # tests inject the two uniform 3-vectors of segmented_voxelize here
+        self.use_fused_proposals = True  # csrc/proposals.hip on the GPU; False = the torch formulation of the same stage
 
         self.ball_query_radius = instance_seg_cfg["ball_query_radius"]
         self.max_num_points_per_query = instance_seg_cfg["max_num_points_per_query"]
@@ -177,6 +179,12 @@ class GAPartNet(LightningModule):
         """dual-set clustering and per-proposal re-voxelisation (model.py:228-346).
         -> (voxel_tensor, pc_voxel_id, proposals) or (None, None, None) when no proposal survives."""
         device = pt_xyz.device
+        ops = backend.raw()
+        if self.use_fused_proposals and batch_size is not None and pt_xyz.is_cuda and hasattr(ops, "proposals_build"):
+            # the stage as ONE library call with ONE host read (csrc/proposals.hip); the torch formulation below is what
+            # runs over other operator backends (the CPU oracle in tests) and what this call is tested against
+            return self._proposals_fused(ops, pt_xyz, batch_indices, pt_features, sem_preds, offset_preds, instance_labels,
+                                         batch_size)
         valid_mask = sem_preds > 0
         if instance_labels is not None:
             valid_mask = valid_mask & (instance_labels >= 0)
@@ -252,6 +260,32 @@ class GAPartNet(LightningModule):
                               instance_labels=instance_labels)
         return voxel_tensor, pc_voxel_id, proposals
 
+    def _proposals_fused(self, ops, pt_xyz, batch_indices, pt_features, sem_preds, offset_preds, instance_labels, batch_size):
+        jitter = self.revoxelize_jitter
+        if jitter is None:  # the reference's two torch.rand(3) draws, in its order, from the device generator
+            jitter = (torch.rand(3, dtype=torch.float32, device=pt_xyz.device),
+                      torch.rand(3, dtype=torch.float32, device=pt_xyz.device))
+        built = ops.proposals_build(pt_xyz, offset_preds, sem_preds, instance_labels, batch_indices, batch_size,
+                                    self.ball_query_radius, self.max_num_points_per_query,
+                                    self.max_num_points_per_query_shift, self.min_num_points_per_proposal,
+                                    float(self.score_fullscale), float(self.score_scale), jitter)
+        if built is None:
+            return None, None, None
+        if built["dropped"] != 0:
+            raise RuntimeError("re-voxelisation dropped points: a proposal left its score_fullscale^3 grid "
+                               "(the reference stops in pdb here, model.py:328-330)")
+        voxel_features = GF.proposal_voxel_mean(pt_features, built)
+        voxel_tensor = spconv.SparseConvTensor(voxel_features, built["voxel_coords"],
+                                               spatial_shape=[self.score_fullscale] * 3, batch_size=built["P"])
+        voxel_tensor.point_csr = (built["point_order"], built["voxel_point_start"])
+        proposals = Instances(valid_mask=built["valid_mask"], valid_indices=built["valid_indices"],
+                              sorted_indices=built["sorted_indices"], point_indices=built["point_indices"],
+                              pt_xyz=built["pt_xyz"], batch_indices=built["batch_indices"],
+                              proposal_offsets=built["proposal_offsets"], proposal_indices=built["proposal_indices"],
+                              num_points_per_proposal=built["sizes"], sem_preds=built["sem_preds"],
+                              instance_labels=built["instance_labels"])
+        return voxel_tensor, built["pc_voxel_id"], proposals
+
     def forward_proposal_score(self, voxel_tensor: spconv.SparseConvTensor, pc_voxel_id: torch.Tensor,
                                proposals: Instances) -> torch.Tensor:
         offsets = proposals.proposal_offsets
@@ -307,6 +341,13 @@ class GAPartNet(LightningModule):
             self._symmetry_tables = tables
         num_proposals = proposals.proposal_offsets.shape[0] - 1
         return compute_npcs_loss_grouped(npcs_preds, gt_npcs, proposal_indices, sym, tables, num_proposals)
+
+    @staticmethod
+    def _proposal_rows(proposals: Instances) -> torch.Tensor:
+        """row of every proposal point in the batch's point arrays"""
+        if proposals.point_indices is not None:
+            return proposals.point_indices
+        return proposals.valid_indices[proposals.sorted_indices]
 
     # ------------------------------------------------------------------------------------------ one step
     def _collate(self, point_clouds: Union[Sequence[PointCloud], PointCloudBatch]) -> PointCloudBatch:
@@ -367,7 +408,7 @@ class GAPartNet(LightningModule):
                 offset_preds=offsets_preds, instance_labels=instance_labels, batch_size=batch_size)
             if proposals is not None:
                 if sem_labels is not None:
-                    proposals.sem_labels = sem_labels[proposals.valid_indices[proposals.sorted_indices]]
+                    proposals.sem_labels = sem_labels[self._proposal_rows(proposals)]
                 proposals.instance_sem_labels = data_batch.instance_sem_labels
 
         loss_prop_score = 0.0
@@ -386,7 +427,7 @@ class GAPartNet(LightningModule):
         if self.current_epoch >= self.start_npcs and voxel_tensor is not None:
             npcs_logits = self.forward_proposal_npcs(voxel_tensor, pc_voxel_id)
             if gt_npcs is not None:
-                gt_npcs = gt_npcs[proposals.valid_indices[proposals.sorted_indices]]
+                gt_npcs = gt_npcs[self._proposal_rows(proposals)]
                 loss_prop_npcs = self.loss_proposal_npcs(npcs_logits, gt_npcs, proposals)
 
         loss = loss_sem_seg + loss_offset_dist + loss_offset_dir + loss_prop_score + loss_prop_npcs

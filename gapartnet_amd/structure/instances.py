@@ -11,6 +11,7 @@ class Instances:
     valid_mask: Optional[torch.Tensor] = None
     valid_indices: Optional[torch.Tensor] = None  # nonzero(valid_mask), computed once (not a reference field)
     sorted_indices: Optional[torch.Tensor] = None
+    point_indices: Optional[torch.Tensor] = None  # row of every proposal point in the batch's point matrix (not a reference field)
     pt_xyz: Optional[torch.Tensor] = None
     # CSR over proposals
     batch_indices: Optional[torch.Tensor] = None

@@ -290,6 +290,10 @@ int gpn_ball_query(const float* points, const float* query, const int32_t* batch
 /* same contract and results, O(n k) instead of O(n^2): points binned into a uniform grid (one radix sort), one wave per
  * query over its 27 neighbour cells, hits ranked back into ascending point index; dense neighbourhoods fall back to the
  * index-order scan inside the kernel. */
+/* Labels < 0 mark INACTIVE points / queries (grid form only): an inactive point is never a hit, an inactive query gets
+ * count 0 - lets a caller run the query over a whole batch with the unwanted points masked instead of compacted away
+ * (gpn_proposals_build).  K | GPN_BQ_NO_PAD: rows are not -1 filled beyond count[q] (saves a Q*K*4-byte fill). */
+#define GPN_BQ_NO_PAD (1 << 30)
 size_t gpn_ball_query_grid_ws_bytes(int64_t Np);
 int gpn_ball_query_grid(const float* points, const float* query, const int32_t* batch_indices,
                         const int32_t* batch_offsets, const int32_t* point_labels, const int32_t* query_labels,
@@ -385,6 +389,41 @@ int gpn_point_losses_fwd(const float* logits, const int64_t* labels, const float
 int gpn_point_losses_bwd(const float* logits, const int64_t* labels, const float* offsets, const float* gt_offsets,
                          const int32_t* instance_labels, int64_t M, int C, int64_t ignore_index, const void* stats,
                          const float* grad_losses, float* d_logits, float* d_offsets, gpn_stream_t stream);
+
+/* ================================================================================================
+ * PR — the proposal stage of a step in one call: GAPartNet.proposal_clustering_and_revoxelize (network/model.py:228-346)
+ * with cluster_proposals (network/grouping_utils.py:108-140) and the geometry of segmented_voxelize (:47-104).
+ * Inputs: points [N, point_stride] f32 (xyz = first three columns), offset_preds [N,3] f32, sem_preds [N] i64 (arg-max of
+ * the semantic head), instance_labels [N] i32 or NULL, batch_indices [N] i32 (scene of every point, non-decreasing),
+ * jitter [6] f32 on the DEVICE = the two uniform 3-vectors of grouping_utils.py:86-90.
+ * A point is valid if sem_preds > 0 (and instance_labels >= 0 when given).  Both cluster sets (xyz, xyz + offset; radius,
+ * K1 / K2 neighbours, label-aware) -> proposals of >= min_points points, ordered by their first point, members ascending,
+ * set A's proposals before set B's -> per-proposal frame (centre, scale <= max_scale, jittered shift) -> fullscale^3 voxel
+ * grid per proposal.  Nothing is read back: every output has its upper-bound capacity and counts [8] i64 (device) holds
+ * {Q valid points, M proposal points, P proposals, V voxels, points dropped by the voxeliser, ...}.
+ * Outputs (capacity): valid_mask [N] u8, valid_indices [N] i64; per proposal point [2N]: sorted_indices i64 (numbering
+ * among the valid points, as the reference), point_indices i64 (row of `points`), proposal_indices i64, batch_indices_p
+ * i32, pt_xyz_p [.,3] f32, sem_preds_p i32, instance_labels_p i32, pc_voxel_id i32, point_order i32 (+ voxel_point_start
+ * [2N+1] i32: points grouped by voxel); member_slot [2N] i32 (row of the proposal-point list holding point i in set A
+ * (entry i) / set B (entry N+i), -1 if none); per proposal [gpn_proposals_max_proposals + 1]: sizes i64,
+ * proposal_offsets i32; voxel_coords4 [2N,4] i32 = (proposal, x, y, z), ordered.
+ * gpn_proposals_voxel_mean(_bwd): voxel features = ordered mean of feats[point_indices] over each voxel's points, and its
+ * transpose (each point sums its at most two memberships in fixed order) - the differentiable half of kernel V.
+ * ================================================================================================ */
+int64_t gpn_proposals_max_proposals(int64_t N, int min_points);
+size_t gpn_proposals_build_ws_bytes(int64_t N, int64_t B, int K1, int K2, int min_points);
+int gpn_proposals_build(const float* points, int point_stride, const float* offset_preds, const int64_t* sem_preds,
+                        const int32_t* instance_labels, const int32_t* batch_indices, int64_t N, int64_t B, float radius,
+                        int K1, int K2, int min_points, float fullscale, float max_scale, const float* jitter,
+                        int64_t* counts, uint8_t* valid_mask, int64_t* valid_indices, int64_t* sorted_indices,
+                        int64_t* point_indices, int64_t* proposal_indices, int32_t* batch_indices_p, float* pt_xyz_p,
+                        int32_t* sem_preds_p, int32_t* instance_labels_p, int64_t* sizes, int32_t* proposal_offsets,
+                        int32_t* member_slot, int32_t* voxel_coords4, int32_t* pc_voxel_id, int32_t* point_order,
+                        int32_t* voxel_point_start, void* ws, size_t ws_bytes, gpn_stream_t stream);
+int gpn_proposals_voxel_mean(const float* feats, const int64_t* point_indices, const int32_t* point_order,
+                             const int32_t* voxel_point_start, int64_t V, int C, float* out, gpn_stream_t stream);
+int gpn_proposals_voxel_mean_bwd(const float* dout, const int32_t* member_slot, const int32_t* pc_voxel_id,
+                                 const int32_t* voxel_point_start, int64_t N, int C, float* dfeats, gpn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -153,7 +153,9 @@ def test_config5_mixed_batch32_npcs_and_pose_heads(cuda):
     the test path with batched pose fitting on the predicted NPCS of every kept proposal."""
     from gapartnet_amd.misc.pose_fitting_batched import estimate_pose_from_npcs_batched
     scenes = [pc.to(cuda) for pc in _mixed_category_scenes(32)]
-    model = make_model((0, 0)).to(cuda)
+    model = make_model((0, 0))
+    model.load_state_dict(recipe.name_keyed_state(model))
+    model = model.to(cuda)
     model.revoxelize_jitter = tuple(j.to(cuda) for j in JITTER)
     rec = {}
     model._log_sink = lambda name, value, bs, sync: rec.__setitem__(name, float(value))

@@ -1,0 +1,78 @@
+"""csrc/proposals.hip (the proposal stage as one library call with one host read) against the torch formulation of the same
+stage on the same GPU inputs - which is itself pinned to the reference's model.py by tests/test_golden_pipeline.py.  Every
+integer output must be equal, the voxel features (ordered means) too; gradients w.r.t. the point features bit-equal."""
+import numpy as np
+import pytest
+import torch
+
+from gapartnet_amd.smoke import make_batch, make_model
+from gapartnet_amd.structure.point_cloud import PointCloud
+from tests.golden import recipe
+
+pytestmark = pytest.mark.gpu
+JITTER = (torch.tensor([0.3, 0.6, 0.1]), torch.tensor([0.5, 0.2, 0.9]))
+FIELDS = ("valid_mask", "valid_indices", "sorted_indices", "pt_xyz", "batch_indices", "proposal_offsets", "proposal_indices",
+          "num_points_per_proposal", "sem_preds", "instance_labels")
+
+
+def _stage(model, batch, feats, sem_preds, offsets, fused, with_labels=True):
+    model.use_fused_proposals = fused
+    f = feats.clone().requires_grad_(True)
+    vt, pid, props = model.proposal_clustering_and_revoxelize(
+        pt_xyz=batch.points[:, :3], batch_indices=batch.batch_indices, pt_features=f, sem_preds=sem_preds, offset_preds=offsets,
+        instance_labels=batch.instance_labels if with_labels else None, batch_size=batch.batch_size)
+    return f, vt, pid, props
+
+
+@pytest.mark.parametrize("n_scenes,n_points,with_labels", [(2, 4000, True), (8, 20000, True), (3, 6000, False), (1, 50000, True)])
+def test_fused_stage_equals_the_torch_formulation(cuda, n_scenes, n_points, with_labels):
+    model = make_model((0, 0), channels=[16, 32])
+    model.load_state_dict(recipe.name_keyed_state(model))
+    model = model.to(cuda).eval()
+    model.revoxelize_jitter = tuple(j.to(cuda) for j in JITTER)
+    batch = PointCloud.collate([pc.to(cuda) for pc in make_batch(n_scenes, n_points, seed0=900 + n_points)], voxel_size=(0.01,) * 3)
+    g = torch.Generator().manual_seed(n_points)
+    N = batch.points.shape[0]
+    feats = torch.randn(N, 16, generator=g).to(cuda)
+    # spatially coherent fake predictions: class from a coarse grid cell, offsets of a few millimetres
+    cell = torch.floor(batch.points[:, :3] * 4).long()
+    sem_preds = ((cell[:, 0] * 7 + cell[:, 1] * 3 + cell[:, 2]) % 10).clamp(min=0)
+    offsets = (0.01 * torch.randn(N, 3, generator=g)).to(cuda)
+    out = {}
+    for fused in (False, True):
+        f, vt, pid, props = _stage(model, batch, feats, sem_preds, offsets, fused, with_labels)
+        assert props is not None
+        w = torch.linspace(-1, 1, vt.features.numel(), device=cuda).view_as(vt.features)
+        (vt.features * w).sum().backward()
+        out[fused] = (f.grad, vt, pid, props)
+    (g0, vt0, pid0, p0), (g1, vt1, pid1, p1) = out[False], out[True]
+    for name in FIELDS:
+        a, b = getattr(p0, name), getattr(p1, name)
+        if a is None:
+            assert b is None, name
+            continue
+        assert a.dtype == b.dtype and a.shape == b.shape, (name, a.dtype, b.dtype, a.shape, b.shape)
+        assert torch.equal(a, b), name
+    assert torch.equal(p1.point_indices, p0.valid_indices[p0.sorted_indices])
+    assert torch.equal(vt0.indices, vt1.indices) and vt0.batch_size == vt1.batch_size and vt0.spatial_shape == vt1.spatial_shape
+    assert torch.equal(pid0, pid1)
+    assert torch.equal(vt0.features, vt1.features), "ordered means: bit-equal"
+    for a, b in zip(vt0.point_csr, vt1.point_csr):
+        assert torch.equal(a, b)
+    assert torch.equal(g0, g1), "d point features"
+
+
+def test_fused_stage_without_proposals(cuda):
+    model = make_model((0, 0), channels=[16, 32]).to(cuda).eval()
+    batch = PointCloud.collate([pc.to(cuda) for pc in make_batch(2, 3000)], voxel_size=(0.01,) * 3)
+    N = batch.points.shape[0]
+    feats = torch.zeros(N, 16, device=cuda)
+    offsets = torch.zeros(N, 3, device=cuda)
+    # nothing valid at all
+    none = _stage(model, batch, feats, torch.zeros(N, dtype=torch.int64, device=cuda), offsets, True)
+    assert none[1] is None and none[3] is None
+    # valid points, but every one its own class neighbourhood: clusters stay below min_num_points_per_proposal
+    sem = (torch.arange(N, device=cuda) % 9) + 1
+    model.ball_query_radius = 1e-4
+    none = _stage(model, batch, feats, sem, offsets, True)
+    assert none[3] is None
