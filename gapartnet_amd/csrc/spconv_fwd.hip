@@ -23,6 +23,7 @@
 // that a fixed-order kernel sums.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 #include "gpn_common.h"
 
@@ -515,6 +516,157 @@ int dispatch_stream(const StreamPlan& sp, const float* in, const float* packed, 
   return launch_stream<NTW, 8, 8, 1>(sp, in, packed, nbr, perm, n_dst, cin, nt_total, out, stream);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// "Direct" variant for the mid-size levels (a few thousand tiles, 32..64 channels): no LDS, no barrier, no persistence.
+// A wave owns ONE 16-row tile and ONE 16-wide output-column tile and walks all (tap, input block) stages with its
+// accumulator in registers; the weight fragment of a stage (1 KiB, the MFMA B operand) comes straight from L2 with one
+// coalesced 16-byte load per lane, D stages ahead, next to the gathered rows.  The streaming kernel above stages all
+// taps' weights of an input block in LDS (81 KiB at 48 channels => one workgroup per CU, input blocks as separate passes
+// with partial outputs); at these sizes there are only ~1-3 tiles per resident wave slot to amortise that over.  Here
+// every (tile, column tile) pair is its own wave - 4 425 waves for a 23 k-row, 48-channel level - and a SIMD interleaves
+// 4-5 of them, which is what hides the gather latency.  The waves of one tile are adjacent (they gather the same rows:
+// L1 / L2 hits).  Same arithmetic and summation order per output element as the other variants (tap-major, then input
+// block, then channel).
+#ifndef GPN_DIRECT_D
+#define GPN_DIRECT_D 4
+#endif
+template <int KT, int CB>
+__global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __restrict__ in, const float* __restrict__ packed,
+                                                                const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
+                                                                int64_t units, size_t packed_bytes,
+                                                                const int32_t* __restrict__ perm, float* __restrict__ out) {
+  constexpr int S = KT * CB;
+  constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;  // prefetch depth in stages
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  if (unit >= units) return;  // whole wave; no barrier in this kernel
+  const int64_t tile = unit / nt_total;
+  const int nt = (int)(unit - tile * nt_total);
+  const int cin = CB * 16, cout = nt_total * 16;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t nbr_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(nbr), 0, 0x7fffffff, 0x00020000);
+  // weight fragments through a buffer descriptor as well: a stage whose tap no row of the tile has (wave-uniform) reads at
+  // an out-of-range offset - zeros, and no memory access
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed), 0, (int)packed_bytes, 0x00020000);
+  const uint32_t col_bytes = (uint32_t)n_dst * 4u;
+  const int64_t row0 = tile * 16;
+  const bool row_ok = row0 + i16 < n_dst;
+  const uint32_t rc = (uint32_t)(row_ok ? row0 + i16 : n_dst - 1);
+
+  int32_t ireg[KT];
+#pragma unroll
+  for (int u = 0; u < KT; ++u) {
+    const int32_t v = __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(rc * 4u), (int)(u * col_bytes), 0));
+    ireg[u] = v;
+  }
+  f32x4 areg[D], breg[D];
+  auto issue = [&](int s, int slot) {  // s = tap * CB + cb: compile-time after unrolling
+    const int tap = s / CB, cb = s - tap * CB;
+    const int32_t idx = row_ok ? ireg[tap] : -1;
+    const bool live = __builtin_amdgcn_sicmp(idx, -1, 38 /* ICMP_SGT */) != 0;  // wave-uniform: some row of the tile has the tap
+    const uint32_t off = idx < 0 ? 0x80000000u : ((uint32_t)idx * (uint32_t)cin + 4u * (uint32_t)g) * 4u;
+    areg[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, cb * 64, 0));
+    const uint32_t boff = live ? (uint32_t)((s * nt_total + nt) * 1024 + lane * 16) : 0x80000000u;
+    breg[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)boff, 0, 0));
+  };
+#pragma unroll
+  for (int s = 0; s < D; ++s) issue(s, s);
+
+  int32_t orow[4];
+  if (perm) {
+    const int4 pv = *reinterpret_cast<const int4*>(perm + row0 + 4 * g);
+    orow[0] = pv.x, orow[1] = pv.y, orow[2] = pv.z, orow[3] = pv.w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + 4 * g + r;
+      orow[r] = (int32_t)(row < n_dst ? row : n_dst - 1);
+    }
+  }
+  // two-level summation: a tap's CB * 16 products accumulate in `part` (one MFMA chain), the taps' partial sums are
+  // added to `acc` - rounding error grows with sqrt(16 CB) + sqrt(KT) terms instead of sqrt(16 CB KT) (measured against a
+  // float64 evaluation: 2e-7 relative instead of 6e-7; BatchNorm on the tiny deep levels amplifies it ~1000x in backward)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tap = 0; tap < KT; ++tap) {
+    if (__builtin_amdgcn_sicmp(row_ok ? ireg[tap] : -1, -1, 38 /* ICMP_SGT */) != 0) {  // some row of the tile has this tap
+      f32x4 part = zero;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int s = tap * CB + cb;
+        const f32x4 a = areg[s % D], b = breg[s % D];
+        if (s + D < S) issue(s + D, s % D);
+        part = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, part, 0, 0, 0);
+        part = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, part, 0, 0, 0);
+        part = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, part, 0, 0, 0);
+        part = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, part, 0, 0, 0);
+      }
+      acc += part;
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {  // nothing to contract (the operands of these stages were read as zeros): keep the ring moving
+        const int s = tap * CB + cb;
+        if (s + D < S) issue(s + D, s % D);
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = row0 + 4 * g + r;
+    if (row < n_dst) out[(uint32_t)orow[r] * (uint32_t)cout + (uint32_t)(nt * 16 + i16)] = acc[r];
+  }
+}
+
+template <int KT, int CB>
+int launch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int nt_total,
+                  float* out, hipStream_t stream) {
+  const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
+  const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
+  hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)gpn::cdiv(units, 4)), dim3(256), 0, stream, in, packed,
+                     nbr, n_dst, nt_total, units, packed_bytes, perm, out);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+// which shapes take the direct variant.  Measured on the bench shapes (8 x 20k-point scenes; tools/kernel_rooflines.py, us per
+// launch, streaming / lock-step kernel -> direct): L0 16->16 144k rows 32.5 -> 27, L1 32->32 80k rows 71.6 -> 56,
+// L2 48->48 25k rows 74.0 -> 42; conv family per training step 5.23 -> 4.1 ms.  Below 16 tiles (the two deepest levels)
+// a layer has too few (tile, column) units to fill the chip and the tap-split lock-step kernel stays in use; so do the
+// k = 1 layers and input widths the unrolled stage loop is not instantiated for.
+bool use_direct(int K, int64_t n_dst, int cin, int cout) {
+  static const bool disabled = getenv("GPN_CONV_NO_DIRECT") != nullptr;  // A/B switch for measurements
+  if (disabled) return false;
+  const int CB = cin / 16;
+  if (!(K == 27 || K == 8)) return false;
+  if (!(CB >= 1 && (CB <= 8 || CB == 10 || CB == 12))) return false;
+  // 32-bit byte offsets: source rows (at most 8 n_dst of them, for a stride-2 conv), output rows, the neighbour table
+  if (n_dst * (int64_t)8 * std::max(cin, cout) * 4 >= ((int64_t)1 << 31) || (int64_t)K * n_dst * 4 >= ((int64_t)1 << 31)) return false;
+  return gpn::cdiv(n_dst, 16) >= 16;
+}
+
+template <int KT>
+int dispatch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int cin,
+                    int nt_total, float* out, hipStream_t stream) {
+  switch (cin / 16) {
+    case 1: return launch_direct<KT, 1>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    case 2: return launch_direct<KT, 2>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    case 3: return launch_direct<KT, 3>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    case 4: return launch_direct<KT, 4>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    case 5: return launch_direct<KT, 5>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    case 6: return launch_direct<KT, 6>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    case 7: return launch_direct<KT, 7>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    case 8: return launch_direct<KT, 8>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    case 10: return launch_direct<KT, 10>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    default: return launch_direct<KT, 12>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+  }
+}
+
 }  // namespace
 
 extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout) {
@@ -537,6 +689,12 @@ extern "C" int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, co
   if (n_dst == 0) return GPN_OK;
   GPN_CHECK_ARG(in && packed_w && nbr && out);
   const int nt = cout / 16;
+  if (use_direct(K, n_dst, cin, cout)) {
+    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
+    const int32_t* table = nbr_p ? nbr_p : nbr;
+    return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, out, stream)
+                   : dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, out, stream);
+  }
   const StreamPlan sp = plan_stream(K, n_dst, cin, cout);
   if (sp.use) {
     float* target = out;
