@@ -557,16 +557,20 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   const bool row_ok = row0 + i16 < n_dst;
   const uint32_t rc = (uint32_t)(row_ok ? row0 + i16 : n_dst - 1);
 
-  int32_t ireg[KT];
+  // the tile's column of the neighbour table, DI taps ahead of the contraction (a ring instead of all KT entries: 92 -> ~75
+  // VGPRs, one more wave per SIMD)
+  constexpr int DI = KT < 10 ? KT : 10;
+  static_assert(DI == KT || DI >= D + 2, "the index of a stage issued D stages ahead must already be in the ring");
+  int32_t ireg[DI];
+  auto load_idx = [&](int tap) -> int32_t {
+    return __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(rc * 4u), (int)(tap * col_bytes), 0));
+  };
 #pragma unroll
-  for (int u = 0; u < KT; ++u) {
-    const int32_t v = __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(rc * 4u), (int)(u * col_bytes), 0));
-    ireg[u] = v;
-  }
+  for (int u = 0; u < DI; ++u) ireg[u] = load_idx(u);
   f32x4 areg[D], breg[D];
   auto issue = [&](int s, int slot) {  // s = tap * CB + cb: compile-time after unrolling
     const int tap = s / CB, cb = s - tap * CB;
-    const int32_t idx = row_ok ? ireg[tap] : -1;
+    const int32_t idx = row_ok ? ireg[tap % DI] : -1;
     const bool live = __builtin_amdgcn_sicmp(idx, -1, 38 /* ICMP_SGT */) != 0;  // wave-uniform: some row of the tile has the tap
     const uint32_t off = idx < 0 ? 0x80000000u : ((uint32_t)idx * (uint32_t)cin + 4u * (uint32_t)g) * 4u;
     areg[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, cb * 64, 0));
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int tap = 0; tap < KT; ++tap) {
-    if (__builtin_amdgcn_sicmp(row_ok ? ireg[tap] : -1, -1, 38 /* ICMP_SGT */) != 0) {  // some row of the tile has this tap
+    if (__builtin_amdgcn_sicmp(row_ok ? ireg[tap % DI] : -1, -1, 38 /* ICMP_SGT */) != 0) {  // some row of the tile has this tap
       f32x4 part = zero;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
@@ -614,6 +618,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
         if (s + D < S) issue(s + D, s % D);
       }
     }
+    if (tap + DI < KT) ireg[tap % DI] = load_idx(tap + DI);
     asm volatile("" ::: "memory");
   }
 #pragma unroll

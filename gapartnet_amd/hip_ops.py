@@ -144,7 +144,12 @@ def rulebook_subm3(indices, spatial_shape) -> Rulebook:
     return rb
 
 
-TILE_ORDER_MIN_ROWS = 16384  # levels served by the persistent conv kernel (>= 1024 tiles)
+import os as _os
+# rows re-ordered by neighbour mask (gpn_rulebook_tile_order) paid off for the persistent streaming conv kernel (r1: 22.7 ->
+# 12.6 executed taps per tile at level 0); the direct kernel is insensitive to it (29.2 us per launch at level 0 either way,
+# tools/kernel_rooflines.py) while building the order costs a radix sort + a permuted table per level and step (level-0
+# rulebook 207 -> 113 us): off by default, GPN_TILE_ORDER_MIN_ROWS=16384 restores it
+TILE_ORDER_MIN_ROWS = int(_os.environ.get("GPN_TILE_ORDER_MIN_ROWS", 1 << 62))
 TILE_ORDER_BLOCK = 4096  # 1024: 3 % slower convs; 16k-128k: within 1 % (tools sweep), 4096 keeps tiles spatially local
 
 

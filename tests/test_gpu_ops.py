@@ -412,8 +412,9 @@ def test_tile_ordered_conv_is_bit_equal(H, cuda):
     shape = [160, 160, 160]
     idx = dev(synth.surface_indices(rng, 4, shape, 9000), cuda)
     n = idx.shape[0]
-    assert n >= H.TILE_ORDER_MIN_ROWS
     rb = H.rulebook_subm3(idx, shape)
+    if rb.perm is None:  # the order is an option of the rulebook builder (off by default since the direct conv kernel)
+        rb.perm, rb.nbr_p = H.tile_order(rb.nbr, 27, n)
     assert rb.perm is not None and rb.nbr_p is not None
     perm = rb.perm[:n].long()
     assert torch.equal(torch.sort(perm)[0], torch.arange(n, device=cuda)), "perm is a permutation"

@@ -11,7 +11,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o t
 f=$(find /tmp/p1 -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" "$O/kernel_stats.csv"; python "$R/tools/gpu_categories.py" "$f" 21 > "$O/gpu_time_by_category.txt" 2>&1; fi
 f=$(find /tmp/p1 -name "*kernel_trace.csv" 2>/dev/null | head -1)
-if [ -n "$f" ]; then python "$R/tools/timeline.py" "$f" > "$O/timeline.txt" 2>&1; fi
+if [ -n "$f" ]; then python "$R/tools/timeline.py" "$f" "$O/timeline.txt" 0.4 > /dev/null 2>&1; fi
 cd "$R"
 timeout 200 python tools/phase_profile.py > "$O/phase.txt" 2>&1
 timeout 200 python tools/op_count.py > "$O/opcount.txt" 2>&1
