@@ -1,0 +1,60 @@
+// optim.hip — Adam update of every parameter of the model in ONE launch (include/gpn.h section O).
+//
+// Reference: GAPartNet.configure_optimizers (network/model.py:1051-1055) = torch.optim.Adam(lr); the update rule below is
+// torch's single-tensor Adam, operation by operation in fp32 (exp_avg.lerp_(g, 1 - b1); exp_avg_sq.mul_(b2).addcmul_(g, g,
+// 1 - b2); denom = sqrt(exp_avg_sq) / sqrt(1 - b2^t) + eps; p.addcdiv_(exp_avg, denom, -lr / (1 - b1^t))).
+// torch's own fused / foreach implementations spend ~1 ms of host time per step grouping the model's ~330 tensors and issue
+// 9-15 launches; here the tensors are described ONCE by a device-resident table (pointers do not change from step to step:
+// the executor's gradient buffer is persistent), a step is one launch and a few scalars.
+#include "gpn_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 4096;  // elements per workgroup
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(const gpn_adam_tensor_t* __restrict__ table,
+                                                        const int32_t* __restrict__ block_first, int n_tensors, float b1w,
+                                                        float b2, float b2w, float bc2_sqrt, float eps, float neg_step) {
+  // tensor of this block: last t with block_first[t] <= blockIdx.x
+  int lo = 0, hi = n_tensors - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (block_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const gpn_adam_tensor_t t = table[lo];
+  const int64_t base = (int64_t)((int)blockIdx.x - block_first[lo]) * kChunk;
+  float* __restrict__ p = static_cast<float*>(t.param);
+  const float* __restrict__ g = static_cast<const float*>(t.grad);
+  float* __restrict__ m = static_cast<float*>(t.exp_avg);
+  float* __restrict__ v = static_cast<float*>(t.exp_avg_sq);
+  for (int64_t i = base + threadIdx.x; i < base + kChunk && i < t.numel; i += kThreads) {
+    const float gi = g[i];
+    float mi = m[i], vi = v[i];
+    mi = __fadd_rn(mi, __fmul_rn(b1w, __fsub_rn(gi, mi)));
+    vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(b2w, __fmul_rn(gi, gi)));
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), bc2_sqrt), eps);
+    p[i] = __fadd_rn(p[i], __fmul_rn(neg_step, __fdiv_rn(mi, denom)));
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+}  // namespace
+
+extern "C" int gpn_adam_blocks(int64_t numel) { return (int)gpn::cdiv(numel > 0 ? numel : 1, kChunk); }
+
+extern "C" int gpn_adam_step(const gpn_adam_tensor_t* table_dev, const int32_t* block_first_dev, int n_tensors, int n_blocks,
+                             double lr, double beta1, double beta2, double eps, int64_t step, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(n_tensors >= 0 && n_blocks >= 0 && step >= 1);
+  if (n_tensors == 0 || n_blocks == 0) return GPN_OK;
+  GPN_CHECK_ARG(table_dev && block_first_dev);
+  // scalars in double like torch's Python-side arithmetic, rounded to fp32 once (1 - 0.999f would be off by 1.3e-5)
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(n_blocks), dim3(kThreads), 0, stream, table_dev, block_first_dev, n_tensors,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-lr / bc1));
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}

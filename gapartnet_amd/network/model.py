@@ -542,7 +542,7 @@ class GAPartNet(LightningModule):
         self._epoch_end_metrics()
 
     def configure_optimizers(self):
-        params = list(self.parameters())
-        # same update rule; on the GPU the fused multi-tensor implementation does it in a handful of launches
-        fused = len(params) > 0 and all(p.is_cuda and p.dtype == torch.float32 for p in params)
-        return torch.optim.Adam(params, lr=self.learning_rate, fused=fused)
+        """Adam(lr) over every parameter (model.py:1051-1055); FusedAdam is a torch.optim.Adam whose step on the GPU is one
+        launch (gapartnet_amd/optim.py), with torch's implementation for everything else"""
+        from ..optim import FusedAdam
+        return FusedAdam(list(self.parameters()), lr=self.learning_rate)

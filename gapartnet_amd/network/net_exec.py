@@ -103,6 +103,8 @@ class NetProgram:
         self.grad_sizes = [int(v) for v in self.conv_numel] + [int(v) for v in self.bn_C] * 2  # flat gradient buffer layout
         self.grad_total = int(sum(self.grad_sizes))
         self.last_pgrad = None
+        self._grad_cache = {}
+        self._anchor = torch.zeros(1, requires_grad=True)  # see _NetFn
         self.signature = self._signature(unet)
 
     # ------------------------------------------------------------------ program construction
@@ -238,6 +240,22 @@ class NetProgram:
     def params(self):
         return [c.weight for c in self.convs] + [b.weight for b in self.bns] + [b.bias for b in self.bns]
 
+    def grad_buffer(self, device, params, fresh: bool):
+        """-> (flat fp32 buffer of grad_total elements, per-parameter views of it in params() order).  The persistent pair
+        is created once per device and handed out again every step (the kernels overwrite it); ``fresh`` asks for a
+        private buffer instead (gradient accumulation)."""
+        def make():
+            flat = torch.empty((self.grad_total,), dtype=torch.float32, device=device)
+            pieces = flat.split(self.grad_sizes)
+            return flat, [piece.view_as(p) for piece, p in zip(pieces, params)]
+        if fresh:
+            return make()
+        cached = self._grad_cache.get(device)
+        if cached is None or any(v.shape != p.shape for v, p in zip(cached[1], params)):
+            cached = make()
+            self._grad_cache[device] = cached
+        return cached
+
 
 def _vp(a: np.ndarray):
     return ctypes.c_void_p(a.ctypes.data)
@@ -261,10 +279,19 @@ def _call(fn_name, prog, slots, rb_table, conv_table, bn_table, extra, device):
 
 
 class _NetFn(torch.autograd.Function):
-    """the whole program as one differentiable op: inputs = features + every conv weight / BN weight / BN bias"""
+    """the whole program as one differentiable op.  Only the features (and an anchor, below) are autograd inputs; the ~110
+    parameters of a U-Net are not: backward() hands each of them its slice of ONE flat gradient buffer by assigning
+    ``.grad`` directly.  With the parameters as autograd inputs every backward pass cost ~3 dispatches per parameter
+    (slice views, AccumulateGrad's detach) - ~1000 per training step for the three U-Nets, 3 ms of host time
+    (tools/op_count.py) for handing over buffers that already exist.  The flat buffer and the per-parameter views are
+    allocated once per program and reused while ``.grad`` is None at backward time (optimizer.zero_grad(set_to_none=True),
+    the default); a parameter that still holds a gradient gets the new one added, as autograd would.
+    ``anchor`` is a one-element leaf that requires grad: it makes autograd call backward() even when the input features
+    do not require a gradient (the backbone's voxel features)."""
 
     @staticmethod
-    def forward(ctx, features, prog: NetProgram, rt, training, *params):
+    def forward(ctx, features, anchor, prog: NetProgram, rt, training):
+        params = prog.params()
         rows, rb_table, rb_objs = rt
         features = features.contiguous()
         dev = features.device
@@ -327,7 +354,8 @@ class _NetFn(torch.autograd.Function):
         slots["grad_state"][prog.out_slot] = 1
         n_conv, n_bn = len(prog.convs), len(prog.bns)
         total_w, total_c = int(prog.conv_off[-1]), int(prog.bn_off[-1])
-        pgrad = torch.empty((total_w + 2 * total_c,), dtype=torch.float32, device=dev)
+        fresh = any(p.grad is not None for p in params)  # accumulation into existing gradients: temporary buffer, then add
+        pgrad, views = prog.grad_buffer(dev, params, fresh)
         pbase = pgrad.data_ptr()
         conv_table = conv_table.copy()
         conv_table["dW"] = pbase + prog.conv_off[:-1] * 4
@@ -344,12 +372,22 @@ class _NetFn(torch.autograd.Function):
                     GF._log(rb_t, conv.out_channels, conv.in_channels, "dgrad")
                 GF._log(rb, conv.in_channels, conv.out_channels, "wgrad")
         din = garena[:features.numel()].view_as(features) if need_in else None
-        # one split for all 3 x n tensors (a slice + view per parameter costs ~600 dispatches per pass)
-        pieces = pgrad.split(prog.grad_sizes)
-        prog.last_pgrad = pgrad  # grad_sync all-reduces this buffer in place (the slices below become .grad)
-        grads = [pieces[i].view_as(params[i]) for i in range(n_conv)] + list(pieces[n_conv:])
+        if fresh:
+            for p, g in zip(params, views):
+                if not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+            prog.last_pgrad = None
+        else:
+            for p, g in zip(params, views):
+                if p.requires_grad:
+                    p.grad = g
+            prog.last_pgrad = pgrad  # grad_sync all-reduces this buffer in place (its slices are the parameters' .grad)
         ctx.state = None
-        return (din, None, None, None, *grads)
+        return din, None, None, None, None
 
 
 def program_for(unet) -> Optional[NetProgram]:
@@ -390,7 +428,7 @@ def run(unet, x):
     if training:
         with torch.no_grad():
             torch._foreach_add_([bn.num_batches_tracked for bn in prog.bns], 1)
-    out = _NetFn.apply(x.features, prog, (rows, rb_table, rb_objs), training, *prog.params())
+    out = _NetFn.apply(x.features, prog._anchor, prog, (rows, rb_table, rb_objs), training)
     lvl = prog.slot_level[prog.out_slot]
     idx, shape = levels[lvl]
     return spconv.SparseConvTensor(out, idx, shape, x.batch_size, x.indice_dict)

@@ -425,6 +425,24 @@ int gpn_proposals_voxel_mean(const float* feats, const int64_t* point_indices, c
 int gpn_proposals_voxel_mean_bwd(const float* dout, const int32_t* member_slot, const int32_t* pc_voxel_id,
                                  const int32_t* voxel_point_start, int64_t N, int C, float* dfeats, gpn_stream_t stream);
 
+/* ================================================================================================
+ * O — the optimizer step.  GAPartNet.configure_optimizers (network/model.py:1051-1055): torch.optim.Adam(lr) over every
+ * parameter.  One launch for the whole model: table [n_tensors] on the DEVICE describes the fp32 tensors (built once;
+ * pointers are stable from step to step), block_first [n_tensors] i32 = first workgroup of each tensor with
+ * gpn_adam_blocks(numel) workgroups per tensor.  Update = torch's single-tensor Adam in fp32 (no amsgrad, no weight decay),
+ * `step` = the 1-based step count shared by the tensors of the call.
+ * ================================================================================================ */
+typedef struct {
+  void* param;
+  const void* grad;
+  void* exp_avg;
+  void* exp_avg_sq;
+  int64_t numel;
+} gpn_adam_tensor_t;
+int gpn_adam_blocks(int64_t numel);
+int gpn_adam_step(const gpn_adam_tensor_t* table_dev, const int32_t* block_first_dev, int n_tensors, int n_blocks, double lr,
+                  double beta1, double beta2, double eps, int64_t step, gpn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
