@@ -226,3 +226,220 @@ extern "C" int gpn_point_losses_bwd(const float* logits, const int64_t* labels, 
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
+
+// ====================================================================================================================
+// NPCS loss of all proposals (network/model.py:398-462 + compute_npcs_loss, network/grouping_utils.py:14-43).
+// Per point: valid = predicted class == label and a non-zero NPCS target; prediction = the 3 of its 3 x (classes - 1)
+// logits that belong to the predicted class; the class's symmetry type t selects a list of candidate rotations S_j and the
+// loss term (group) it counts in: types 0-2 -> group 0 (2 candidates each), 3 -> group 1 (12), 4 -> group 2 (24).
+// cost_j = 5 d2 if d2 <= 0.01 else sqrt(d2) - 0.05 with d2 = |pred - gt S_j - 0.5|^2; per (proposal, group): mean over the
+// member points, minimum over j; per group: mean over the proposals that have members; loss = sum over groups.
+// The reference (and the torch formulation in network/grouping_utils.py) evaluates this with boolean-mask selections per
+// group (twelve host reads) or ~70 element-wise / segment launches forward and ~100 backward; here: one wave per
+// proposal forward, one block to finish, one thread per point backward.  Reductions are fixed-order: deterministic.
+namespace {
+
+constexpr int kMaxCand = 24;
+
+struct NpcsTypeInfo {  // per symmetry type: first matrix, number of candidates, loss group
+  int first[8], count[8], group[8];
+  int n_types;
+};
+
+__device__ __forceinline__ float npcs_cost(const float pred[3], const float gt[3], const float* __restrict__ S, float* r_out) {
+  // target = gt (row vector) @ S; r = pred - target - 0.5
+  float d2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float t = __fadd_rn(__fadd_rn(__fmul_rn(gt[0], S[c]), __fmul_rn(gt[1], S[3 + c])), __fmul_rn(gt[2], S[6 + c]));
+    const float r = __fsub_rn(__fsub_rn(pred[c], t), 0.5f);
+    if (r_out) r_out[c] = r;
+    d2 = __fadd_rn(d2, __fmul_rn(r, r));
+  }
+  return d2;
+}
+
+__global__ __launch_bounds__(256) void npcs_loss_proposal_kernel(
+    const float* __restrict__ logits, int n_cls3, const float* __restrict__ gt, const int32_t* __restrict__ sem_preds,
+    const int64_t* __restrict__ sem_labels, const int32_t* __restrict__ proposal_offsets, int64_t P,
+    const int64_t* __restrict__ sym_of_class, const float* __restrict__ mats, NpcsTypeInfo info,
+    float* __restrict__ best /* [P,3] */, int32_t* __restrict__ arg /* [P,3] */, int32_t* __restrict__ cnt /* [P,3] */) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  const int32_t b = proposal_offsets[p], e = proposal_offsets[p + 1];
+  int members[3] = {0, 0, 0};
+  for (int32_t m = b + lane; m < e; m += 64) {
+    const int32_t cls = sem_preds[m];
+    const bool valid = (int64_t)cls == sem_labels[m] && (gt[m * 3] != 0.f || gt[m * 3 + 1] != 0.f || gt[m * 3 + 2] != 0.f);
+    if (valid) {
+      const int g = info.group[(int)sym_of_class[cls]];
+      members[0] += g == 0, members[1] += g == 1, members[2] += g == 2;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) members[g] += __shfl_xor(members[g], off, 64);
+  for (int g = 0; g < 3; ++g) {
+    float bestv = 0.f;
+    int bestj = 0;
+    if (members[g] > 0) {  // wave-uniform
+      float acc[kMaxCand];
+#pragma unroll
+      for (int j = 0; j < kMaxCand; ++j) acc[j] = 0.f;
+      int nc = 0;
+      for (int32_t m = b + lane; m < e; m += 64) {
+        const int32_t cls = sem_preds[m];
+        const float gv[3] = {gt[m * 3], gt[m * 3 + 1], gt[m * 3 + 2]};
+        const bool valid = (int64_t)cls == sem_labels[m] && (gv[0] != 0.f || gv[1] != 0.f || gv[2] != 0.f);
+        if (!valid) continue;
+        const int t = (int)sym_of_class[cls];
+        if (info.group[t] != g) continue;
+        const float* row = logits + (int64_t)m * n_cls3 + 3 * (cls - 1);
+        const float pv[3] = {row[0], row[1], row[2]};
+        const int first = info.first[t];
+        nc = info.count[t];
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j) {
+          if (j < nc) {
+            const float d2 = npcs_cost(pv, gv, mats + (first + j) * 9, nullptr);
+            acc[j] = __fadd_rn(acc[j], d2 <= 0.01f ? __fmul_rn(5.f, d2) : __fsub_rn(sqrtf(d2), 0.05f));
+          }
+        }
+      }
+      // candidates per group are the same for every type of the group (2 / 12 / 24): lanes without members report 0
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) nc = max(nc, __shfl_xor(nc, off, 64));
+      bestv = INFINITY;
+#pragma unroll
+      for (int j = 0; j < kMaxCand; ++j) {
+        float s = acc[j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s = __fadd_rn(s, __shfl_xor(s, off, 64));
+        const float mean = __fdiv_rn(s, (float)members[g]);
+        if (j < nc && mean < bestv) { bestv = mean; bestj = j; }  // first minimum, like torch.min
+      }
+    }
+    if (lane == 0) {
+      best[p * 3 + g] = bestv;
+      arg[p * 3 + g] = bestj;
+      cnt[p * 3 + g] = members[g];
+    }
+  }
+}
+
+// loss = sum_g (sum over proposals with members of best) / (their number); stats = {n_has[3]} for the backward
+__global__ __launch_bounds__(1024) void npcs_loss_finish_kernel(const float* __restrict__ best, const int32_t* __restrict__ cnt,
+                                                                int64_t P, float* __restrict__ loss, float* __restrict__ n_has) {
+  __shared__ double ssum[3][1024];
+  __shared__ int scnt[3][1024];
+  double s[3] = {0.0, 0.0, 0.0};
+  int c[3] = {0, 0, 0};
+  const int64_t per = (P + 1023) / 1024;  // contiguous chunk per thread: fixed order
+  for (int64_t p = threadIdx.x * per; p < (threadIdx.x + 1) * per && p < P; ++p)
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      if (cnt[p * 3 + g] > 0) { s[g] += (double)best[p * 3 + g]; c[g] += 1; }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) ssum[g][threadIdx.x] = s[g], scnt[g][threadIdx.x] = c[g];
+  __syncthreads();
+  for (int stride = 512; stride >= 1; stride >>= 1) {
+    if ((int)threadIdx.x < stride)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        ssum[g][threadIdx.x] += ssum[g][threadIdx.x + stride];
+        scnt[g][threadIdx.x] += scnt[g][threadIdx.x + stride];
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float total = 0.f;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      n_has[g] = (float)scnt[g][0];
+      if (scnt[g][0] > 0) total += (float)(ssum[g][0] / (double)scnt[g][0]);
+    }
+    loss[0] = total;
+  }
+}
+
+__global__ __launch_bounds__(256) void npcs_loss_bwd_kernel(
+    const float* __restrict__ logits, int n_cls3, const float* __restrict__ gt, const int32_t* __restrict__ sem_preds,
+    const int64_t* __restrict__ sem_labels, const int64_t* __restrict__ proposal_indices, int64_t M,
+    const int64_t* __restrict__ sym_of_class, const float* __restrict__ mats, NpcsTypeInfo info,
+    const int32_t* __restrict__ arg, const int32_t* __restrict__ cnt, const float* __restrict__ n_has,
+    const float* __restrict__ grad_loss, float* __restrict__ d_logits) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float* drow = d_logits + m * n_cls3;
+  for (int c = 0; c < n_cls3; ++c) drow[c] = 0.f;
+  const int32_t cls = sem_preds[m];
+  const float gv[3] = {gt[m * 3], gt[m * 3 + 1], gt[m * 3 + 2]};
+  const bool valid = (int64_t)cls == sem_labels[m] && (gv[0] != 0.f || gv[1] != 0.f || gv[2] != 0.f);
+  if (!valid) return;
+  const int t = (int)sym_of_class[cls];
+  const int g = info.group[t];
+  const int64_t p = proposal_indices[m];
+  const float* row = logits + m * n_cls3 + 3 * (cls - 1);
+  const float pv[3] = {row[0], row[1], row[2]};
+  float r[3];
+  const float d2 = npcs_cost(pv, gv, mats + (info.first[t] + arg[p * 3 + g]) * 9, r);
+  const float coef = grad_loss[0] / (n_has[g] * (float)cnt[p * 3 + g]);
+  const float k = d2 <= 0.01f ? 10.f : 1.f / sqrtf(d2);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) drow[3 * (cls - 1) + c] = coef * k * r[c];
+}
+
+}  // namespace
+
+// sym_of_class [n_classes] i64 (symmetry type of every class, gapartnet.yaml symmetry_indices); mats [n_mats,3,3] f32 =
+// the candidate rotations of all types back to back; type_first / type_count / type_group [n_types] (host).
+// scratch [P * 9 + 4] floats (best [P,3] | arg [P,3] i32 | cnt [P,3] i32 | n_has [3]) is kept by the caller for the backward.
+extern "C" int gpn_npcs_loss_fwd(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                                 const int64_t* sem_labels, const int32_t* proposal_offsets, int64_t P,
+                                 const int64_t* sym_of_class, const float* mats, const int32_t* type_first,
+                                 const int32_t* type_count, const int32_t* type_group, int n_types, float* loss, void* scratch,
+                                 gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(P >= 1 && n_cls3 >= 3 && n_types >= 1 && n_types <= 8);
+  GPN_CHECK_ARG(logits && gt_npcs && sem_preds && sem_labels && proposal_offsets && sym_of_class && mats && loss && scratch);
+  NpcsTypeInfo info;
+  info.n_types = n_types;
+  for (int t = 0; t < n_types; ++t) {
+    GPN_CHECK_ARG(type_count[t] >= 1 && type_count[t] <= kMaxCand && type_group[t] >= 0 && type_group[t] < 3);
+    info.first[t] = type_first[t], info.count[t] = type_count[t], info.group[t] = type_group[t];
+  }
+  float* best = static_cast<float*>(scratch);
+  int32_t* arg = reinterpret_cast<int32_t*>(best + P * 3);
+  int32_t* cnt = arg + P * 3;
+  float* n_has = reinterpret_cast<float*>(cnt + P * 3);
+  hipLaunchKernelGGL(npcs_loss_proposal_kernel, dim3((unsigned)gpn::cdiv(P, 4)), dim3(256), 0, stream, logits, n_cls3, gt_npcs,
+                     sem_preds, sem_labels, proposal_offsets, P, sym_of_class, mats, info, best, arg, cnt);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(npcs_loss_finish_kernel, dim3(1), dim3(1024), 0, stream, best, cnt, P, loss, n_has);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_npcs_loss_bwd(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                                 const int64_t* sem_labels, const int64_t* proposal_indices, int64_t M, int64_t P,
+                                 const int64_t* sym_of_class, const float* mats, const int32_t* type_first,
+                                 const int32_t* type_count, const int32_t* type_group, int n_types, const void* scratch,
+                                 const float* grad_loss, float* d_logits, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(M >= 0 && P >= 1 && n_types >= 1 && n_types <= 8);
+  if (M == 0) return GPN_OK;
+  GPN_CHECK_ARG(logits && gt_npcs && sem_preds && sem_labels && proposal_indices && scratch && grad_loss && d_logits);
+  NpcsTypeInfo info;
+  info.n_types = n_types;
+  for (int t = 0; t < n_types; ++t) info.first[t] = type_first[t], info.count[t] = type_count[t], info.group[t] = type_group[t];
+  const float* best = static_cast<const float*>(scratch);
+  const int32_t* arg = reinterpret_cast<const int32_t*>(best + P * 3);
+  const int32_t* cnt = arg + P * 3;
+  const float* n_has = reinterpret_cast<const float*>(cnt + P * 3);
+  hipLaunchKernelGGL(npcs_loss_bwd_kernel, dim3((unsigned)gpn::cdiv(M, 256)), dim3(256), 0, stream, logits, n_cls3, gt_npcs,
+                     sem_preds, sem_labels, proposal_indices, M, sym_of_class, mats, info, arg, cnt, n_has, grad_loss, d_logits);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}

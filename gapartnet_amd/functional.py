@@ -222,6 +222,31 @@ def proposal_voxel_mean(feats, built) -> torch.Tensor:
                                       built["member_slot"], built["pc_voxel_id"], built["V"])
 
 
+class _NpcsLossFn(torch.autograd.Function):
+    """symmetry-aware NPCS loss of all proposals (model.py:398-462): two launches forward, one backward"""
+
+    @staticmethod
+    def forward(ctx, logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, proposal_indices, sym):
+        ops = backend.raw()
+        logits, gt_npcs = logits.contiguous(), gt_npcs.contiguous()
+        sem_preds, sem_labels = sem_preds.to(torch.int32).contiguous(), sem_labels.to(torch.int64).contiguous()
+        loss, scratch = ops.npcs_loss_fwd(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, sym)
+        ctx.save_for_backward(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, scratch)
+        ctx.sym, ctx.P = sym, proposal_offsets.shape[0] - 1
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        ops = backend.raw()
+        logits, gt_npcs, sem_preds, sem_labels, proposal_indices, scratch = ctx.saved_tensors
+        d_logits = ops.npcs_loss_bwd(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, ctx.P, ctx.sym, scratch, grad_loss)
+        return d_logits, None, None, None, None, None, None
+
+
+def npcs_loss(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, proposal_indices, sym) -> torch.Tensor:
+    return _NpcsLossFn.apply(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, proposal_indices, sym)
+
+
 class _PointLossesFn(torch.autograd.Function):
     """kernel family P: focal + dice + offset-distance + offset-direction losses of all points in one pass"""
 

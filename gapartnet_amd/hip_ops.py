@@ -697,3 +697,37 @@ def proposals_voxel_mean_bwd(dout, member_slot, pc_voxel_id, voxel_point_start, 
     check(_C.lib().gpn_proposals_voxel_mean_bwd(ptr(dout), ptr(member_slot), ptr(pc_voxel_id), ptr(voxel_point_start), i64(N),
                                                 i32(dout.shape[1]), ptr(dfeats), _stream()), "gpn_proposals_voxel_mean_bwd")
     return dfeats
+
+
+# ---------------------------------------------------------------------------------------------------- NPCS loss
+def _npcs_args(sym):
+    i32a = lambda v: (_C.ctypes.c_int32 * len(v))(*v)  # noqa: E731
+    return i32a(sym["first"]), i32a(sym["count"]), i32a(sym["group"]), i32(len(sym["first"]))
+
+
+def npcs_loss_fwd(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, sym):
+    """-> (loss [1] f32, scratch for the backward).  ``sym`` = dict(sym_of_class i64 [classes], mats f32 [n,3,3] (device),
+    first / count / group: python lists per symmetry type)."""
+    dev = _dev(logits, gt_npcs)
+    logits, gt_npcs = _c(logits, torch.float32), _c(gt_npcs, torch.float32)
+    sem_preds, sem_labels = _c(sem_preds, torch.int32), _c(sem_labels, torch.int64)
+    proposal_offsets = _c(proposal_offsets, torch.int32)
+    P = proposal_offsets.shape[0] - 1
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    scratch = torch.empty((9 * P + 4,), dtype=torch.float32, device=dev)
+    first, count, group, n = _npcs_args(sym)
+    check(_C.lib().gpn_npcs_loss_fwd(ptr(logits), i32(logits.shape[1]), ptr(gt_npcs), ptr(sem_preds), ptr(sem_labels),
+                                     ptr(proposal_offsets), i64(P), ptr(sym["sym_of_class"]), ptr(sym["mats"]), first, count,
+                                     group, n, ptr(loss), ptr(scratch), _stream()), "gpn_npcs_loss_fwd")
+    return loss, scratch
+
+
+def npcs_loss_bwd(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, P, sym, scratch, grad_loss):
+    dev = _dev(logits)
+    d_logits = torch.empty_like(logits)
+    first, count, group, n = _npcs_args(sym)
+    check(_C.lib().gpn_npcs_loss_bwd(ptr(logits), i32(logits.shape[1]), ptr(gt_npcs), ptr(sem_preds), ptr(sem_labels),
+                                     ptr(_c(proposal_indices, torch.int64)), i64(logits.shape[0]), i64(P), ptr(sym["sym_of_class"]),
+                                     ptr(sym["mats"]), first, count, group, n, ptr(scratch),
+                                     ptr(_c(grad_loss.reshape(1), torch.float32)), ptr(d_logits), _stream()), "gpn_npcs_loss_bwd")
+    return d_logits

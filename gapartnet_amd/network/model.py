@@ -91,6 +91,7 @@ class GAPartNet(LightningModule):
         self.symmetry_indices = torch.as_tensor(symmetry_indices, dtype=torch.int64)
         self.voxel_size = [float(v) for v in voxel_size]
         self.revoxelize_jitter = None  # tests inject the two uniform 3-vectors of segmented_voxelize here
+        self.record_npcs_preds = False  # True: keep proposals.npcs_preds / gt_npcs in training steps too (costs a host read)
         self.use_fused_proposals = True  # csrc/proposals.hip on the GPU; False = the torch formulation of the same stage
 
         self.ball_query_radius = instance_seg_cfg["ball_query_radius"]
@@ -313,24 +314,50 @@ class GAPartNet(LightningModule):
         target (model.py:398-462); the per-class 3-vector is selected by the predicted class."""
         sem_preds, sem_labels = proposals.sem_preds, proposals.sem_labels
         valid = (sem_preds == sem_labels) & (gt_npcs != 0).any(dim=-1)
-
-        valid_idx = torch.nonzero(valid).squeeze(1)
-        npcs_logits, gt_npcs = npcs_logits[valid_idx], gt_npcs[valid_idx]
-        sem_preds = sem_preds[valid_idx].long()
-        proposal_indices = proposals.proposal_indices[valid_idx]
-
-        per_class = npcs_logits.reshape(npcs_logits.shape[0], npcs_logits.shape[1] // 3, 3)  # valid for 0 rows too
-        npcs_preds = per_class.gather(1, (sem_preds - 1)[:, None, None].expand(-1, 1, 3)).squeeze(1)
-
-        proposals.npcs_preds = npcs_preds.detach()
-        proposals.gt_npcs = gt_npcs
+        ops = backend.raw()
+        fused = npcs_logits.is_cuda and hasattr(ops, "npcs_loss_fwd") and npcs_logits.shape[0] > 0
         proposals.npcs_valid_mask = valid
+        valid_idx = None
+        if fused and self.training and not self.record_npcs_preds:
+            # nobody reads the selected predictions during training: skip the compaction (a host read) altogether
+            proposals.npcs_preds, proposals.gt_npcs = None, None
+        else:
+            valid_idx = torch.nonzero(valid).squeeze(1)
+            per_class = npcs_logits[valid_idx].reshape(valid_idx.shape[0], npcs_logits.shape[1] // 3, 3)
+            cls = sem_preds[valid_idx].long()
+            proposals.npcs_preds = per_class.gather(1, (cls - 1)[:, None, None].expand(-1, 1, 3)).squeeze(1).detach()
+            proposals.gt_npcs = gt_npcs[valid_idx]
 
         dev = sem_preds.device
         self.symmetry_indices = self.symmetry_indices.to(dev)
         self.symmetry_matrix_1 = self.symmetry_matrix_1.to(dev)
         self.symmetry_matrix_2 = self.symmetry_matrix_2.to(dev)
         self.symmetry_matrix_3 = self.symmetry_matrix_3.to(dev)
+        if fused:
+            # the whole loss in two launches (csrc/losses.hip); the torch formulation below is what runs over other operator
+            # backends and what the kernel is tested against
+            sym = getattr(self, "_npcs_sym", None)
+            if sym is None or sym["mats"].device != dev:
+                tables = (self.symmetry_matrix_1, self.symmetry_matrix_2, self.symmetry_matrix_3)
+                first, count, group, mats = [], [], [], []
+                for g, table in enumerate(tables):
+                    for t in range(table.shape[0]):
+                        first.append(sum(m.shape[0] for m in mats))
+                        count.append(int(table.shape[1]))
+                        group.append(g)
+                        mats.append(table[t].reshape(-1, 3, 3))
+                sym = dict(sym_of_class=self.symmetry_indices.to(torch.int64).contiguous(),
+                           mats=torch.cat(mats).to(device=dev, dtype=torch.float32).contiguous(), first=first, count=count,
+                           group=group)
+                self._npcs_sym = sym
+            return GF.npcs_loss(npcs_logits, gt_npcs, sem_preds, sem_labels, proposals.proposal_offsets,
+                                proposals.proposal_indices, sym)
+
+        npcs_logits, gt_npcs = npcs_logits[valid_idx], gt_npcs[valid_idx]
+        sem_preds = sem_preds[valid_idx].long()
+        proposal_indices = proposals.proposal_indices[valid_idx]
+        per_class = npcs_logits.reshape(npcs_logits.shape[0], npcs_logits.shape[1] // 3, 3)  # valid for 0 rows too
+        npcs_preds = per_class.gather(1, (sem_preds - 1)[:, None, None].expand(-1, 1, 3)).squeeze(1)
         sym = self.symmetry_indices[sem_preds]
 
         # the reference evaluates compute_npcs_loss once per symmetry group (sym < 3, == 3, == 4) on boolean-mask

@@ -18,13 +18,24 @@ import torch.nn as nn
 from . import pointnet2_utils as P
 
 
+class PointwiseConv2d(nn.Conv2d):
+    """1x1 Conv2d (same parameters / state_dict keys as nn.Conv2d) evaluated as a channel contraction (a library GEMM)
+    instead of through the convolution library: MIOpen's implicit-GEMM backward-data kernel for this shape
+    (igemm_bwd_gtcx35_nhwc_fp32 ...) faulted on the MI355X image depending on which solver its search picked
+    (rocgdb: memory violation inside that kernel, in the middle of the GPU test suite)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = torch.einsum("oi,bihw->bohw", self.weight[:, :, 0, 0], x)
+        return y if self.bias is None else y + self.bias[None, :, None, None]
+
+
 def shared_mlp(spec: Sequence[int], bn: bool = True, instance_norm: bool = False) -> nn.Sequential:
     """per-point MLP as a stack of 1x1 Conv2d (+BatchNorm2d | InstanceNorm2d) + ReLU, children named like the reference's
     ``SharedMLP`` (pytorch_utils.py:5-32): layer<i> -> conv, bn -> bn, activation"""
     net = nn.Sequential()
     for i, (cin, cout) in enumerate(zip(spec[:-1], spec[1:])):
         block = nn.Sequential()
-        conv = nn.Conv2d(cin, cout, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), bias=not bn)
+        conv = PointwiseConv2d(cin, cout, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), bias=not bn)
         nn.init.kaiming_normal_(conv.weight)
         if conv.bias is not None:
             nn.init.constant_(conv.bias, 0)

@@ -390,6 +390,22 @@ int gpn_point_losses_bwd(const float* logits, const int64_t* labels, const float
                          const int32_t* instance_labels, int64_t M, int C, int64_t ignore_index, const void* stats,
                          const float* grad_losses, float* d_logits, float* d_offsets, gpn_stream_t stream);
 
+/* NPCS loss of all proposals in two launches (+ one backward): network/model.py:398-462 with compute_npcs_loss
+ * (network/grouping_utils.py:14-43).  logits [M, n_cls3 = 3 (classes - 1)], gt_npcs [M,3], sem_preds [M] i32 (one class per
+ * proposal point), sem_labels [M] i64, proposal_offsets [P+1] i32 / proposal_indices [M] i64 (CSR of the proposals),
+ * sym_of_class [classes] i64 (device), mats [n_mats,3,3] f32 (device): candidate rotations of every symmetry type back to
+ * back; type_first / type_count (<= 24) / type_group (0..2) [n_types <= 8] on the HOST.  loss [1] f32 (device);
+ * scratch: (9 P + 4) * 4 bytes kept by the caller between forward and backward.  d_logits [M, n_cls3] fully written. */
+int gpn_npcs_loss_fwd(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                      const int64_t* sem_labels, const int32_t* proposal_offsets, int64_t P, const int64_t* sym_of_class,
+                      const float* mats, const int32_t* type_first, const int32_t* type_count, const int32_t* type_group,
+                      int n_types, float* loss, void* scratch, gpn_stream_t stream);
+int gpn_npcs_loss_bwd(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                      const int64_t* sem_labels, const int64_t* proposal_indices, int64_t M, int64_t P,
+                      const int64_t* sym_of_class, const float* mats, const int32_t* type_first, const int32_t* type_count,
+                      const int32_t* type_group, int n_types, const void* scratch, const float* grad_loss, float* d_logits,
+                      gpn_stream_t stream);
+
 /* ================================================================================================
  * PR — the proposal stage of a step in one call: GAPartNet.proposal_clustering_and_revoxelize (network/model.py:228-346)
  * with cluster_proposals (network/grouping_utils.py:108-140) and the geometry of segmented_voxelize (:47-104).

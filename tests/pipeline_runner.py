@@ -97,6 +97,7 @@ def _record_forward(prefix, tap, out):
 
 def run_train_step(gold, device, per_scene_voxelisation=True):
     model = build_model(device).train()
+    model.record_npcs_preds = True  # the fixture pins the selected NPCS predictions of the training step as well
     model._current_epoch = 10
     logged = {}
     model._log_sink = lambda name, value, bs, sync: logged.setdefault(name, []).append(float(value))

@@ -76,3 +76,48 @@ def test_fused_stage_without_proposals(cuda):
     model.ball_query_radius = 1e-4
     none = _stage(model, batch, feats, sem, offsets, True)
     assert none[3] is None
+
+
+@pytest.mark.parametrize("n_props,seed", [(1, 0), (37, 1), (600, 2)])
+def test_fused_npcs_loss_equals_the_torch_formulation(cuda, n_props, seed):
+    """csrc/losses.hip gpn_npcs_loss_* against compute_npcs_loss_grouped (itself pinned to the reference's per-group
+    compute_npcs_loss by tests/golden/npcs_loss.npz): value and d logits, all five symmetry types, proposals without any
+    valid point, points whose class is wrong / whose target is zero"""
+    from gapartnet_amd.structure.instances import Instances
+    g = torch.Generator().manual_seed(seed)
+    sizes = torch.randint(5, 200, (n_props,), generator=g)
+    M = int(sizes.sum())
+    offsets = torch.zeros(n_props + 1, dtype=torch.int32)
+    offsets[1:] = sizes.cumsum(0)
+    prop = torch.repeat_interleave(torch.arange(n_props), sizes)
+    cls_of_prop = torch.randint(1, 10, (n_props,), generator=g)
+    sem_preds = cls_of_prop[prop].to(torch.int32)
+    sem_labels = sem_preds.long().clone()
+    wrong = torch.rand(M, generator=g) < 0.2
+    sem_labels[wrong] = (sem_labels[wrong] % 9) + 1
+    gt = torch.rand(M, 3, generator=g) - 0.5
+    gt[torch.rand(M, generator=g) < 0.15] = 0.0
+    if n_props > 5:  # a proposal with no valid point at all
+        gt[offsets[3]:offsets[4]] = 0.0
+    logits = torch.randn(M, 27, generator=g)
+    results = []
+    for fused in (False, True):
+        model = make_model((0, 0), channels=[16, 32]).to(cuda).train()
+        x = logits.clone().to(cuda).requires_grad_(True)
+        props = Instances(sem_preds=sem_preds.to(cuda), sem_labels=sem_labels.to(cuda), proposal_offsets=offsets.to(cuda),
+                          proposal_indices=prop.to(cuda))
+        if not fused:
+            from gapartnet_amd import hip_ops
+            saved = hip_ops.npcs_loss_fwd
+            del hip_ops.npcs_loss_fwd
+        try:
+            loss = model.loss_proposal_npcs(x, gt.to(cuda), props)
+        finally:
+            if not fused:
+                hip_ops.npcs_loss_fwd = saved
+        (loss * 1.7).backward()
+        results.append((float(loss), x.grad.cpu(), props.npcs_valid_mask.cpu()))
+    (l0, g0, v0), (l1, g1, v1) = results
+    assert torch.equal(v0, v1)
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)), (l0, l1)
+    assert torch.allclose(g0, g1, rtol=1e-4, atol=1e-7), float((g0 - g1).abs().max())
