@@ -14,10 +14,19 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o t
 f=$(find /tmp/p1 -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" "$O/kernel_stats.csv"; python "$R/tools/gpu_categories.py" "$f" 21 > "$O/gpu_time_by_category.txt" 2>&1 < /dev/null; fi
 f=$(find /tmp/p1 -name "*kernel_trace.csv" 2>/dev/null | head -1)
-if [ -n "$f" ]; then python "$R/tools/summarize_trace.py" "$f" "$O/conv_kernels_by_grid.csv" "spconv,wgrad,bn_,ccl_" > /dev/null 2>&1 < /dev/null; fi
+if [ -n "$f" ]; then python "$R/tools/summarize_trace.py" "$f" "$O/conv_kernels_by_grid.csv" "spconv,wgrad,bn_,ccl_" > /dev/null 2>&1 < /dev/null; python "$R/tools/timeline.py" "$f" "$O/timeline.txt" 0.12 > /dev/null 2>&1 < /dev/null; fi
+for cfg in "--schedule 5,10" "--points 50000 --batch 4" "--batch 32"; do
+  tag=$(echo "$cfg" | tr -d ' -' | tr ',' '_')
+  timeout 200 python "$R/bench.py" $cfg --no-cpu-baseline > "$O/bench_$tag.json" 2> /dev/null < /dev/null
+done
+timeout 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/p_sq -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+f=$(find /tmp/p_sq -name "*counter_collection.csv" 2>/dev/null | head -1)
+if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_sq.txt" 2>&1 < /dev/null; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
   f=$(find /tmp/p_$c -name "*counter_collection.csv" 2>/dev/null | head -1)
   if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_$c.txt" 2>&1 < /dev/null; fi
 done
+f1=$O/pmc_FETCH_SIZE.txt; f2=$O/pmc_WRITE_SIZE.txt
+if [ -s "$f1" ] && [ -s "$f2" ]; then (cd "$R" && python tools/pmc_traffic.py "$f1" "$f2" "$O/traffic.json" spconv_fwd > /dev/null 2>&1); fi
 ls -la "$O"
