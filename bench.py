@@ -122,6 +122,26 @@ def roofline_from_profile(device):
     return out
 
 
+def usable_cores() -> int:
+    """host cores this process may actually use: the smaller of the scheduler affinity and the cgroup CPU quota (the GPU
+    boxes report 256 logical CPUs under a 16-CPU quota; 256 threads there run ~100x slower than 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                quota, period = int(fq.read()), int(fp.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def _cpu_steps(args, n_scenes, threads, timed):
     """median seconds of `timed` full train steps (after one warm-up step) through the CPU oracle with `threads` threads"""
     import statistics
@@ -152,10 +172,11 @@ def cpu_baseline(args):
     path cannot be installed here) on a bounded sample: one warm-up step, then the median of 3 timed steps - with one
     thread, and with every host core (OpenMP over the rule pairs of a tap in the conv loops and over queries in the ball
     query, torch's own threads for the glue).  The reported value is the all-cores run."""
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     single_n = 1
     t1, spent1 = _cpu_steps(args, single_n, 1, 3)
     tn, spentn = _cpu_steps(args, args.cpu_scenes, cores, 3)
+    torch.set_num_threads(cores)
     return dict(value=args.cpu_scenes / tn, unit="point-clouds/sec", cores=cores, kind="port",
                 single_thread=dict(value=single_n / t1, cores=1, scenes_per_step=single_n, median_step_s=t1),
                 sample=f"median of 3 full train steps (fwd+bwd+Adam) after 1 warm-up, {args.cpu_scenes} synthetic scene(s) x "
@@ -166,6 +187,7 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    torch.set_num_threads(usable_cores())  # torch sizes its CPU pool from the logical CPU count, not from the cgroup quota
     from gapartnet_amd.trainer import init_distributed
     rank, local_rank, world, device = init_distributed("cuda")
     assert device.type == "cuda", "bench.py needs a GPU (the product has no CPU path)"

@@ -1,26 +1,24 @@
 // spconv_fwd.hip — the fused gather-MFMA sparse convolution (forward and dgrad launches) for gfx950.
 //
-// Output-stationary, accumulators in registers, no scatter.  A wave owns 16 destination rows (the M dimension of
-// v_mfma_f32_16x16x4_f32) and NTW 16-wide output-column tiles; MFMA row i of every tap IS destination row i of the tile,
-// so the fp32 accumulators stay in registers for the whole kernel and each output row is written once.  For tap k the A
-// operand row i is the gathered source row nbr[k][row0 + i] (zero where the neighbour does not exist), read straight
-// from the tap-major neighbour table the rulebook builder produces — one coalesced 64-byte index read per wave and tap,
-// no pair lists, no atomics, no LDS traffic for the accumulation.  (Block-compacted pair lists with an LDS scatter
-// measured 3-5x slower here: with 16..112 channels the layers are bound by instruction issue and dependent-load
-// latency, not by the MFMA work that zero rows waste.)
+// Output-stationary, accumulators in registers, no scatter: a wave owns 16 destination rows (the M dimension of
+// v_mfma_f32_16x16x4_f32); MFMA row i of every tap IS destination row i of the tile, so the fp32 accumulators stay in
+// registers for the whole kernel and each output row is written once.  For tap k the A operand row i is the gathered
+// source row nbr[k][row0 + i] (zero where the neighbour does not exist), read straight from the tap-major neighbour table
+// the rulebook builder produces - no pair lists, no atomics.  Lane (i = l&15, g = l>>4) loads channels [16cb+4g, 16cb+4g+4)
+// of row i's neighbour with one 16-byte load (whole 64-byte pieces of each gathered row); the 4 channels feed 4
+// consecutive MFMA steps and the matching K-permutation is baked into the packed weights.  The fp32 MFMA is exact and
+// the summation order is fixed, so results are deterministic.
 //
-// Workgroup = WPB waves (4..16) walking stages (tap k, chunk of CW 16-channel blocks) in lock-step, so a stage's weight
-// slab (CW x NTW pre-packed 1 KiB MFMA-B fragments) comes from L2 once per workgroup and is shared through a
-// double-buffered LDS slab (conflict-free ds_read_b128), one barrier per stage.  Global loads are software-pipelined
-// with compile-time ring slots (stage loop unrolled by 2D, stage count padded with empty stages):
-//     neighbour indices 2D stages ahead, gathered rows and weight slabs D stages ahead.
-// Every load is unconditional and branch-free (clamped indices + selects) so that the compiler can count them and emit
-// partial s_waitcnt vmcnt(N); with lane-divergent guards it falls back to vmcnt(0) and every stage pays a full memory
-// latency.  Lane (i = l&15, g = l>>4) loads channels [16cb+4g, 16cb+4g+4) of row i's neighbour with one 16-byte load
-// (whole 64-byte pieces of each gathered row); the 4 channels feed 4 consecutive MFMA steps and the matching
-// K-permutation is baked into the packed weights.  The fp32 MFMA is exact (== an fmaf chain) and the summation order
-// is fixed (tap-major), so results are deterministic.  Small layers split their taps over grid.z into partial outputs
-// that a fixed-order kernel sums.
+// Two kernels:
+//  * spconv_fwd_direct_kernel (below, second half of the file) - every k = 27 / k = 8 layer with >= 16 row tiles, i.e.
+//    ~95 % of the flops: one wave per (16-row tile, 16-column tile), weight fragments straight from L2, no LDS, no
+//    barrier, no partial outputs.  It replaced round 1's persistent LDS-slab streaming kernel (L0 / L1 / L2 launches
+//    32 / 72 / 74 us -> 27 / 56 / 42 us; that kernel, its tile-order rulebook option and its input-block partial sums are gone).
+//  * spconv_fwd_kernel - the k = 1 layers and the deepest levels (< 16 tiles): WPB waves (4..16) walk stages (tap k, chunk of
+//    CW 16-channel blocks) in lock-step, a stage's weight slab (CW x NTW 1 KiB MFMA-B fragments) goes through a
+//    double-buffered LDS slab, one barrier per stage; loads are software-pipelined with compile-time ring slots and are
+//    unconditional / branch-free so that the compiler emits counted s_waitcnt vmcnt(N); tiny layers split their taps over
+//    grid.z into partial outputs that a fixed-order kernel sums.
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -178,190 +176,6 @@ __global__ void spconv_fwd_kernel(const float* __restrict__ in, const float* __r
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Persistent tile-streaming variant for the large levels (K = 27 or 8, >= 1024 tiles, no tap split).
-// The lock-step kernel above pays a workgroup start-up (index column + slab round trips before the first MFMA) once
-// per 16-row tile and one barrier per stage, and its 1024-thread workgroups leave only two slots per CU to hide that
-// in: on the two largest levels it ran at 3.5-4.6x its MFMA time.  Here a workgroup
-// (8 waves, one or two per CU) is persistent: it stages the slab of an input block once and every wave streams
-// through many tiles with the rings carried ACROSS tile boundaries - while tile i is contracted, the index column
-// of tile i+1 refills the slots tile i has consumed and its first gathers are already in flight, so a wave never
-// restarts cold.  For cin > 16 the input blocks are the outer loop (slab staged CB times per workgroup, no barrier
-// inside a pass); block 0 writes the partial output rows and later blocks add to them (fixed order: deterministic).
-// Tiles are dealt so that each XCD owns a contiguous range of rows and neighbouring tiles run at the same time on
-// the same XCD (they gather largely the same source rows: L2 hits).
-template <int NTW, int KT, int D, int CW>  // CW = 16-channel input blocks contracted per pass (slab = KT x CW x NTW KiB)
-__global__ __launch_bounds__(512) void spconv_fwd_stream_kernel(const float* __restrict__ in,
-                                                                const float* __restrict__ packed,
-                                                                const int32_t* __restrict__ nbr, int64_t n_dst, int cin,
-                                                                int nt_total, int64_t tiles, int cb_per_split, const int32_t* __restrict__ perm,
-                                                                float* __restrict__ out_base) {
-  static_assert(KT % D == 0, "ring slots are compile-time: the gather distance must divide the tap count");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x4* slab = reinterpret_cast<f32x4*>(smem);  // [KT][CW][NTW][64 lanes]
-  constexpr int WPB = 8;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int i16 = lane & 15, g = lane >> 4;
-
-  // tile ownership: XCD x (workgroup ids go round-robin over the 8 XCDs) owns tiles [tile_lo, tile_hi); inside it
-  // wave slot j takes tiles tile_lo + j, + waves_per_xcd, ...
-  const int xcd = blockIdx.x & 7;
-  const int waves_per_xcd = (gridDim.x >> 3) * WPB;
-  const int slot = (blockIdx.x >> 3) * WPB + wave;
-  const int64_t tiles_per_xcd = (tiles + 7) >> 3;
-  const int64_t tile_lo = xcd * tiles_per_xcd;
-  const int64_t tile_hi = tile_lo + tiles_per_xcd < tiles ? tile_lo + tiles_per_xcd : tiles;
-  const int64_t first = tile_lo + slot;
-  const int m = first < tile_hi ? (int)((tile_hi - first + waves_per_xcd - 1) / waves_per_xcd) : 0;
-
-  const int nt0 = blockIdx.y * NTW;
-  const int ntw = (nt_total - nt0 < NTW) ? (nt_total - nt0) : NTW;
-  const int cout = nt_total * 16;
-  const int CB = cin >> 4;
-  const f32x4* __restrict__ pw = reinterpret_cast<const f32x4*>(packed);
-  // mid-size levels (about one tile per wave) split the input blocks over grid.z: each slice is a single pass writing
-  // its own partial output (summed afterwards in slice order) instead of CB sequential passes with their start-ups
-  const int cb_lo = blockIdx.z * cb_per_split;
-  const int cb_hi = (cb_lo + cb_per_split < CB) ? (cb_lo + cb_per_split) : CB;
-  float* __restrict__ out = out_base + (int64_t)blockIdx.z * n_dst * cout;
-
-  // Gathers and index reads are buffer loads: wave-uniform descriptor + 32-bit per-lane byte offset (one VGPR per
-  // pending load, no per-lane 64-bit arithmetic), and an absent neighbour becomes an out-of-range offset, which the
-  // hardware answers with zeros WITHOUT touching memory.  (The host guarantees every byte offset < 2^31.)
-  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t nbr_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(nbr), 0, 0x7fffffff, 0x00020000);
-  const uint32_t col_bytes = (uint32_t)n_dst * 4u;  // one tap's column of the neighbour table
-  auto clamp_row = [&](int64_t tile) -> uint32_t {
-    const int64_t r = tile * 16 + i16;
-    return (uint32_t)(r < n_dst ? r : n_dst - 1);
-  };
-  auto load_idx = [&](int u, uint32_t row) -> int32_t {
-    return __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(row * 4u), (int)(u * col_bytes), 0));
-  };
-  // the CW 64-byte pieces of one gathered row; absent neighbours and rows past the end of the tensor read as zeros
-  // (out-of-range offset), so the MFMA operands need no select - a VALU op between two MFMAs of a dependent chain
-  // costs ~40 cycles on this core
-  auto load_a = [&](int32_t idx, bool row_valid, int cb, f32x4 (&a)[CW]) {
-    const uint32_t off = (idx < 0 || !row_valid) ? 0x80000000u : ((uint32_t)idx * (uint32_t)cin + 4u * (uint32_t)g) * 4u;
-#pragma unroll
-    for (int c = 0; c < CW; ++c)
-      a[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, (cb + c) * 64, 0));
-  };
-
-  for (int cb = cb_lo; cb < cb_hi; cb += CW) {  // CW divides CB and cb_per_split (host)
-    if (cb > cb_lo) __syncthreads();  // every wave has finished its pass over the previous blocks' slab
-    for (int q = tid; q < KT * CW * NTW * 64; q += WPB * 64) {
-      const int t = q / (CW * NTW * 64);
-      const int rem = q - t * (CW * NTW * 64);
-      const int c = rem / (NTW * 64);
-      int nt = (rem - c * (NTW * 64)) >> 6;
-      nt = nt < ntw ? nt : 0;
-      slab[q] = pw[((int64_t)(t * CB + cb + c) * nt_total + nt0 + nt) * 64 + (rem & 63)];
-    }
-    // rings of the wave's first tile (their round trip overlaps the slab's)
-    int32_t ireg[KT];
-    f32x4 areg[D][CW];
-    if (m > 0) {
-      const uint32_t rc = clamp_row(first);
-#pragma unroll
-      for (int u = 0; u < KT; ++u) ireg[u] = load_idx(u, rc);
-      const bool ok_first = first * 16 + i16 < n_dst;
-#pragma unroll
-      for (int u = 0; u < D; ++u) load_a(ireg[u], ok_first, cb, areg[u]);
-    }
-    __syncthreads();
-
-    for (int i = 0; i < m; ++i) {
-      const int64_t cur = first + (int64_t)i * waves_per_xcd;
-      const int64_t nxt = i + 1 < m ? cur + waves_per_xcd : cur;  // last tile: refills become harmless duplicates
-      const int64_t row0 = cur * 16;
-      const bool row_ok = row0 + i16 < n_dst;
-      const bool row_ok_next = nxt * 16 + i16 < n_dst;
-      const uint32_t rc_next = clamp_row(nxt);
-
-      // destination rows of this lane's accumulator fragment: tile positions row0 + 4g + r, or the rows the rulebook's
-      // tile order maps them to (`nbr` is then the table in that order; perm is padded past n_dst)
-      int32_t orow[4];
-      if (perm) {
-        const int4 pv = *reinterpret_cast<const int4*>(perm + row0 + 4 * g);
-        orow[0] = pv.x, orow[1] = pv.y, orow[2] = pv.z, orow[3] = pv.w;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t row = row0 + 4 * g + r;
-          orow[r] = (int32_t)(row < n_dst ? row : n_dst - 1);
-        }
-      }
-      f32x4 acc[NTW], prev[NTW];
-      f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};  // second accumulator of the NTW == 1 case
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}, prev[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (cb > cb_lo) {  // partial sums of the earlier input blocks (issued now, consumed at the end of the tile)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const uint32_t rr = (uint32_t)orow[r];
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt)
-            prev[nt][r] = out[rr * (uint32_t)cout + (uint32_t)((nt0 + (nt < ntw ? nt : 0)) * 16 + i16)];
-        }
-      }
-
-#pragma unroll
-      for (int u = 0; u < KT; ++u) {
-        // wave-uniform skip of taps no row of the tile has (64-bit compare mask straight into a scalar branch)
-        if (__builtin_amdgcn_sicmp(ireg[u], -1, 38 /* ICMP_SGT */) != 0) {
-#pragma unroll
-          for (int c = 0; c < CW; ++c) {
-            const f32x4 a = areg[u % D][c];
-            const f32x4* sb = slab + (u * CW + c) * (NTW * 64) + lane;
-            f32x4 bf[NTW];
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) bf[nt] = sb[nt * 64];
-            // the four k-steps of a tap stay a dependent chain per accumulator (interleaving column tiles measured 1.6x
-            // slower); with a single column tile and a single block two accumulators alternate (40-cycle dependent latency
-            // vs 32-cycle issue)
-            if (NTW == 1 && CW == 1) {
-              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[0].x, acc[0], 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[0].y, acc2, 0, 0, 0);
-              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[0].z, acc[0], 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[0].w, acc2, 0, 0, 0);
-            } else {
-#pragma unroll
-              for (int nt = 0; nt < NTW; ++nt) {
-                if (nt < ntw) {
-                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[nt].x, acc[nt], 0, 0, 0);
-                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[nt].y, acc[nt], 0, 0, 0);
-                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[nt].z, acc[nt], 0, 0, 0);
-                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[nt].w, acc[nt], 0, 0, 0);
-                }
-              }
-            }
-          }
-        }
-        asm volatile("" ::: "memory");  // keep the unrolled taps in program order
-        // slot u now belongs to the next tile; the gather D taps ahead uses this tile's column while u + D < KT and
-        // the next tile's (refilled KT - D taps ago) after that - the same expression either way
-        ireg[u] = load_idx(u, rc_next);
-        load_a(ireg[(u + D) % KT], (u + D < KT) ? row_ok : row_ok_next, cb, areg[u % D]);
-      }
-
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = row0 + 4 * g + r;
-        if (row < n_dst) {
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt)
-            if (nt < ntw)
-              out[(uint32_t)orow[r] * (uint32_t)cout + (uint32_t)((nt0 + nt) * 16 + i16)] =
-                  (NTW == 1 && CW == 1 ? acc[nt][r] + acc2[r] : acc[nt][r]) + prev[nt][r];
-        }
-      }
-    }
-  }
-}
-
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int splits, int64_t elems4,
                                        float* __restrict__ out) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,74 +262,6 @@ int dispatch_cw(const FwdPlan& p, const float* in, const float* packed, const in
     default: return dispatch_ns<NTW, 4>(p, in, packed, nbr, K, n_dst, cin, nt_total, out, stream);
   }
 }
-
-// the persistent tile-streaming kernel serves the large levels: K = 27 / 8 and enough tiles that no tap split is needed
-struct StreamPlan {
-  bool use;
-  int ntw, groups;
-  int cw, cb_splits, cb_per_split;
-};
-
-StreamPlan plan_stream(int K, int64_t n_dst, int cin, int cout) {
-  const int nt = cout / 16;
-  StreamPlan p;
-  p.groups = (int)gpn::cdiv(nt, 4);  // up to 4 output-column tiles per workgroup (slab = K x ntw KiB of LDS)
-  p.ntw = (int)gpn::cdiv(nt, p.groups);
-  // the kernel addresses with 32-bit byte offsets (< 2^31): source rows (at most 8 n_dst of them, for a stride-2 conv),
-  // output rows and the neighbour table must fit
-  p.use = (K == 27 || K == 8) && gpn::cdiv(n_dst, 16) >= 1024 &&
-          n_dst * (int64_t)8 * std::max(cin, cout) * 4 < ((int64_t)1 << 31) && (int64_t)K * n_dst * 4 < ((int64_t)1 << 31);
-  // two input blocks per pass when the slab allows it (K x 2 x ntw KiB <= 108): a 32-channel level is then one pass
-  const int CB = cin / 16;
-  p.cw = (CB % 2 == 0 && p.ntw <= 2) ? 2 : 1;
-  // fewer than ~2 tiles per wave slot: the passes over the input blocks run side by side (grid.z) into partial outputs
-  const int passes = CB / p.cw;
-  p.cb_splits = (gpn::cdiv(n_dst, 16) < 8192 && passes > 1) ? passes : 1;
-  p.cb_per_split = (passes / p.cb_splits) * p.cw;
-  return p;
-}
-
-template <int NTW, int KT, int D, int CW>
-int launch_stream(const StreamPlan& sp, const float* in, const float* packed, const int32_t* nbr, const int32_t* perm,
-                  int64_t n_dst, int cin, int nt_total, float* out, hipStream_t stream) {
-  constexpr size_t lds = (size_t)KT * CW * NTW * 64 * 16;
-  // persistent grid = (workgroups that are resident at once) x CUs: asked from the runtime once per instantiation AND
-  // device (a process may drive several devices; occupancy and CU count are properties of the device)
-  static std::atomic<int> wgs_of_device[gpn::kMaxDevices] = {};
-  int dev = 0;
-  GPN_CHECK_HIP(hipGetDevice(&dev));
-  GPN_CHECK_ARG(dev >= 0 && dev < gpn::kMaxDevices);
-  int wgs = wgs_of_device[dev].load(std::memory_order_acquire);
-  if (wgs == 0) {
-    GPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_fwd_stream_kernel<NTW, KT, D, CW>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0, cus = 0;
-    GPN_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_stream_kernel<NTW, KT, D, CW>, 512, lds));
-    GPN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
-    wgs = (cus * per_cu + 7) / 8 * 8;
-    wgs_of_device[dev].store(wgs, std::memory_order_release);  // idempotent: racing threads compute the same value
-  }
-  const dim3 grid((unsigned)wgs, (unsigned)sp.groups, (unsigned)sp.cb_splits);
-  hipLaunchKernelGGL((spconv_fwd_stream_kernel<NTW, KT, D, CW>), grid, dim3(512), lds, stream, in, packed, nbr, n_dst, cin,
-                     nt_total, gpn::cdiv(n_dst, 16), sp.cb_per_split, perm, out);
-  GPN_CHECK_LAUNCH();
-  return GPN_OK;
-}
-
-template <int NTW>
-int dispatch_stream(const StreamPlan& sp, const float* in, const float* packed, const int32_t* nbr, const int32_t* perm,
-                    int K, int64_t n_dst, int cin, int nt_total, float* out, hipStream_t stream) {
-  constexpr int CW2 = NTW <= 2 ? 2 : 1;  // (instantiated only where the slab fits)
-  if (K == 27) {
-    if (sp.cw == 2) return launch_stream<NTW, 27, 3, CW2>(sp, in, packed, nbr, perm, n_dst, cin, nt_total, out, stream);
-    return launch_stream<NTW, 27, 9, 1>(sp, in, packed, nbr, perm, n_dst, cin, nt_total, out, stream);
-  }
-  if (sp.cw == 2) return launch_stream<NTW, 8, 4, CW2>(sp, in, packed, nbr, perm, n_dst, cin, nt_total, out, stream);
-  return launch_stream<NTW, 8, 8, 1>(sp, in, packed, nbr, perm, n_dst, cin, nt_total, out, stream);
-}
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // "Direct" variant for the mid-size levels (a few thousand tiles, 32..64 channels): no LDS, no barrier, no persistence.
@@ -676,10 +422,7 @@ int dispatch_direct(const float* in, const float* packed, const int32_t* nbr, co
 
 extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout) {
   if (n_dst <= 0 || cin < 16 || cout < 16) return 0;
-  {
-    const StreamPlan sp = plan_stream(K, n_dst, cin, cout);
-    if (sp.use) return sp.cb_splits > 1 ? gpn::align_up((size_t)sp.cb_splits * n_dst * cout * sizeof(float)) : 0;
-  }
+  if (use_direct(K, n_dst, cin, cout)) return 0;
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   return p.splits > 1 ? gpn::align_up((size_t)p.splits * n_dst * cout * sizeof(float)) : 0;
 }
@@ -699,33 +442,6 @@ extern "C" int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, co
     const int32_t* table = nbr_p ? nbr_p : nbr;
     return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, out, stream)
                    : dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, out, stream);
-  }
-  const StreamPlan sp = plan_stream(K, n_dst, cin, cout);
-  if (sp.use) {
-    float* target = out;
-    if (sp.cb_splits > 1) {
-      if (!ws || ws_bytes < (size_t)sp.cb_splits * n_dst * cout * sizeof(float)) {
-        gpn::set_error("gpn_spconv_fwd: workspace too small for %d input-block slices", sp.cb_splits);
-        return GPN_ERR_WS;
-      }
-      target = static_cast<float*>(ws);
-    }
-    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
-    int rc;
-    switch (sp.ntw) {
-      case 1: rc = dispatch_stream<1>(sp, in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, nt, target, stream); break;
-      case 2: rc = dispatch_stream<2>(sp, in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, nt, target, stream); break;
-      case 3: rc = dispatch_stream<3>(sp, in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, nt, target, stream); break;
-      default: rc = dispatch_stream<4>(sp, in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, nt, target, stream); break;
-    }
-    if (rc == GPN_OK && sp.cb_splits > 1) {
-      const int64_t elems4 = n_dst * cout / 4;
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)gpn::cdiv(elems4, 256)), dim3(256), 0, stream, target,
-                         sp.cb_splits, elems4, out);
-      hipError_t e_ = hipGetLastError();
-      if (e_ != hipSuccess) { gpn::set_error("gpn_spconv_fwd: reduce launch failed: %s", hipGetErrorString(e_)); rc = GPN_ERR_HIP; }
-    }
-    return rc;
   }
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   float* target = out;
