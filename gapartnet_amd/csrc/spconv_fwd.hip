@@ -274,6 +274,11 @@ int dispatch_cw(const FwdPlan& p, const float* in, const float* packed, const in
 // 4-5 of them, which is what hides the gather latency.  The waves of one tile are adjacent (they gather the same rows:
 // L1 / L2 hits).  Same arithmetic and summation order per output element as the other variants (tap-major, then input
 // block, then channel).
+// GPN_ABL (default 0) builds measurement variants of the direct kernel for tools/conv_ablation.sh: 1 = no MFMA, 2 = no
+// gather / weight loads, 3 = no loads at all (synthetic neighbour pattern), 4 = 3 without MFMA.  Results are wrong by design.
+#ifndef GPN_ABL
+#define GPN_ABL 0
+#endif
 #ifndef GPN_DIRECT_D
 #define GPN_DIRECT_D 4
 #endif
@@ -309,7 +314,11 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   static_assert(DI == KT || DI >= D + 2, "the index of a stage issued D stages ahead must already be in the ring");
   int32_t ireg[DI];
   auto load_idx = [&](int tap) -> int32_t {
+#if GPN_ABL >= 3
+    return (int32_t)((rc * 2654435761u + (uint32_t)tap * 40503u) % (5u * (uint32_t)n_dst)) < (int32_t)n_dst ? (int32_t)rc : -1;
+#else
     return __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(rc * 4u), (int)(tap * col_bytes), 0));
+#endif
   };
 #pragma unroll
   for (int u = 0; u < DI; ++u) ireg[u] = load_idx(u);
@@ -319,9 +328,14 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
     const int32_t idx = row_ok ? ireg[tap % DI] : -1;
     const bool live = __builtin_amdgcn_sicmp(idx, -1, 38 /* ICMP_SGT */) != 0;  // wave-uniform: some row of the tile has the tap
     const uint32_t off = idx < 0 ? 0x80000000u : ((uint32_t)idx * (uint32_t)cin + 4u * (uint32_t)g) * 4u;
-    areg[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, cb * 64, 0));
     const uint32_t boff = live ? (uint32_t)((s * nt_total + nt) * 1024 + lane * 16) : 0x80000000u;
+#if GPN_ABL >= 2
+    areg[slot] = (f32x4){(float)off, 1.f, 2.f, 3.f};
+    breg[slot] = (f32x4){(float)boff, 1.f, 2.f, 3.f};
+#else
+    areg[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, cb * 64, 0));
     breg[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)boff, 0, 0));
+#endif
   };
 #pragma unroll
   for (int s = 0; s < D; ++s) issue(s, s);
@@ -351,11 +365,17 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
         const int s = tap * CB + cb;
         const f32x4 a = areg[s % D], b = breg[s % D];
         if (s + D < S) issue(s + D, s % D);
+#if GPN_ABL == 1 || GPN_ABL == 4
+        part += a * b;
+#else
         part = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, part, 0, 0, 0);
         part = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, part, 0, 0, 0);
         part = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, part, 0, 0, 0);
         part = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, part, 0, 0, 0);
+#endif
       }
+      // (keep this add in the block of the MFMAs: moved behind the join of the two paths, hipcc 7.2 does not insert the wait
+      // states an accumulator read needs after an MFMA and the add reads stale registers - seen as wrong rows, fixed by s_nop)
       acc += part;
     } else {
 #pragma unroll
