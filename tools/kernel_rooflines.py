@@ -118,6 +118,18 @@ csr = batch.pc_voxel_csr
 dpt = torch.randn(N, 16, device=dev)
 row("G' scatter rows points->voxels (CSR, ordered)", timeit(lambda: H.scatter_rows(dpt, pid, V0, csr=csr)), 8 * N + 64 * N + 64 * V0)
 
+# the same two kernels at 4x and 16x the rows (the bench's batch of 32 and a 128-scene batch): the index -> row chain is one more
+# memory round trip than a copy has, a fixed ~1 us that the small case cannot hide
+for mult in (4, 16):
+    Vm, Nm = V0 * mult, N * mult
+    featm = torch.randn(Vm, 16, device=dev)
+    pidm = torch.cat([pid + i * V0 for i in range(mult)]).contiguous()
+    row(f"G  gather rows, {mult}x ({Nm} x 16 ch)", timeit(lambda: H.gather_rows(featm, pidm)), 4 * Nm + 64 * Vm + 64 * Nm)
+    csrm = H.rows_csr(pidm, Vm)
+    dptm = torch.randn(Nm, 16, device=dev)
+    row(f"G' scatter rows, {mult}x (CSR, ordered)", timeit(lambda: H.scatter_rows(dptm, pidm, Vm, csr=csrm)), 8 * Nm + 64 * Nm + 64 * Vm)
+    del featm, pidm, csrm, dptm
+
 # B / L -- ball query on the foreground points (semantic label > 0), CCL on its result
 sem = batch.sem_labels
 fg = torch.nonzero(sem > 0).squeeze(1)
