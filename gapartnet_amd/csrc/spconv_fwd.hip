@@ -291,7 +291,11 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;  // prefetch depth in stages
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous eighth of the
+  // tiles, so that the source rows its waves gather (spatial neighbours = nearby rows) are fetched into ONE L2 instead of
+  // all eight (time per launch unchanged; fetched bytes per launch, averaged over the bench's conv launches: 16.2 -> 8.9 MB)
+  const int64_t wg = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t unit = wg * 4 + wave;
   if (unit >= units) return;  // whole wave; no barrier in this kernel
   const int64_t tile = unit / nt_total;
   const int nt = (int)(unit - tile * nt_total);
@@ -399,7 +403,7 @@ int launch_direct(const float* in, const float* packed, const int32_t* nbr, cons
                   float* out, hipStream_t stream) {
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
-  hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)gpn::cdiv(units, 4)), dim3(256), 0, stream, in, packed,
+  hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4), 8) * 8)), dim3(256), 0, stream, in, packed,
                      nbr, n_dst, nt_total, units, packed_bytes, perm, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
