@@ -62,12 +62,12 @@ def build_step(model, optimizer, world, device):
 
 
 def kernel_source_fingerprint():
-    """sha256 over the HIP sources the conv kernels are built from: identifies WHICH kernels a PMC pass measured"""
+    """sha256 over the HIP sources (and the Makefile) the kernels are built from: identifies WHICH kernels a PMC pass measured"""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "gapartnet_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h")) or name == "Makefile":  # (the Makefile carries per-file compiler flags)
             with open(os.path.join(csrc, name), "rb") as fh:
                 h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

@@ -5,7 +5,7 @@
 #   on the GPU box:  tools/conv_ablation.sh run
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -Wno-unused-value"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1"
 if [ "${1:-build}" = build ]; then
   mkdir -p $R/_variants
   make -s -C $R/gapartnet_amd/csrc -j8
