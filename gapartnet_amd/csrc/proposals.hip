@@ -29,7 +29,7 @@ namespace {
 constexpr int kThreads = 256;
 
 // counts[] slots (int64, device): the caller reads them once after the call
-enum { kQ = 0, kM = 1, kP = 2, kV = 3, kDropped = 4, kRuns = 5, kCounts = 8 };
+enum { kQ = 0, kM = 1, kP = 2, kV = 3, kDropped = 4, kRuns = 5, kCoarse = 6, kCounts = 8 };  // kCoarse: rows of the grid's stride-2 level
 
 __global__ __launch_bounds__(kThreads) void prop_label_kernel(const float* __restrict__ points, int stride,
                                                               const float* __restrict__ offsets,
@@ -377,6 +377,7 @@ PropWs carve(void* ws, size_t ws_bytes, int64_t N, int64_t B, int Kmax, int64_t 
   o.prim_bytes = prim_bytes_for((int64_t)t2);
   o.prim = w.take<char>(o.prim_bytes);
   o.sub_bytes = std::max(std::max(gpn_ball_query_grid_ws_bytes(N), gpn_ccl_ws_bytes(N)), gpn_voxelize_ws_bytes((int64_t)t2, 3));
+  o.sub_bytes = std::max(o.sub_bytes, gpn_rulebook_level_counts_ws_bytes((int64_t)t2, 1));
   o.sub = w.take<char>(o.sub_bytes);
   o.total = w.used;
   return o;
@@ -498,7 +499,11 @@ extern "C" int gpn_proposals_build(const float* points, int point_stride, const 
   hipLaunchKernelGGL(prop_finish_kernel, dim3(grid_of(T2)), dim3(kThreads), 0, stream, o.vc3, o.vseg, pc_voxel_id, T2,
                      voxel_coords4, counts);
   GPN_CHECK_LAUNCH();
-  return GPN_OK;
+  // rows of the proposal grid's coarse level (the ScoreNet / NPCS-Net U-Nets have one stride-2 level): with it in the same
+  // read as the other counts, building their rulebooks needs no host read of its own
+  const int32_t grid_shape[3] = {(int32_t)fullscale, (int32_t)fullscale, (int32_t)fullscale};
+  return gpn_rulebook_level_counts(voxel_coords4, T2, counts + kV, P_ub > 0 ? P_ub : 1, grid_shape, 1, counts + kCoarse, o.sub, o.sub_bytes,
+                                   stream_);
 }
 
 extern "C" int gpn_proposals_voxel_mean(const float* feats, const int64_t* point_indices, const int32_t* point_order,

@@ -215,6 +215,46 @@ size_t iscan_temp_bytes(int64_t n) {
   return bytes;
 }
 
+
+// ---- row counts of every coarse level in one pass ------------------------------------------------------------------
+// The k2 s2 rule applied l times: level-l coordinate = c >> l, dropped (for good) once it falls outside that level's
+// shape (shape_l = shape_{l-1} / 2).  One hash set per level; a voxel whose level-l key is already present stops - the
+// voxel that inserted it also inserts the coarser ones.  New keys are counted per wave (ballot) with one atomic each.
+__global__ __launch_bounds__(kThreads) void level_counts_kernel(const int32_t* __restrict__ indices, int64_t n_max,
+                                                                const int64_t* __restrict__ n_dev, int nb, int s0, int s1,
+                                                                int s2, int n_levels, uint64_t* __restrict__ tables,
+                                                                uint64_t cap, int64_t* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t n = n_dev ? (*n_dev < n_max ? *n_dev : n_max) : n_max;
+  bool active = i < n;
+  int4 c = make_int4(0, 0, 0, 0);
+  if (active) c = reinterpret_cast<const int4*>(indices)[i];
+  active = active && c.x >= 0 && c.x < nb && c.y >= 0 && c.z >= 0 && c.w >= 0 && c.y < s0 && c.z < s1 && c.w < s2;
+  int x = c.y, y = c.z, z = c.w;
+  const uint64_t mask = cap - 1;
+  for (int l = 0; l < n_levels; ++l) {  // wave-uniform trip count: every lane reaches the ballot
+    x >>= 1, y >>= 1, z >>= 1;
+    s0 /= 2, s1 /= 2, s2 /= 2;
+    active = active && x < s0 && y < s1 && z < s2;
+    bool is_new = false;
+    if (active) {
+      const uint64_t key = lin_key(c.x, x, y, z, s0, s1, s2);
+      uint64_t* table = tables + (uint64_t)l * cap;
+      uint64_t slot = mix64(key) & mask;
+      while (true) {
+        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(table + slot),
+                                                  (unsigned long long)kEmpty, (unsigned long long)key);
+        if (prev == kEmpty) { is_new = true; break; }
+        if (prev == key) break;
+        slot = (slot + 1) & mask;
+      }
+    }
+    const uint64_t m = __ballot(is_new);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(reinterpret_cast<unsigned long long*>(counts + l), (unsigned long long)__popcll(m));
+    active = active && is_new;
+  }
+}
+
 }  // namespace
 
 // ================================================================================================ subm3
@@ -454,3 +494,36 @@ extern "C" int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int3
   return lists_from_table(tb, pos, 8, N, bwd_src, bwd_dst, bwd_tile_off, nullptr, prim_tmp, prim_bytes, stream);
 }
 
+
+static uint64_t level_table_cap(int64_t n_max) {
+  uint64_t cap = 1024;
+  while (cap < 2 * (uint64_t)(n_max > 0 ? n_max : 1)) cap <<= 1;
+  return cap;
+}
+
+extern "C" size_t gpn_rulebook_level_counts_ws_bytes(int64_t n_max, int n_levels) {
+  return gpn::align_up((size_t)level_table_cap(n_max) * (size_t)(n_levels > 0 ? n_levels : 1) * sizeof(uint64_t));
+}
+
+extern "C" int gpn_rulebook_level_counts(const int32_t* indices, int64_t n_max, const int64_t* n_dev, int64_t batch_size,
+                                         const int32_t* spatial_shape_host, int n_levels, int64_t* counts, void* ws,
+                                         size_t ws_bytes, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(n_max >= 0 && n_levels >= 1 && n_levels <= 16 && spatial_shape_host && counts && batch_size >= 1);
+  GPN_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)n_levels, stream));
+  if (n_max == 0) return GPN_OK;
+  GPN_CHECK_ARG(indices && n_max < (int64_t)0x7fffffff);
+  const uint64_t cap = level_table_cap(n_max);
+  const size_t need = (size_t)cap * (size_t)n_levels * sizeof(uint64_t);
+  if (!ws || ws_bytes < need) {
+    gpn::set_error("gpn_rulebook_level_counts: workspace too small (%zu needed, %zu given)", need, ws_bytes);
+    return GPN_ERR_WS;
+  }
+  GPN_CHECK_HIP(hipMemsetAsync(ws, 0xff, need, stream));
+  gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 16.0 * (double)n_max);
+  hipLaunchKernelGGL(level_counts_kernel, dim3((unsigned)gpn::cdiv(n_max, kThreads)), dim3(kThreads), 0, stream, indices, n_max,
+                     n_dev, (int)batch_size, spatial_shape_host[0], spatial_shape_host[1], spatial_shape_host[2], n_levels,
+                     static_cast<uint64_t*>(ws), cap, counts);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}

@@ -165,8 +165,23 @@ def tile_order(nbr, K, n):
     return perm, nbr_p
 
 
-def rulebook_down(indices, spatial_shape, batch_size):
-    """Returns (out_indices [No,4] i32, out_shape, rb_fwd (dst=coarse), rb_bwd (dst=fine)). One host sync."""
+def rulebook_level_counts(indices, spatial_shape, batch_size, n_levels):
+    """-> device tensor [n_levels] i64: rows of each of the next ``n_levels`` stride-2 levels below ``indices`` (what the
+    successive rulebook_down calls would report), so that a caller can fetch them all with ONE host read."""
+    dev = _dev(indices)
+    indices = _c(indices, torch.int32)
+    N = indices.shape[0]
+    counts = torch.empty((n_levels,), dtype=torch.int64, device=dev)
+    L = _C.lib()
+    ws = _ws(L.gpn_rulebook_level_counts_ws_bytes(i64(N), i32(n_levels)), dev)
+    check(L.gpn_rulebook_level_counts(ptr(indices), i64(N), ptr(None), i64(batch_size), host_i32x3(spatial_shape), i32(n_levels),
+                                      ptr(counts), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_level_counts")
+    return counts
+
+
+def rulebook_down(indices, spatial_shape, batch_size, n_out=None):
+    """Returns (out_indices [No,4] i32, out_shape, rb_fwd (dst=coarse), rb_bwd (dst=fine)).  One host sync, none when the
+    caller already knows the coarse row count ``n_out`` (rulebook_level_counts / the proposal stage's counts)."""
     dev = _dev(indices)
     indices = _c(indices, torch.int32)
     N = indices.shape[0]
@@ -179,7 +194,7 @@ def rulebook_down(indices, spatial_shape, batch_size):
     check(L.gpn_rulebook_down(ptr(indices), i64(N), i64(batch_size), host_i32x3(spatial_shape), ptr(out_idx),
                               ptr(f2c), ptr(tap), ptr(nout), ptr(ws), szt(ws.numel()), _stream()),
           "gpn_rulebook_down")
-    No = int(nout.item())
+    No = int(nout.item()) if n_out is None else int(n_out)
     cap = max(N, 1)
     fs = torch.empty((cap,), dtype=torch.int32, device=dev)
     fd = torch.empty((cap,), dtype=torch.int32, device=dev)
@@ -670,10 +685,10 @@ def proposals_build(points_xyz, offset_preds, sem_preds, instance_labels, batch_
                                 ptr(point_indices), ptr(proposal_indices), ptr(batch_p), ptr(xyz_p), ptr(sem_p), ptr(inst_p),
                                 ptr(sizes), ptr(offsets), ptr(member_slot), ptr(coords4), ptr(pid), ptr(order), ptr(vstart),
                                 ptr(ws), szt(ws.numel()), _stream()), "gpn_proposals_build")
-    Q, M, P, V, dropped = counts.tolist()[:5]  # the stage's single device -> host read
+    Q, M, P, V, dropped, _, coarse = counts.tolist()[:7]  # the stage's single device -> host read
     if M == 0:
         return None
-    return dict(Q=Q, M=M, P=P, V=V, dropped=dropped, valid_mask=valid_mask, valid_indices=valid_indices[:Q],
+    return dict(Q=Q, M=M, P=P, V=V, dropped=dropped, coarse=coarse, valid_mask=valid_mask, valid_indices=valid_indices[:Q],
                 sorted_indices=sorted_indices[:M], point_indices=point_indices[:M], proposal_indices=proposal_indices[:M],
                 batch_indices=batch_p[:M], pt_xyz=xyz_p[:M], sem_preds=sem_p[:M],
                 instance_labels=inst_p[:M] if instance_labels is not None else None, sizes=sizes[:P],

@@ -278,6 +278,7 @@ class GAPartNet(LightningModule):
         voxel_features = GF.proposal_voxel_mean(pt_features, built)
         voxel_tensor = spconv.SparseConvTensor(voxel_features, built["voxel_coords"],
                                                spatial_shape=[self.score_fullscale] * 3, batch_size=built["P"])
+        voxel_tensor.level_counts = [built["coarse"]]  # rows of the grid's stride-2 level: no read when its rulebook is built
         voxel_tensor.point_csr = (built["point_order"], built["voxel_point_start"])
         proposals = Instances(valid_mask=built["valid_mask"], valid_indices=built["valid_indices"],
                               sorted_indices=built["sorted_indices"], point_indices=built["point_indices"],

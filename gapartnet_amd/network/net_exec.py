@@ -195,6 +195,13 @@ class NetProgram:
         ops = backend.raw()
         levels = [(x.indices, list(x.spatial_shape))]
         subm, down = [], []
+        # row counts of the coarse levels still to be built: known to the producer of the tensor (the proposal stage reports
+        # its grid's in its one read), else fetched for all levels with ONE read instead of one per level
+        known = list(getattr(x, "level_counts", None) or [])
+        missing = [lvl for lvl in range(self.n_levels - 1) if x.indice_dict.get(self.level_keys[lvl][1]) is None]
+        if missing and len(known) < self.n_levels - 1 and missing[0] == 0 and hasattr(ops, "rulebook_level_counts") \
+                and x.indices.is_cuda and x.indices.shape[0] > 0 and self.n_levels > 2:
+            known = ops.rulebook_level_counts(x.indices, list(x.spatial_shape), x.batch_size, self.n_levels - 1).tolist()
         for lvl in range(self.n_levels):
             idx, shape = levels[lvl]
             skey, dkey = self.level_keys[lvl]
@@ -206,7 +213,10 @@ class NetProgram:
             if lvl + 1 < self.n_levels:
                 rec = x.indice_dict.get(dkey)
                 if rec is None:
-                    out_idx, out_shape, rb_fwd, rb_bwd = ops.rulebook_down(idx, shape, x.batch_size)
+                    if lvl < len(known) and idx.is_cuda:
+                        out_idx, out_shape, rb_fwd, rb_bwd = ops.rulebook_down(idx, shape, x.batch_size, n_out=known[lvl])
+                    else:
+                        out_idx, out_shape, rb_fwd, rb_bwd = ops.rulebook_down(idx, shape, x.batch_size)
                     rec = spconv._DownRecord(idx, shape, out_idx, out_shape, rb_fwd, rb_bwd)
                     x.indice_dict[dkey] = rec
                 down.append(rec)

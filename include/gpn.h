@@ -124,6 +124,14 @@ size_t gpn_rulebook_down_ws_bytes(int64_t N);
 int gpn_rulebook_down(const int32_t* indices, int64_t N, int64_t batch_size,
                       const int32_t* spatial_shape_host, int32_t* out_indices, int32_t* fine_to_coarse, int32_t* tap, int64_t* num_out,
                       void* ws, size_t ws_bytes, gpn_stream_t stream);
+/* row counts of ALL coarse levels below a voxel set in one pass (what n_levels successive gpn_rulebook_down calls would
+ * report in num_out): counts [n_levels] i64 on the device, so that a U-Net's rulebook pyramid costs ONE host read instead of
+ * one per level; gpn_rulebook_down itself is unchanged (its num_out is then only a cross-check).  n_dev (optional, device):
+ * the number of valid rows when indices is an upper-bound buffer. */
+size_t gpn_rulebook_level_counts_ws_bytes(int64_t n_max, int n_levels);
+int gpn_rulebook_level_counts(const int32_t* indices, int64_t n_max, const int64_t* n_dev, int64_t batch_size,
+                              const int32_t* spatial_shape_host, int n_levels, int64_t* counts, void* ws, size_t ws_bytes,
+                              gpn_stream_t stream);
 size_t gpn_rulebook_down_lists_ws_bytes(int64_t N, int64_t n_out);
 int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N,
                             int64_t n_out,

@@ -103,6 +103,29 @@ def test_rulebooks_bit_exact(H, cuda, kind, batch, shape, n):
     _check_rb(rb_b, d["bwd"])
 
 
+@pytest.mark.parametrize("kind,batch,shape,n,levels", [("surface", 3, [64, 64, 64], 5000, 5), ("random", 2, [12, 10, 14], 700, 3),
+                                                        ("surface", 8, [190, 200, 130], 40000, 6), ("random", 1, [3, 3, 3], 1, 1)])
+def test_level_counts_equal_the_chain_of_down_rulebooks(H, cuda, kind, batch, shape, n, levels):
+    """gpn_rulebook_level_counts (one pass, one read) == the row counts n successive stride-2 rulebooks produce (oracle), and
+    rulebook_down fed with the count builds what it builds when it reads the count itself; odd extents drop the last plane"""
+    rng = np.random.default_rng(n + levels)
+    idx = synth.random_sparse_indices(rng, batch, shape, n) if kind == "random" else synth.surface_indices(rng, batch, shape, n)
+    want, cur, cur_shape = [], idx, list(shape)
+    for _ in range(levels):
+        d = O.rulebook_down(cur, cur_shape)
+        want.append(d["out_indices"].shape[0])
+        cur, cur_shape = d["out_indices"], d["out_shape"]
+    got = H.rulebook_level_counts(dev(idx, cuda), shape, batch, levels).tolist()
+    assert got == want
+    a = H.rulebook_down(dev(idx, cuda), shape, batch)
+    b = H.rulebook_down(dev(idx, cuda), shape, batch, n_out=got[0])
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]
+    for ra, rb in ((a[2], b[2]), (a[3], b[3])):
+        P = int(ra.num_pairs.item())  # (the pair arrays are capacity-sized: only the first P entries are defined)
+        assert P == int(rb.num_pairs.item()) and torch.equal(ra.tile_off, rb.tile_off)
+        assert torch.equal(ra.pair_src[:P], rb.pair_src[:P]) and torch.equal(ra.pair_dst[:P], rb.pair_dst[:P])
+
+
 # ------------------------------------------------------------------------------------------------ C
 CONV_SHAPES = [(16, 16), (32, 32), (48, 48), (64, 64), (80, 80), (96, 96), (112, 112), (32, 16), (64, 32), (96, 48),
                (128, 64), (160, 80), (192, 96), (16, 32), (96, 112)]
@@ -467,6 +490,7 @@ def test_empty_and_degenerate_inputs(H, cuda):
     assert rb.n_dst == 0 and int(rb.num_pairs.item()) == 0
     out_idx, out_shape, rb_f, rb_b = H.rulebook_down(idx0, [8, 8, 8], 1)
     assert out_idx.shape == (0, 4) and out_shape == [4, 4, 4] and rb_f.n_dst == 0
+    assert H.rulebook_level_counts(idx0, [8, 8, 8], 1, 3).tolist() == [0, 0, 0]
     # C: a conv over nothing, and over one isolated voxel (only the centre tap exists)
     w = dev(np.ones((27, 16, 16), f32), cuda)
     assert H.conv_fwd(dev(np.zeros((0, 16), f32), cuda), w, rb).shape == (0, 16)
