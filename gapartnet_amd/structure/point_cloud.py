@@ -143,6 +143,19 @@ class PointCloud:
             instance_sem_labels=instance_sem_labels, gt_npcs=cat("gt_npcs"))
 
 
+_VOXEL_SIZE_CACHE = {}
+
+
+def _voxel_size_on(device, voxel_size):
+    """the voxel size as a device tensor, uploaded once per (device, size): a pageable host->device copy per batch is a
+    synchronising call"""
+    key = (str(device), tuple(float(v) for v in voxel_size))
+    t = _VOXEL_SIZE_CACHE.get(key)
+    if t is None:
+        t = _VOXEL_SIZE_CACHE[key] = torch.as_tensor(list(key[1]), dtype=torch.float32, device=device)
+    return t
+
+
 @torch.no_grad()
 def voxelize_scenes(xyz: torch.Tensor, feats: torch.Tensor, counts: Sequence[int], voxel_size: Sequence[float]):
     """Batched scene voxelisation with the reference's per-scene conventions (dataset/gapartnet.py:179-205):
@@ -152,16 +165,17 @@ def voxelize_scenes(xyz: torch.Tensor, feats: torch.Tensor, counts: Sequence[int
     n_scenes = len(counts)
     offsets = torch.zeros((n_scenes + 1,), dtype=torch.int64)
     offsets[1:] = torch.as_tensor(counts, dtype=torch.int64).cumsum(0)
-    offsets_dev = offsets.to(device)
-    if len(set(counts)) == 1:  # equal-size scenes (the 20k-point contract): one strided reduction
+    if len(set(counts)) == 1:  # equal-size scenes (the 20k-point contract): one strided reduction, offsets made on the device
+        offsets_dev = torch.arange(n_scenes + 1, dtype=torch.int64, device=device) * int(counts[0])
         per_scene = xyz.reshape(n_scenes, counts[0], 3)
         lo, hi = per_scene.amin(1), per_scene.amax(1)
     else:
+        offsets_dev = offsets.to(device)
         bounds = offsets.tolist()
         lo = torch.stack([xyz[bounds[s]:bounds[s + 1]].amin(0) for s in range(n_scenes)])
         hi = torch.stack([xyz[bounds[s]:bounds[s + 1]].amax(0) for s in range(n_scenes)])
     rmin, rmax = lo - 1e-4, hi + 1e-4
-    vs = torch.as_tensor(list(voxel_size), dtype=torch.float32, device=device)
+    vs = _voxel_size_on(device, voxel_size)
     cells = (torch.floor((rmax - rmin) / vs).max(0)[0].to(torch.int64) + 2).tolist()  # host sync #1 (3 ints)
     out = backend.raw().voxelize(xyz, feats, offsets_dev, rmin, rmax, [float(v) for v in voxel_size], cells,
                                  want_csr=True, want_stats=True)

@@ -31,7 +31,8 @@ sites = Counter()
 def hook(message, category, filename, lineno, file=None, line=None):
     if "synchroniz" not in str(message):
         return
-    stack = [f for f in traceback.extract_stack() if "/gapartnet_amd/" in f.filename]
+    full = traceback.extract_stack()
+    stack = [f for f in full if "/gapartnet_amd/" in f.filename] or [f for f in full if "sync_sites" not in f.filename][-4:]
     key = " <- ".join(f"{os.path.relpath(f.filename, ROOT)}:{f.lineno}" for f in reversed(stack[-3:]))
     sites[key] += 1
 
