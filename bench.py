@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # see gapartnet_amd/__init__.py: one hardware queue per stream incl. RCCL's
 import torch
 import torch.distributed as dist
 

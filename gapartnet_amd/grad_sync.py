@@ -67,6 +67,8 @@ class GradSync:
         self._buckets: Optional[List[List[int]]] = None
         self.stats = {"in_place": 0, "flattened": 0, "skipped": 0, "steps": 0, "host_ms": 0.0}
         self._verify_always = os.environ.get("GPN_GRAD_SYNC_VERIFY") == "1"
+        # (gloo has no coalescing: its buckets go one call each, as before)
+        self._coalesce = self.backend == "nccl" and os.environ.get("GPN_GRAD_SYNC_NO_COALESCE") != "1"
 
     # ------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
@@ -143,12 +145,30 @@ class GradSync:
             return None
         return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(store, g0.storage_offset(), (total,), (1,))
 
-    def _all_reduce_mean(self, flat):
-        if self.backend == "nccl":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+    def _all_reduce_mean(self, flats):
+        """mean over the ranks of every buffer in ``flats``, in place, as ONE collective launch (RCCL group call): each
+        separate all-reduce costs ~0.2 ms of host bookkeeping and a stream hand-off (four per step were +2 ms on a 13 ms
+        step, bench.py with GPN_BENCH_FORCE_GRAD_SYNC=1)"""
+        if not flats:
+            return
+        op = dist.ReduceOp.AVG if self.backend == "nccl" else dist.ReduceOp.SUM
+        if len(flats) == 1 or not self._coalesce:
+            for flat in flats:
+                dist.all_reduce(flat, op=op, group=self.group)
         else:
-            dist.all_reduce(flat, group=self.group)
-            flat.div_(self.world)
+            try:
+                from torch.distributed.distributed_c10d import _coalescing_manager
+                with _coalescing_manager(group=self.group, device=flats[0].device, async_ops=False):
+                    for flat in flats:
+                        dist.all_reduce(flat, op=op, group=self.group)
+            except (ImportError, RuntimeError, TypeError) as exc:  # a backend without coalescing: one call per buffer
+                print(f"[grad_sync] coalesced all-reduce unavailable ({type(exc).__name__}: {exc}); one call per bucket", flush=True)
+                self._coalesce = False
+                for flat in flats:
+                    dist.all_reduce(flat, op=op, group=self.group)
+        if self.backend != "nccl":
+            for flat in flats:
+                flat.div_(self.world)
 
     @torch.no_grad()
     def sync(self):
@@ -165,13 +185,14 @@ class GradSync:
             used = on_dev.cpu()
         used = used.tolist()
         self.stats["steps"] += 1
+        flats, repoint = [], []  # buffers to reduce in this step's one collective; (flat, live ids) whose .grad follow it
         for ids, prog in zip(self._buckets, self._progs):
             # (every rank must reduce the same number of elements: the whole-buffer path only when the consensus says every
             # parameter of the bucket has a gradient somewhere - which is always the case for a net that ran)
             if prog is not None and all(used[i] for i in ids):
                 flat = self._executor_flat(prog, [params[i].grad for i in ids], prog.grad_total)
                 if flat is not None:
-                    self._all_reduce_mean(flat)
+                    flats.append(flat)
                     self.stats["in_place"] += 1
                     continue
             live = [i for i in ids if used[i]]
@@ -181,7 +202,7 @@ class GradSync:
             grads = [params[i].grad for i in live]
             flat = self._shared_flat(grads) if all(g is not None for g in grads) else None
             if flat is not None:
-                self._all_reduce_mean(flat)
+                flats.append(flat)
                 self.stats["in_place"] += 1
                 continue
             ref = params[live[0]]
@@ -191,8 +212,11 @@ class GradSync:
                 flat = torch.cat([g.reshape(-1) if g is not None else
                                   torch.zeros(params[i].numel(), dtype=ref.dtype, device=ref.device)
                                   for i, g in zip(live, grads)])
-            self._all_reduce_mean(flat)
+            flats.append(flat)
+            repoint.append((flat, live))
+            self.stats["flattened"] += 1
+        self._all_reduce_mean(flats)
+        for flat, live in repoint:
             for i, piece in zip(live, flat.split([params[i].numel() for i in live])):
                 params[i].grad = piece.view_as(params[i])
-            self.stats["flattened"] += 1
         self.stats["host_ms"] += (time.perf_counter() - t0) * 1e3  # host time spent issuing the exchange (all steps)

@@ -11,6 +11,11 @@ import torch
 from gapartnet_amd.smoke import make_batch, make_model
 
 dev = torch.device("cuda:0")
+if os.environ.get("PROBE_GROUP") == "1":  # with an RCCL communicator alive (what every rank of a multi-GPU run has)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29535")
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
 model = make_model((0, 0)).to(dev)
 opt = model.configure_optimizers()
 batch = [pc.to(dev) for pc in make_batch(8, 20000)]
