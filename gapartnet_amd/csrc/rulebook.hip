@@ -255,6 +255,18 @@ __global__ __launch_bounds__(kThreads) void level_counts_kernel(const int32_t* _
   }
 }
 
+
+// K = 1 "rulebook": every row is its own (only) neighbour.  rows [n], tile_off [n_tiles + 1], nbr [n + 1] (last = -1)
+__global__ __launch_bounds__(kThreads) void identity_rulebook_kernel(int64_t n, int64_t n_tiles, int32_t* __restrict__ rows,
+                                                                     int32_t* __restrict__ tile_off, int32_t* __restrict__ nbr,
+                                                                     int64_t* __restrict__ num_pairs) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) rows[i] = (int32_t)i, nbr[i] = (int32_t)i;
+  if (i == n) nbr[n] = -1;
+  if (i <= n_tiles) tile_off[i] = (int32_t)(i * GPN_TILE_ROWS < n ? i * GPN_TILE_ROWS : n);
+  if (i == 0) num_pairs[0] = n;
+}
+
 }  // namespace
 
 // ================================================================================================ subm3
@@ -524,6 +536,17 @@ extern "C" int gpn_rulebook_level_counts(const int32_t* indices, int64_t n_max, 
   hipLaunchKernelGGL(level_counts_kernel, dim3((unsigned)gpn::cdiv(n_max, kThreads)), dim3(kThreads), 0, stream, indices, n_max,
                      n_dev, (int)batch_size, spatial_shape_host[0], spatial_shape_host[1], spatial_shape_host[2], n_levels,
                      static_cast<uint64_t*>(ws), cap, counts);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_rulebook_identity(int64_t n, int32_t* rows, int32_t* tile_off, int32_t* nbr, int64_t* num_pairs,
+                                     gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(n >= 0 && n < (int64_t)0x7fffffff && rows && tile_off && nbr && num_pairs);
+  const int64_t n_tiles = gpn::cdiv(n, (int64_t)GPN_TILE_ROWS);
+  hipLaunchKernelGGL(identity_rulebook_kernel, dim3((unsigned)gpn::cdiv(n + 1, (int64_t)kThreads)), dim3(kThreads), 0, stream, n,
+                     n_tiles, rows, tile_off, nbr, num_pairs);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

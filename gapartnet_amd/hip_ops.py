@@ -98,7 +98,7 @@ def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_siz
     vc = torch.empty((M, 3), dtype=torch.int32, device=dev)
     vseg = torch.empty((M,), dtype=torch.int32, device=dev)
     pid = torch.empty((M,), dtype=torch.int32, device=dev)
-    nv = torch.zeros((1,), dtype=torch.int64, device=dev)
+    nv = torch.empty((1,), dtype=torch.int64, device=dev)  # (always written by the library)
     order = torch.empty((M,), dtype=torch.int32, device=dev) if want_csr else None
     vstart = torch.empty((M + 1,), dtype=torch.int32, device=dev) if want_csr else None
     L = _C.lib()
@@ -132,7 +132,7 @@ def rulebook_subm3(indices, spatial_shape) -> Rulebook:
     src = torch.empty((cap,), dtype=torch.int32, device=dev)
     dst = torch.empty((cap,), dtype=torch.int32, device=dev)
     toff = torch.empty((27, n_tiles(N) + 1), dtype=torch.int32, device=dev)
-    npairs = torch.zeros((1,), dtype=torch.int64, device=dev)
+    npairs = torch.empty((1,), dtype=torch.int64, device=dev)  # (always written by the library)
     L = _C.lib()
     ws = _ws(L.gpn_rulebook_subm3_ws_bytes(i64(N)), dev)
     nbr = torch.empty((27 * N + 1,), dtype=torch.int32, device=dev)
@@ -165,6 +165,17 @@ def tile_order(nbr, K, n):
     return perm, nbr_p
 
 
+def rulebook_identity(n, device) -> Rulebook:
+    """the K = 1 rulebook over ``n`` rows (SubMConv3d(k=1), linear layers on the conv kernels) in one launch"""
+    rows = torch.empty((max(n, 1),), dtype=torch.int32, device=device)[:n]
+    tile_off = torch.empty((1, n_tiles(n) + 1), dtype=torch.int32, device=device)
+    nbr = torch.empty((n + 1,), dtype=torch.int32, device=device)
+    npairs = torch.empty((1,), dtype=torch.int64, device=device)
+    check(_C.lib().gpn_rulebook_identity(i64(n), ptr(rows if n > 0 else nbr), ptr(tile_off), ptr(nbr), ptr(npairs), _stream()),
+          "gpn_rulebook_identity")
+    return Rulebook(rows, rows, tile_off, 1, n, n, npairs[0], nbr)
+
+
 def rulebook_level_counts(indices, spatial_shape, batch_size, n_levels):
     """-> device tensor [n_levels] i64: rows of each of the next ``n_levels`` stride-2 levels below ``indices`` (what the
     successive rulebook_down calls would report), so that a caller can fetch them all with ONE host read."""
@@ -188,7 +199,7 @@ def rulebook_down(indices, spatial_shape, batch_size, n_out=None):
     out_idx = torch.empty((max(N, 1), 4), dtype=torch.int32, device=dev)
     f2c = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
     tap = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
-    nout = torch.zeros((1,), dtype=torch.int64, device=dev)
+    nout = torch.empty((1,), dtype=torch.int64, device=dev)  # (always written by the library)
     L = _C.lib()
     ws = _ws(L.gpn_rulebook_down_ws_bytes(i64(N)), dev)
     check(L.gpn_rulebook_down(ptr(indices), i64(N), i64(batch_size), host_i32x3(spatial_shape), ptr(out_idx),
@@ -202,7 +213,7 @@ def rulebook_down(indices, spatial_shape, batch_size, n_out=None):
     bd = torch.empty((cap,), dtype=torch.int32, device=dev)
     ft = torch.empty((8, n_tiles(No) + 1), dtype=torch.int32, device=dev)
     bt = torch.empty((8, n_tiles(N) + 1), dtype=torch.int32, device=dev)
-    npairs = torch.zeros((1,), dtype=torch.int64, device=dev)
+    npairs = torch.empty((1,), dtype=torch.int64, device=dev)  # (always written by the library)
     ws = _ws(L.gpn_rulebook_down_lists_ws_bytes(i64(N), i64(No)), dev)
     fn = torch.empty((8 * No + 1,), dtype=torch.int32, device=dev)
     bn = torch.empty((8 * N + 1,), dtype=torch.int32, device=dev)

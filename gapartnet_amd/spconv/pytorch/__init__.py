@@ -183,6 +183,9 @@ class _SparseConvBase(SparseModule):
 def _identity_rulebook(n: int, device):
     """K = 1 rulebook whose only tap maps every row to itself (pure torch: it is just arange)."""
     from ...hip_ops import Rulebook, n_tiles
+    if torch.device(device).type == "cuda":
+        from ... import hip_ops
+        return hip_ops.rulebook_identity(n, torch.device(device))
     rows = torch.arange(n, dtype=torch.int32, device=device)
     tile_off = torch.clamp(torch.arange(n_tiles(n) + 1, dtype=torch.int32, device=device) * 32, max=n).reshape(1, -1)
     nbr = torch.cat([rows, torch.full((1,), -1, dtype=torch.int32, device=device)])

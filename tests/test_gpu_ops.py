@@ -126,6 +126,18 @@ def test_level_counts_equal_the_chain_of_down_rulebooks(H, cuda, kind, batch, sh
         assert torch.equal(ra.pair_src[:P], rb.pair_src[:P]) and torch.equal(ra.pair_dst[:P], rb.pair_dst[:P])
 
 
+@pytest.mark.parametrize("n", [0, 1, 31, 32, 33, 1000, 65537])
+def test_identity_rulebook_equals_the_torch_formulation(H, cuda, n):
+    """gpn_rulebook_identity (one launch) == the arange / clamp / cat construction the K = 1 convs used before"""
+    rb = H.rulebook_identity(n, cuda)
+    rows = torch.arange(n, dtype=torch.int32, device=cuda)
+    tiles = (n + 31) // 32
+    assert torch.equal(rb.pair_src, rows) and torch.equal(rb.pair_dst, rows) and int(rb.num_pairs.item()) == n
+    assert torch.equal(rb.tile_off.reshape(-1), torch.clamp(torch.arange(tiles + 1, dtype=torch.int32, device=cuda) * 32, max=n))
+    assert torch.equal(rb.nbr, torch.cat([rows, torch.full((1,), -1, dtype=torch.int32, device=cuda)]))
+    assert (rb.K, rb.n_src, rb.n_dst) == (1, n, n)
+
+
 # ------------------------------------------------------------------------------------------------ C
 CONV_SHAPES = [(16, 16), (32, 32), (48, 48), (64, 64), (80, 80), (96, 96), (112, 112), (32, 16), (64, 32), (96, 48),
                (128, 64), (160, 80), (192, 96), (16, 32), (96, 112)]
