@@ -124,11 +124,12 @@ size_t gpn_rulebook_down_ws_bytes(int64_t N);
 int gpn_rulebook_down(const int32_t* indices, int64_t N, int64_t batch_size,
                       const int32_t* spatial_shape_host, int32_t* out_indices, int32_t* fine_to_coarse, int32_t* tap, int64_t* num_out,
                       void* ws, size_t ws_bytes, gpn_stream_t stream);
-/* the K = 1 rulebook of a SubMConv3d(k=1) / linear layer over n rows (every row its own neighbour): rows [max(n,1)] (serves as
+/* the K = 1 rulebook of a SubMConv3d(k=1) (network/backbone.py:19-20, the residual blocks' shortcut) / linear layer over n rows
+ * (every row its own neighbour): rows [max(n,1)] (serves as
  * pair_src and pair_dst), tile_off [n_tiles + 1], nbr [n + 1], num_pairs [1] - one launch instead of seven torch ops */
 int gpn_rulebook_identity(int64_t n, int32_t* rows, int32_t* tile_off, int32_t* nbr, int64_t* num_pairs, gpn_stream_t stream);
-/* row counts of ALL coarse levels below a voxel set in one pass (what n_levels successive gpn_rulebook_down calls would
- * report in num_out): counts [n_levels] i64 on the device, so that a U-Net's rulebook pyramid costs ONE host read instead of
+/* row counts of ALL coarse levels below a voxel set in one pass (what n_levels successive gpn_rulebook_down calls - the
+ * SparseConv3d(k=2,s=2) of every UBlock, network/backbone.py:74-77 - would report in num_out): counts [n_levels] i64 on the device, so that a U-Net's rulebook pyramid costs ONE host read instead of
  * one per level; gpn_rulebook_down itself is unchanged (its num_out is then only a cross-check).  n_dev (optional, device):
  * the number of valid rows when indices is an upper-bound buffer. */
 size_t gpn_rulebook_level_counts_ws_bytes(int64_t n_max, int n_levels);
