@@ -165,6 +165,9 @@ def tile_order(nbr, K, n):
     return perm, nbr_p
 
 
+_CHECK_LEVEL_COUNTS = _os.environ.get("GPN_CHECK_LEVEL_COUNTS") == "1"
+
+
 def rulebook_identity(n, device) -> Rulebook:
     """the K = 1 rulebook over ``n`` rows (SubMConv3d(k=1), linear layers on the conv kernels) in one launch"""
     rows = torch.empty((max(n, 1),), dtype=torch.int32, device=device)[:n]
@@ -206,6 +209,8 @@ def rulebook_down(indices, spatial_shape, batch_size, n_out=None):
                               ptr(f2c), ptr(tap), ptr(nout), ptr(ws), szt(ws.numel()), _stream()),
           "gpn_rulebook_down")
     No = int(nout.item()) if n_out is None else int(n_out)
+    if n_out is not None and _CHECK_LEVEL_COUNTS:  # debug aid: the caller's count against the one this call computed (a host read)
+        assert int(nout.item()) == No, f"rulebook_down: caller passed n_out={No}, the level has {int(nout.item())} rows"
     cap = max(N, 1)
     fs = torch.empty((cap,), dtype=torch.int32, device=dev)
     fd = torch.empty((cap,), dtype=torch.int32, device=dev)
