@@ -8,6 +8,9 @@
  * the reference binaries; it is pinned instead against independent oracles in tests/ (torch dense
  * conv3d, numpy unique, scipy connected_components, torch.cdist, torch.segment_reduce).  The
  * PointNet++ family (F) follows the vendored CUDA sources line by line and is cited per kernel.
+ * What IS pinned to the reference itself: everything around these operators - the reference's own
+ * model.py / backbone.py / grouping_utils.py / dataset code run unmodified over this oracle generated
+ * tests/golden/{glue_step,loader,eval_ap}.npz (tests/golden/make_golden_pipeline.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no fused multiply-add, so distance and
