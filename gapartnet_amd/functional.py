@@ -135,8 +135,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     K = 1 cases of the fused conv kernel family (forward, dgrad, wgrad): at [160k, 16] x [16, 3..27] the library GEMMs
     the framework dispatches to run at 0.2-0.4 TFLOP/s (fwd+bwd 260-380 us per layer vs 200-250 here).
     Falls back to F.linear for shapes the kernels do not cover."""
-    if (backend.raw().name != "hip" or not x.is_cuda or x.dim() != 2 or x.shape[1] % 16 != 0 or x.shape[0] < 4096
-            or x.dtype != torch.float32):
+    if (backend.raw().name != "hip" or not x.is_cuda or x.dim() != 2 or x.shape[1] % 16 != 0 or x.shape[0] < 16
+            or x.dtype != torch.float32):  # (small row counts too: the library GEMM costs 165 us of host time per call)
         return F.linear(x, weight, bias)
     return _LinearFn.apply(x, weight, bias)
 

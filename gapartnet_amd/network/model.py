@@ -294,7 +294,7 @@ class GAPartNet(LightningModule):
         feats = self.score_unet(voxel_tensor)
         feats = GF.gather_rows(feats.features, pc_voxel_id, getattr(voxel_tensor, "point_csr", None))
         pooled, _ = segmented_maxpool(feats, offsets[:-1], offsets[1:])
-        return self.score_head(pooled)
+        return GF.linear(pooled, self.score_head.weight, self.score_head.bias)
 
     def loss_proposal_score(self, score_logits: torch.Tensor, proposals: Instances,
                             num_points_per_instance: torch.Tensor) -> torch.Tensor:
