@@ -43,6 +43,10 @@ struct WsCarver {
   bool ok() const { return used <= cap && (base != nullptr || used == 0); }
 };
 
+// gpn_spconv_fwd_ordered with an "add to out" mode (spconv_fwd.hip); used by the network executor's backward (net.hip)
+int spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p, const int32_t* perm, int K,
+                    int64_t n_dst, int cin, int cout, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+
 }  // namespace gpn
 
 #define GPN_CHECK_ARG(cond)                                                     \

@@ -533,12 +533,11 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
           gpn::set_error("%s: op %d: null gradient buffer / transposed table", __func__, i);
           return GPN_ERR_ARG;
         }
-        GradTarget t = grad_target(s0, tmp);
-        rc = gpn_spconv_fwd_ordered(d.grad, packed_of[i], rb.nbr_t, rb.nbr_t_p, rb.perm_t, rb.K, rb.n_src, cv.cout, cv.cin,
-                                    t.ptr, op_ws, op_ws_bytes, stream_);
+        // a slot that already holds a gradient takes this one added in place (no staging buffer, no accumulate launch)
+        rc = gpn::spconv_fwd_into(d.grad, packed_of[i], rb.nbr_t, rb.nbr_t_p, rb.perm_t, rb.K, rb.n_src, cv.cout, cv.cin, s0.grad,
+                                  s0.grad_state ? 1 : 0, op_ws, op_ws_bytes, stream);
         if (rc) return rc;
-        rc = commit(s0, t, stream);
-        if (rc) return rc;
+        s0.grad_state = 1;
       }
     } else if (op.kind == GPN_NET_BN) {
       const gpn_net_bn_t& bn = bns[op.param];

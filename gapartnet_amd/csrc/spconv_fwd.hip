@@ -47,7 +47,7 @@ struct StageCursor {
 template <int NTW, int CW, int NS>  // NS = slab float4 per thread = ceil(SLAB_V4 / blockDim.x)
 __global__ void spconv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                   const int32_t* __restrict__ nbr, int K, int64_t n_dst, int cin, int nt_total,
-                                  int taps_per_split, float* __restrict__ out) {
+                                  int taps_per_split, int accumulate, float* __restrict__ out) {
   using C = FwdCfg<NTW, CW>;
   constexpr int SLAB_V4 = C::SLAB_V4, D = C::D, E = 2 * C::D;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -171,12 +171,15 @@ __global__ void spconv_fwd_kernel(const float* __restrict__ in, const float* __r
     if (row < n_dst) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)
-        if (nt < ntw) outz[row * cout + (nt0 + nt) * 16 + i16] = acc[nt][r];
+        if (nt < ntw) {
+          float* o = outz + row * cout + (nt0 + nt) * 16 + i16;
+          *o = accumulate ? *o + acc[nt][r] : acc[nt][r];  // (accumulate: a second gradient of the same rows, added in place)
+        }
     }
   }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int splits, int64_t elems4,
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int splits, int64_t elems4, int accumulate,
                                        float* __restrict__ out) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= elems4) return;
@@ -192,7 +195,8 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int sp
     acc += v3;
   }
   for (; s < splits; ++s) acc += p[(int64_t)s * elems4 + t];
-  reinterpret_cast<f32x4*>(out)[t] = acc;
+  f32x4* o = reinterpret_cast<f32x4*>(out) + t;
+  *o = accumulate ? *o + acc : acc;
 }
 
 struct FwdPlan {
@@ -230,36 +234,36 @@ FwdPlan plan_fwd(int K, int64_t n_dst, int cin, int cout) {
 
 template <int NTW, int CW, int NS>
 int launch_fwd(const FwdPlan& p, const float* in, const float* packed, const int32_t* nbr, int K, int64_t n_dst,
-               int cin, int nt_total, float* out, hipStream_t stream) {
+               int cin, int nt_total, int accumulate, float* out, hipStream_t stream) {
   const int64_t tiles = gpn::cdiv(n_dst, 16);
   const dim3 grid((unsigned)gpn::cdiv(tiles, p.wpb), (unsigned)gpn::cdiv(nt_total, NTW), (unsigned)p.splits);
   const size_t lds = FwdCfg<NTW, CW>::lds_bytes;
   hipLaunchKernelGGL((spconv_fwd_kernel<NTW, CW, NS>), grid, dim3(p.wpb * 64), lds, stream, in, packed, nbr, K, n_dst,
-                     cin, nt_total, p.taps_per_split, out);
+                     cin, nt_total, p.taps_per_split, accumulate, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
 template <int NTW, int CW>
 int dispatch_ns(const FwdPlan& p, const float* in, const float* packed, const int32_t* nbr, int K, int64_t n_dst,
-                int cin, int nt_total, float* out, hipStream_t stream) {
+                int cin, int nt_total, int accumulate, float* out, hipStream_t stream) {
   constexpr int SLAB_V4 = FwdCfg<NTW, CW>::SLAB_V4;
   const int ns = (int)gpn::cdiv(SLAB_V4, p.wpb * 64);
   switch (ns) {
-    case 1: return launch_fwd<NTW, CW, 1>(p, in, packed, nbr, K, n_dst, cin, nt_total, out, stream);
-    case 2: return launch_fwd<NTW, CW, 2>(p, in, packed, nbr, K, n_dst, cin, nt_total, out, stream);
-    case 3: return launch_fwd<NTW, CW, 3>(p, in, packed, nbr, K, n_dst, cin, nt_total, out, stream);
-    default: return launch_fwd<NTW, CW, 4>(p, in, packed, nbr, K, n_dst, cin, nt_total, out, stream);
+    case 1: return launch_fwd<NTW, CW, 1>(p, in, packed, nbr, K, n_dst, cin, nt_total, accumulate, out, stream);
+    case 2: return launch_fwd<NTW, CW, 2>(p, in, packed, nbr, K, n_dst, cin, nt_total, accumulate, out, stream);
+    case 3: return launch_fwd<NTW, CW, 3>(p, in, packed, nbr, K, n_dst, cin, nt_total, accumulate, out, stream);
+    default: return launch_fwd<NTW, CW, 4>(p, in, packed, nbr, K, n_dst, cin, nt_total, accumulate, out, stream);
   }
 }
 
 template <int NTW>
 int dispatch_cw(const FwdPlan& p, const float* in, const float* packed, const int32_t* nbr, int K, int64_t n_dst,
-                int cin, int nt_total, float* out, hipStream_t stream) {
+                int cin, int nt_total, int accumulate, float* out, hipStream_t stream) {
   switch (p.cw) {
-    case 1: return dispatch_ns<NTW, 1>(p, in, packed, nbr, K, n_dst, cin, nt_total, out, stream);
-    case 2: return dispatch_ns<NTW, 2>(p, in, packed, nbr, K, n_dst, cin, nt_total, out, stream);
-    default: return dispatch_ns<NTW, 4>(p, in, packed, nbr, K, n_dst, cin, nt_total, out, stream);
+    case 1: return dispatch_ns<NTW, 1>(p, in, packed, nbr, K, n_dst, cin, nt_total, accumulate, out, stream);
+    case 2: return dispatch_ns<NTW, 2>(p, in, packed, nbr, K, n_dst, cin, nt_total, accumulate, out, stream);
+    default: return dispatch_ns<NTW, 4>(p, in, packed, nbr, K, n_dst, cin, nt_total, accumulate, out, stream);
   }
 }
 
@@ -286,7 +290,8 @@ template <int KT, int CB>
 __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                                                 const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
                                                                 int64_t units, size_t packed_bytes,
-                                                                const int32_t* __restrict__ perm, float* __restrict__ out) {
+                                                                const int32_t* __restrict__ perm, int accumulate,
+                                                                float* __restrict__ out) {
   constexpr int S = KT * CB;
   constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;  // prefetch depth in stages
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -394,17 +399,20 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + 4 * g + r;
-    if (row < n_dst) out[(uint32_t)orow[r] * (uint32_t)cout + (uint32_t)(nt * 16 + i16)] = acc[r];
+    if (row < n_dst) {
+      float* o = out + ((uint32_t)orow[r] * (uint32_t)cout + (uint32_t)(nt * 16 + i16));
+      *o = accumulate ? *o + acc[r] : acc[r];  // (accumulate: a second gradient of the same rows, added in place)
+    }
   }
 }
 
 template <int KT, int CB>
 int launch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int nt_total,
-                  float* out, hipStream_t stream) {
+                  int accumulate, float* out, hipStream_t stream) {
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
   hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4), 8) * 8)), dim3(256), 0, stream, in, packed,
-                     nbr, n_dst, nt_total, units, packed_bytes, perm, out);
+                     nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -427,18 +435,18 @@ bool use_direct(int K, int64_t n_dst, int cin, int cout) {
 
 template <int KT>
 int dispatch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int cin,
-                    int nt_total, float* out, hipStream_t stream) {
+                    int nt_total, int accumulate, float* out, hipStream_t stream) {
   switch (cin / 16) {
-    case 1: return launch_direct<KT, 1>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
-    case 2: return launch_direct<KT, 2>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
-    case 3: return launch_direct<KT, 3>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
-    case 4: return launch_direct<KT, 4>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
-    case 5: return launch_direct<KT, 5>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
-    case 6: return launch_direct<KT, 6>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
-    case 7: return launch_direct<KT, 7>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
-    case 8: return launch_direct<KT, 8>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
-    case 10: return launch_direct<KT, 10>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
-    default: return launch_direct<KT, 12>(in, packed, nbr, perm, n_dst, nt_total, out, stream);
+    case 1: return launch_direct<KT, 1>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    case 2: return launch_direct<KT, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    case 3: return launch_direct<KT, 3>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    case 4: return launch_direct<KT, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    case 5: return launch_direct<KT, 5>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    case 6: return launch_direct<KT, 6>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    case 7: return launch_direct<KT, 7>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    case 8: return launch_direct<KT, 8>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    case 10: return launch_direct<KT, 10>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    default: return launch_direct<KT, 12>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
   }
 }
 
@@ -453,8 +461,15 @@ extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cou
 
 extern "C" int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p,
                                       const int32_t* perm, int K, int64_t n_dst, int cin, int cout, float* out,
-                                      void* ws, size_t ws_bytes, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+                                      void* ws, size_t ws_bytes, gpn_stream_t stream) {
+  return gpn::spconv_fwd_into(in, packed_w, nbr, nbr_p, perm, K, n_dst, cin, cout, out, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// out = conv (accumulate == 0) or out += conv (the network executor's second gradient of a slot: same value as staging the
+// conv's result and adding it with a separate launch, which is what it replaces)
+int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p, const int32_t* perm,
+                         int K, int64_t n_dst, int cin, int cout, float* out, int accumulate, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
   GPN_CHECK_ARG((nbr_p == nullptr) == (perm == nullptr));
   GPN_CHECK_ARG(K >= 1 && n_dst >= 0);
   GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
@@ -464,8 +479,8 @@ extern "C" int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, co
   if (use_direct(K, n_dst, cin, cout)) {
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
     const int32_t* table = nbr_p ? nbr_p : nbr;
-    return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, out, stream)
-                   : dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, out, stream);
+    return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, out, stream)
+                   : dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, out, stream);
   }
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   float* target = out;
@@ -480,15 +495,15 @@ extern "C" int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, co
   {
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
     switch (p.ntw) {
-      case 1: rc = dispatch_cw<1>(p, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
-      case 2: rc = dispatch_cw<2>(p, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
-      case 3: rc = dispatch_cw<3>(p, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
-      default: rc = dispatch_cw<4>(p, in, packed_w, nbr, K, n_dst, cin, nt, target, stream); break;
+      case 1: rc = dispatch_cw<1>(p, in, packed_w, nbr, K, n_dst, cin, nt, p.splits > 1 ? 0 : accumulate, target, stream); break;
+      case 2: rc = dispatch_cw<2>(p, in, packed_w, nbr, K, n_dst, cin, nt, p.splits > 1 ? 0 : accumulate, target, stream); break;
+      case 3: rc = dispatch_cw<3>(p, in, packed_w, nbr, K, n_dst, cin, nt, p.splits > 1 ? 0 : accumulate, target, stream); break;
+      default: rc = dispatch_cw<4>(p, in, packed_w, nbr, K, n_dst, cin, nt, p.splits > 1 ? 0 : accumulate, target, stream); break;
     }
     if (rc == GPN_OK && p.splits > 1) {
       const int64_t elems4 = n_dst * cout / 4;
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)gpn::cdiv(elems4, 256)), dim3(256), 0, stream, target,
-                         p.splits, elems4, out);
+                         p.splits, elems4, accumulate, out);
       hipError_t e_ = hipGetLastError();
       if (e_ != hipSuccess) { gpn::set_error("gpn_spconv_fwd: reduce launch failed: %s", hipGetErrorString(e_)); rc = GPN_ERR_HIP; }
     }
