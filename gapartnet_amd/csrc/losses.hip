@@ -98,10 +98,16 @@ __global__ __launch_bounds__(kThreads) void point_losses_fwd_kernel(
 
 __global__ void point_losses_finalize_kernel(const double* __restrict__ partial, int blocks, int64_t M,
                                              float* __restrict__ losses /* [4] */, Stats* __restrict__ stats) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: lane l sums the partials of workgroups l, l + 64, ... in that order, then a fixed-order shuffle tree
+  // (deterministic; a single thread walking all ~600 partials was a 58 us chain of dependent loads)
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   double s[6] = {0, 0, 0, 0, 0, 0};
-  for (int b = 0; b < blocks; ++b)
+  for (int b = threadIdx.x; b < blocks; b += 64)
     for (int k = 0; k < 6; ++k) s[k] += partial[(int64_t)b * 6 + k];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+    for (int k = 0; k < 6; ++k) s[k] += __shfl_down(s[k], off, 64);
+  if (threadIdx.x != 0) return;
   losses[0] = s[4] > 0 ? (float)(s[0] / s[4]) : 0.f;  // focal: 0 for an all-ignored batch
   losses[1] = (float)(s[1] / (double)M);
   losses[2] = (float)(s[2] / s[5]);                   // NaN when no point is on a part (as x[mask].mean())

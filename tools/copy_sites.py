@@ -32,7 +32,9 @@ import traceback
 from torch.utils._python_dispatch import TorchDispatchMode
 
 WATCH = {"aten.copy_.default", "aten._to_copy.default", "aten._local_scalar_dense.default", "aten.nonzero.default",
-         "aten.fill_.Scalar", "aten.cat.default", "aten.index.Tensor", "aten.zero_.default", "aten.lift_fresh.default"}
+         "aten.fill_.Scalar", "aten.cat.default", "aten.index.Tensor", "aten.zero_.default", "aten.lift_fresh.default",
+         "aten.zeros.default", "aten.zeros_like.default", "aten.full.default", "aten.ones.default", "aten.ones_like.default",
+         "aten.clone.default", "aten.new_zeros.default", "aten.fill_.Tensor", "aten.constant_pad_nd.default"}
 sites = defaultdict(lambda: [0, 0.0])
 
 

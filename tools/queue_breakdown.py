@@ -20,5 +20,5 @@ for q, ks in sorted(per_q.items(), key=lambda kv: -sum(v[1] for v in kv[1].value
     total = sum(v[1] for v in ks.values())
     n = sum(v[0] for v in ks.values())
     print(f"queue {q}: {total / steps / 1e3:.2f} ms of kernels per step, {n / steps:.0f} launches per step")
-    for name, (c, t) in sorted(ks.items(), key=lambda kv: -kv[1][1])[:12]:
+    for name, (c, t) in sorted(ks.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"    {t / steps:8.1f} us/step {c / steps:7.1f} x  {name}")
