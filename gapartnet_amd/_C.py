@@ -54,6 +54,8 @@ def lib():
         _lib.gpn_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64t, i32t, i32t, i32t, vp, vp, vp, vp, vp, st, vp]
         _lib.gpn_gather_rows.argtypes = [vp, vp, i64t, i32t, vp, vp]
         _lib.gpn_scatter_rows_csr.argtypes = [vp, vp, vp, i64t, i32t, vp, vp]
+        _lib.gpn_spconv_tiles_min_tiles.argtypes = [i64t]
+        _lib.gpn_spconv_tiles_min_tiles.restype = i64t
     return _lib
 
 

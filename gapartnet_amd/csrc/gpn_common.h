@@ -47,6 +47,11 @@ struct WsCarver {
 int spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p, const int32_t* perm, int K,
                     int64_t n_dst, int cin, int cout, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 
+// the masked-tile kernel (spconv_tiles.hip): which shapes it takes, and its launch
+bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout);
+int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
+                        int cin, int cout, int accumulate, float* out, hipStream_t stream);
+
 }  // namespace gpn
 
 #define GPN_CHECK_ARG(cond)                                                     \

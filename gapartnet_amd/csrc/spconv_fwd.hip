@@ -454,7 +454,7 @@ int dispatch_direct(const float* in, const float* packed, const int32_t* nbr, co
 
 extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout) {
   if (n_dst <= 0 || cin < 16 || cout < 16) return 0;
-  if (use_direct(K, n_dst, cin, cout)) return 0;
+  if (gpn::spconv_tiles_supported(K, n_dst, cin, cout) || use_direct(K, n_dst, cin, cout)) return 0;
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   return p.splits > 1 ? gpn::align_up((size_t)p.splits * n_dst * cout * sizeof(float)) : 0;
 }
@@ -476,6 +476,10 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
   if (n_dst == 0) return GPN_OK;
   GPN_CHECK_ARG(in && packed_w && nbr && out);
   const int nt = cout / 16;
+  if (gpn::spconv_tiles_supported(K, n_dst, cin, cout)) {  // the masked-tile kernel (spconv_tiles.hip): every layer of >= 16 tiles
+    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
+    return gpn::spconv_tiles_launch(in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, cout, accumulate, out, stream);
+  }
   if (use_direct(K, n_dst, cin, cout)) {
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
     const int32_t* table = nbr_p ? nbr_p : nbr;

@@ -1,0 +1,328 @@
+// spconv_tiles.hip — the masked-tile sparse convolution kernel (forward and dgrad launches) for gfx950, round 3.
+//
+// Same arithmetic as the direct kernel of spconv_fwd.hip (output-stationary: MFMA row i of a 16-row tile IS destination row
+// i for every tap, fp32 accumulators in registers, every output row written once, no atomics, v_mfma_f32_16x16x4_f32),
+// different work mapping.  The direct kernel spends ~26 VALU / SALU instructions of index, offset and skip handling per
+// (tile, tap, column tile) for 4 MFMAs and walks all K taps of every tile (profiles/r02_conv_ablation.txt: without loads
+// and without MFMAs it still takes 60 % of its time).  Here:
+//   * prologue, once per wave: the wave's column of the neighbour table for ALL K taps is read with a handful of coalesced
+//     loads that are in flight together (lane = (row of the wave, tap sub-slot): 64 entries per instruction), ballots find
+//     the taps any row of the wave has, and the gather offsets of exactly those taps are written - compacted, in tap order -
+//     to a per-wave LDS slab.  The long-latency table reads (HBM) are thereby paid once and kept out of the main loop:
+//     vmcnt counts loads in issue order, so a table read requested ahead inside the loop would hold up every younger
+//     operand load of the same wave (the first version of this kernel did that: 1 us per tap).
+//   * main loop over the LIVE taps only (scalar bit scan, dynamic trip count; a dead tap costs nothing): per (tap, row tile)
+//     one ds_read of the offset and one v_add, per 16-channel input block R row-gathers + NT weight fragments (1 KiB from
+//     L2, shared by the R row tiles) feeding R x NT x 4 MFMAs.  Groups of U taps per iteration (~32 MFMAs), straight-line
+//     body with unconditional buffer loads (an absent neighbour reads at an out-of-range offset: zeros, no memory access),
+//     so the compiler interleaves loads and MFMAs and emits counted s_waitcnt; what latency remains is covered by the
+//     other waves of the SIMD (<= 64 VGPRs: 8 resident).
+//   * the rulebook's TILE ORDER (gpn_rulebook_tile_order: rows sorted by neighbour mask inside 4096-row blocks) makes the
+//     rows of a tile share their taps: 2.4x (level 0) / 1.4x (levels 1, 2) the MFMA row-slots of the useful pairs instead
+//     of 4.3x / 2.2x / 2.0x in voxel order; a stride-2 / inverse conv drops from 4.4x to 1.0-1.3x.
+//   * a wave owns ONE row tile and NT (1..7) column tiles (the widest divisor of the layer's column tiles that still leaves
+//     ~1500 waves: cols_per_wave below).  R = 2 row tiles per wave - half the waves, a weight fragment shared by both - is
+//     implemented (template parameter) and measured 25-38 % slower at the 80k-row level: the kernel lives on the number of
+//     waves a SIMD interleaves.
+// (A hand-rolled register ring across loop iterations was tried first: hipcc 7.2 hoists the requests above the MFMAs that
+// still read the slot, gives them fresh registers and closes every iteration with s_waitcnt vmcnt(0) and a block of v_mov
+// copies - nothing stays in flight across iterations; scheduling barriers do not hold buffer loads back.)
+// Summation order per output element = the direct kernel's: ascending tap, a tap's input blocks and channels in one MFMA
+// chain, the taps' sums added in fp32 (two-level); taps a row does not have add exact zeros, so the result does not depend
+// on the tile order, equals the direct kernel's bit for bit and is deterministic.
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+
+#include "gpn_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMaxTaps = 27;
+
+constexpr int cfg_group(int CB, int R, int NT) {  // taps per iteration of the main loop: ~32 MFMAs
+  const int per_tap = CB * R * NT * 4;
+  const int U = (32 + per_tap - 1) / per_tap;
+  return U < 1 ? 1 : (U > 4 ? 4 : U);
+}
+
+template <int CB, int NT, int R>
+__global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restrict__ in, const float* __restrict__ packed,
+                                                           const int32_t* __restrict__ nbr, const int32_t* __restrict__ perm,
+                                                           int K, int64_t n_dst, int n_tiles, int n_units, int nt_total,
+                                                           int col_groups, size_t packed_bytes, int accumulate,
+                                                           float* __restrict__ out) {
+  constexpr int U = cfg_group(CB, R, NT);
+  constexpr int RW = R * 16;        // rows of a wave
+  constexpr int TPI = 64 / RW;      // taps covered by one table load of the prologue
+  constexpr int NI = (kMaxTaps + TPI - 1) / TPI;
+  constexpr uint32_t kOob = 0x80000000u;
+  __shared__ uint32_t slab[4][kMaxTaps + 1][RW];  // per wave: byte offset of the gathered row (kOob = none) by live-tap slot
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  // workgroups are dealt round-robin to the 8 XCDs: every XCD takes one contiguous eighth of the units (the rows its waves
+  // gather are fetched into ONE L2)
+  const int wg = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  const int unit = __builtin_amdgcn_readfirstlane(wg * 4 + wave);
+  if (unit >= n_units) return;  // whole wave; no barrier in this kernel
+  const int rg = unit / col_groups;
+  const int nt0 = (unit - rg * col_groups) * NT;
+  const int tile0 = rg * R;
+  constexpr int cin = CB * 16;
+  const int cout = nt_total * 16;
+
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t nbr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(nbr), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed), 0, (int)packed_bytes, 0x00020000);
+  const uint32_t col_bytes = (uint32_t)n_dst * 4u;
+
+  // ---- prologue: table column of the wave's rows, all taps; live taps; compacted offsets into the slab --------------------
+  const int lr = lane % RW, lt = lane / RW;
+  const int64_t pos = (int64_t)tile0 * 16 + lr;
+  const bool row_ok = pos < n_dst;
+  const uint32_t tvoff = (uint32_t)(row_ok ? pos : n_dst - 1) * 4u;
+  int32_t raw[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int tap = i * TPI + lt;
+    const int tc = tap < K ? tap : 0;  // (lanes past the last tap re-read tap 0 and are masked below)
+    raw[i] = -1;
+    if (i * TPI < K)  // (uniform: a K = 8 table needs 2-4 of the loads)
+      raw[i] = __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(tvoff + (uint32_t)tc * col_bytes), 0, 0));
+  }
+  uint32_t um = 0;  // bit k = some row of the wave has tap k
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int tap = i * TPI + lt;
+    const bool valid = row_ok && tap < K && raw[i] >= 0;
+    const uint64_t b = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (int s = 0; s < TPI; ++s) {
+      const uint64_t sub = RW == 32 ? (b >> (32 * s)) & 0xffffffffull : (b >> (16 * s)) & 0xffffull;
+      if (sub != 0 && i * TPI + s < kMaxTaps) um |= 1u << (i * TPI + s);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int tap = i * TPI + lt;
+    const bool valid = row_ok && tap < K && raw[i] >= 0;
+    const bool live = tap < kMaxTaps && ((um >> tap) & 1u) != 0u;
+    const int slot = __builtin_popcount(um & ((1u << tap) - 1u));
+    if (live) slab[wave][slot][lr] = valid ? (uint32_t)raw[i] * (uint32_t)(cin * 4) : kOob;
+  }
+  int remaining = __builtin_popcount(um);
+
+  f32x4 acc[R][NT];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < R; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = zero;
+
+  const uint32_t bvoff = (uint32_t)lane * 16u;
+  const uint32_t g16 = (uint32_t)g * 16u;
+  int slot0 = 0;
+  auto pop = [&]() -> int {  // next live tap (ascending)
+    const int k = __builtin_ctz(um);
+    um &= um - 1u;
+    return k;
+  };
+  // one group of UU live taps, straight-line: offsets from the slab, all operands of the UU x CB stages, their MFMAs
+  auto group = [&](auto uu_tag) {
+    constexpr int UU = decltype(uu_tag)::value;
+    uint32_t aoff[UU][R];
+    int kk[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+      kk[u] = pop();
+#pragma unroll
+      for (int t = 0; t < R; ++t) aoff[u][t] = slab[wave][slot0 + u][t * 16 + i16] + g16;  // (kOob + g16 stays out of range)
+    }
+    slot0 += UU;
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+      // two-level summation, as the direct kernel: a tap's CB * 16 products accumulate in `part` (one MFMA chain from zero),
+      // the taps' sums are added to `acc` - rounding error grows with sqrt(16 CB) + sqrt(K) terms instead of sqrt(16 CB K)
+      // (2e-7 instead of 6e-7 relative; BatchNorm on the small deep levels amplifies it ~1000x in backward: with one chain
+      // the golden-pipeline gradient bound of 1e-3 x max|g| is missed by 3 %)
+      f32x4 part[R][NT];
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) part[t][nt] = zero;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        f32x4 a[R], b[NT];
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+          a[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)aoff[u][t], cb * 64, 0));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          b[nt] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)bvoff, ((kk[u] * CB + cb) * nt_total + nt0 + nt) * 1024, 0));
+        // column tiles interleaved: a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles, an independent one after 32
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < R; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              part[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b[nt][s], part[t][nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] += part[t][nt];
+    }
+  };
+  while (remaining >= U) {
+    remaining -= U;
+    group(std::integral_constant<int, U>());
+  }
+  if constexpr (U > 1) {
+    while (remaining > 0) {  // fewer than U taps left, one at a time
+      remaining -= 1;
+      group(std::integral_constant<int, 1>());
+    }
+  }
+
+  // ---- D[row = 4g + r][col = i16] of every (row tile, column tile) -> out ----------------------------------------------
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    const int tile = tile0 + t;
+    if (tile < n_tiles) {
+      int32_t orow[4];
+      if (perm) {
+        const int4 pv = *reinterpret_cast<const int4*>(perm + (int64_t)tile * 16 + 4 * g);
+        orow[0] = pv.x, orow[1] = pv.y, orow[2] = pv.z, orow[3] = pv.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) orow[r] = tile * 16 + 4 * g + r;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if ((int64_t)tile * 16 + 4 * g + r < n_dst) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float* o = out + ((uint32_t)orow[r] * (uint32_t)cout + (uint32_t)((nt0 + nt) * 16 + i16));
+            *o = accumulate ? *o + acc[t][nt][r] : acc[t][nt][r];  // (accumulate: a second gradient of the same rows, added in place)
+          }
+        }
+      }
+    }
+  }
+}
+
+std::atomic<int64_t> g_min_tiles{[] {
+  const char* e = getenv("GPN_TILES_MIN_TILES");
+  return (int64_t)(e ? atoll(e) : 4096);
+}()};
+
+int tiles_mode() {  // GPN_CONV_TILES=0: off (the direct kernel of spconv_fwd.hip runs instead; A/B switch for measurements)
+  static const int mode = [] {
+    const char* e = getenv("GPN_CONV_TILES");
+    return e ? atoi(e) : 1;
+  }();
+  return mode;
+}
+int min_waves() {  // a launch takes as many column tiles per wave as still leave this many waves
+  static const int v = [] {
+    const char* e = getenv("GPN_TILES_MIN_WAVES");
+    return e ? atoi(e) : 1536;
+  }();
+  return v;
+}
+
+template <int CB, int NT>
+int launch_tiles(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
+                 int nt_total, int accumulate, float* out, hipStream_t stream) {
+  constexpr int R = 1;
+  const int n_tiles = (int)gpn::cdiv(n_dst, 16);
+  const int col_groups = nt_total / NT;
+  const int n_units = (int)gpn::cdiv(n_tiles, R) * col_groups;
+  const size_t packed_bytes = (size_t)K * CB * nt_total * 1024;
+  const dim3 grid((unsigned)(gpn::cdiv(gpn::cdiv(n_units, 4), 8) * 8));
+  hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
+                     n_units, nt_total, col_groups, packed_bytes, accumulate, out);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+// Column tiles per wave (a divisor of the layer's nt_total, at most 7).  Measured on the bench's level shapes
+// (tools/conv_tiles_bench.py, profiles/r03_conv_wave_shapes.txt): what pays is the number of WAVES first - a wave is a
+// serial chain of (offset read, operand loads, MFMAs) per tap, and the SIMDs hide it only with several waves each - and
+// the reuse of a gathered row across column tiles second.  Two row tiles per wave (half the waves, weight fragments shared)
+// lost 25-38 % at the 80k-row level; one column tile per wave (rows re-gathered per column tile) loses as much where
+// >= 1536 waves are available with more.  So: the widest divisor that leaves >= 1536 waves, else two (if that still
+// gives 512 waves), else one.
+int cols_per_wave(int64_t n_tiles, int nt_total) {
+  for (int d = nt_total < 7 ? nt_total : 7; d >= 1; --d)
+    if (nt_total % d == 0 && n_tiles * (nt_total / d) >= min_waves()) return d;
+  return (nt_total % 2 == 0 && n_tiles * (nt_total / 2) >= 512) ? 2 : 1;
+}
+
+// input widths (16-channel blocks) the kernel is instantiated for: those of a residual U-Net with channels 16 (l + 1),
+// l < 7, and of its decoder convs behind the skip concats (2c -> c)
+#define GPN_TILES_CB(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(10) X(12) X(14)
+
+bool supported_width(int CB) {
+#define GPN_X(cb) if (CB == cb) return true;
+  GPN_TILES_CB(GPN_X)
+#undef GPN_X
+  return false;
+}
+
+template <int CB>
+int dispatch_cols(int NT, const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
+                  int nt_total, int accumulate, float* out, hipStream_t stream) {
+  switch (NT) {
+    case 1: return launch_tiles<CB, 1>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+    case 2: return launch_tiles<CB, 2>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+    case 3: return launch_tiles<CB, 3>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+    case 4: return launch_tiles<CB, 4>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+    case 5: return launch_tiles<CB, 5>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+    case 6: return launch_tiles<CB, 6>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+    default: return launch_tiles<CB, 7>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+  }
+}
+
+}  // namespace
+
+namespace gpn {
+
+bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout) {
+  if (tiles_mode() == 0) return false;
+  if (!(K >= 1 && K <= kMaxTaps) || cin % 16 || cout % 16) return false;
+  // 32-bit byte offsets: source rows (at most 8 n_dst of them, for a stride-2 conv), output rows, the neighbour table
+  if (n_dst * (int64_t)8 * std::max(cin, cout) * 4 >= ((int64_t)1 << 31) || (int64_t)K * n_dst * 4 >= ((int64_t)1 << 31)) return false;
+  // Below ~4096 tiles a launch has too few waves for the SIMDs to hide a wave's serial chain of (offset read, operand loads,
+  // MFMAs) per tap behind other waves: in the training step (cold table, operands written by the previous kernel) the
+  // direct kernel with its 4-stage operand ring and 10-tap index ring per wave is faster there (25k rows: 41 vs 48 us,
+  // 1.8k rows: 22 vs 28 us; profiles/r03_conv_in_situ.txt), this kernel is at 80k / 144k rows (44 vs 60 us, 26 vs 28 us).
+  if (gpn::cdiv(n_dst, 16) < std::max<int64_t>(g_min_tiles.load(std::memory_order_relaxed), 16)) return false;
+  return supported_width(cin / 16);
+}
+
+int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
+                        int cin, int cout, int accumulate, float* out, hipStream_t stream) {
+  const int CB = cin / 16, nt_total = cout / 16;
+  const int NT = cols_per_wave(gpn::cdiv(n_dst, 16), nt_total);
+#define GPN_X(cb) \
+  if (CB == cb) return dispatch_cols<cb>(NT, in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+  GPN_TILES_CB(GPN_X)
+#undef GPN_X
+  gpn::set_error("gpn_spconv_fwd: no masked-tile kernel for %d -> %d channels", cin, cout);
+  return GPN_ERR_ARG;
+}
+
+}  // namespace gpn
+
+// smallest layer (in 16-row tiles) the masked-tile kernel takes; smaller ones run on the direct / lock-step kernels of
+// spconv_fwd.hip.  min_tiles < 0 only queries.  Returns the previous value.  (Default 4096, env GPN_TILES_MIN_TILES; tests
+// and tools lower it to run the kernel on small inputs.)
+extern "C" int64_t gpn_spconv_tiles_min_tiles(int64_t min_tiles) {
+  return min_tiles < 0 ? g_min_tiles.load(std::memory_order_relaxed) : g_min_tiles.exchange(min_tiles, std::memory_order_relaxed);
+}

@@ -74,7 +74,7 @@ class Rulebook:
     num_pairs: torch.Tensor  # 0-dim int64 on device (no host sync)
     nbr: Optional[torch.Tensor] = None  # tap-major neighbour table [K*n_dst + 1] i32 (-1 = none) the fused conv gathers from
     # optional tile order of the large levels (gpn_rulebook_tile_order): the table with its columns sorted by neighbour
-    # mask inside 4096-row blocks, and the destination row of every tile position
+    # mask inside 16384-row blocks, and the destination row of every tile position
     nbr_p: Optional[torch.Tensor] = None
     perm: Optional[torch.Tensor] = None
 
@@ -138,23 +138,27 @@ def rulebook_subm3(indices, spatial_shape) -> Rulebook:
     nbr = torch.empty((27 * N + 1,), dtype=torch.int32, device=dev)
     check(L.gpn_rulebook_subm3(ptr(indices), i64(N), host_i32x3(spatial_shape), ptr(nbr), ptr(src), ptr(dst), ptr(toff),
                                ptr(npairs), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_subm3")
-    rb = Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr)
-    if N >= TILE_ORDER_MIN_ROWS:
-        rb.perm, rb.nbr_p = tile_order(nbr, 27, N)
-    return rb
+    return _with_tile_order(Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr))
 
 
 import os as _os
-# rows re-ordered by neighbour mask (gpn_rulebook_tile_order) paid off for the persistent streaming conv kernel (r1: 22.7 ->
-# 12.6 executed taps per tile at level 0); the direct kernel is insensitive to it (29.2 us per launch at level 0 either way,
-# tools/kernel_rooflines.py) while building the order costs a radix sort + a permuted table per level and step (level-0
-# rulebook 207 -> 113 us): off by default, GPN_TILE_ORDER_MIN_ROWS=16384 restores it
-TILE_ORDER_MIN_ROWS = int(_os.environ.get("GPN_TILE_ORDER_MIN_ROWS", 1 << 62))
-TILE_ORDER_BLOCK = 4096  # 1024: 3 % slower convs; 16k-128k: within 1 % (tools sweep), 4096 keeps tiles spatially local
+# Rows re-ordered by neighbour mask (gpn_rulebook_tile_order) for the masked-tile conv kernel (csrc/spconv_tiles.hip): a
+# tile executes a tap as soon as ANY of its rows has that neighbour.  In voxel order a level-0 tile of the bench scenes runs
+# 4.3x the MFMA row-slots of its useful pairs, sorted by mask inside 16384-row blocks 2.1x (levels 1 / 2: 2.2x / 2.0x ->
+# 1.4x; stride-2 convs 4.4x -> 1.3x, inverse convs 4.3x -> 1.0x; tools/conv_tiles_bench.py).  The order costs a radix sort
+# and a permuted table per rulebook; levels below 4096 tiles run on the direct kernel and keep voxel order.
+TILE_ORDER_MIN_ROWS = int(_os.environ.get("GPN_TILE_ORDER_MIN_ROWS", 65536))  # = the levels the masked-tile kernel takes
+TILE_ORDER_BLOCK = int(_os.environ.get("GPN_TILE_ORDER_BLOCK", 16384))
+
+
+def _with_tile_order(rb: "Rulebook") -> "Rulebook":
+    if rb.nbr is not None and rb.n_dst >= TILE_ORDER_MIN_ROWS:
+        rb.perm, rb.nbr_p = tile_order(rb.nbr, rb.K, rb.n_dst)
+    return rb
 
 
 def tile_order(nbr, K, n):
-    """-> (perm [ceil(n/16)*16 + 16] i32, nbr_p [K*n + 1] i32): rows of every 4096-row block sorted by neighbour mask"""
+    """-> (perm [ceil(n/16)*16 + 16] i32, nbr_p [K*n + 1] i32): rows of every 16384-row block sorted by neighbour mask"""
     dev = nbr.device
     L = _C.lib()
     perm = torch.empty(((n + 15) // 16 * 16 + 16,), dtype=torch.int32, device=dev)
@@ -226,8 +230,8 @@ def rulebook_down(indices, spatial_shape, batch_size, n_out=None):
                                     ptr(bs), ptr(bd), ptr(bt), ptr(npairs), ptr(ws), szt(ws.numel()), _stream()),
           "gpn_rulebook_down_lists")
     out_shape = [int(s) // 2 for s in spatial_shape]
-    rb_fwd = Rulebook(fs, fd, ft, 8, N, No, npairs[0], fn)
-    rb_bwd = Rulebook(bs, bd, bt, 8, No, N, npairs[0], bn)
+    rb_fwd = _with_tile_order(Rulebook(fs, fd, ft, 8, N, No, npairs[0], fn))
+    rb_bwd = _with_tile_order(Rulebook(bs, bd, bt, 8, No, N, npairs[0], bn))
     return out_idx[:No], out_shape, rb_fwd, rb_bwd
 
 
@@ -307,6 +311,27 @@ def _conv_w(features, W, layout, flags, rb: Rulebook, cin_op, cout_op):
                                 out.data_ptr(), ws_ptr, ws_size, stream)
     if rc:
         _raise("gpn_spconv_fwd_w")
+    return out
+
+
+def conv_fwd_ordered(features, W, rb: Rulebook, flags=0):
+    """conv over ``rb`` through gpn_spconv_fwd_ordered: uses the rulebook's tile order (nbr_p / perm) when it has one.
+    ``W`` canonical [K, Cin, Cout]; ``flags`` = PACK_TRANSPOSE | PACK_REVERSE turns the call into the dgrad of a SubM conv
+    (features = dout).  What the network executor does per layer; the per-layer autograd path (conv_fwd) passes the plain
+    table only."""
+    dev = _dev(features)
+    features = _c(features, torch.float32)
+    K, cin_w, cout_w = W.shape
+    cin, cout = (cout_w, cin_w) if flags & PACK_TRANSPOSE else (cin_w, cout_w)
+    assert features.shape == (rb.n_src, cin), (features.shape, rb.n_src, cin)
+    packed = pack_weights(W, flags)
+    out = torch.empty((rb.n_dst, cout), dtype=torch.float32, device=dev)
+    L = _C.lib()
+    ws_bytes = L.gpn_spconv_fwd_ws_bytes(i32(K), i64(rb.n_dst), i32(cin), i32(cout))
+    ws = _ws(ws_bytes, dev) if ws_bytes else None
+    check(L.gpn_spconv_fwd_ordered(ptr(features), ptr(packed), ptr(rb.nbr), ptr(rb.nbr_p), ptr(rb.perm), i32(K), i64(rb.n_dst),
+                                   i32(cin), i32(cout), ptr(out), ptr(ws), szt(ws.numel() if ws is not None else 0), _stream()),
+          "gpn_spconv_fwd_ordered")
     return out
 
 

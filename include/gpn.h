@@ -172,6 +172,9 @@ int gpn_spconv_fwd(const float* in, const float* packed_w, const int32_t* nbr, i
 int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p,
                            const int32_t* perm, int K, int64_t n_dst, int cin, int cout, float* out, void* ws,
                            size_t ws_bytes, gpn_stream_t stream);
+/* kernel selection knob: layers of >= min_tiles 16-row tiles run on the masked-tile kernel (csrc/spconv_tiles.hip), smaller
+ * ones on the direct / lock-step kernels; results are identical.  min_tiles < 0 queries.  Returns the previous value. */
+int64_t gpn_spconv_tiles_min_tiles(int64_t min_tiles);
 size_t gpn_spconv_fwd_w_ws_bytes(int K, int64_t n_dst, int cin, int cout);
 int gpn_spconv_fwd_w(const float* in, const float* W, int K, int cin_w, int cout_w, int pack_flags, const int32_t* nbr,
                      int64_t n_dst, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream);

@@ -192,6 +192,71 @@ def test_down_and_inverse_conv(H, cuda, cin, cout):
     assert np.allclose(dci, O.spconv_dgrad(gi, Wi, d["bwd"], N, No), atol=FP_TOL, rtol=1e-4)
 
 
+@pytest.fixture
+def tiles_everywhere():
+    """route every conv of >= 16 tiles through the masked-tile kernel (by default it takes layers of >= 4096 tiles)"""
+    from gapartnet_amd import _C
+    prev = _C.lib().gpn_spconv_tiles_min_tiles(16)
+    yield
+    _C.lib().gpn_spconv_tiles_min_tiles(prev)
+
+
+@pytest.mark.parametrize("cin,cout", CONV_SHAPES)
+def test_masked_tile_kernel_fwd_dgrad(H, cuda, tiles_everywhere, cin, cout):
+    """the masked-tile kernel (csrc/spconv_tiles.hip) on every channel pair of the U-Net, voxel order and tile order:
+    oracle values at 1e-4, and bit-equal to the direct kernel (same per-row summation order)"""
+    from gapartnet_amd import _C
+    rng = np.random.default_rng(cin * 1000 + cout + 7)
+    shape = [40, 40, 40]
+    idx = synth.surface_indices(rng, 2, shape, 1500)
+    N = idx.shape[0]
+    f = rng.normal(size=(N, cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    g = rng.normal(size=(N, cout)).astype(np.float32)
+    rb_ref = O.rulebook_subm3(idx, shape)
+    rb = H.rulebook_subm3(dev(idx, cuda), shape)
+    assert rb.perm is None
+    ref_out, ref_din = O.spconv_fwd(f, W, rb_ref, N), O.spconv_dgrad(g, W, rb_ref, N, N)
+    outs, dins = [], []
+    for ordered in (False, True):
+        if ordered:
+            rb.perm, rb.nbr_p = H.tile_order(rb.nbr, 27, N)
+        outs.append(H.conv_fwd_ordered(dev(f, cuda), dev(W, cuda), rb))
+        dins.append(H.conv_fwd_ordered(dev(g, cuda), dev(W, cuda), rb, flags=H.PACK_TRANSPOSE | H.PACK_REVERSE))
+        assert np.allclose(host(outs[-1]), ref_out, atol=FP_TOL, rtol=1e-4)
+        assert np.allclose(host(dins[-1]), ref_din, atol=FP_TOL, rtol=1e-4)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(dins[0], dins[1]), "the tile order must not change a bit"
+    prev = _C.lib().gpn_spconv_tiles_min_tiles(1 << 40)  # the direct kernel on the same inputs
+    try:
+        assert torch.equal(outs[0], H.conv_fwd_ordered(dev(f, cuda), dev(W, cuda), rb))
+    finally:
+        _C.lib().gpn_spconv_tiles_min_tiles(prev)
+
+
+def test_masked_tile_kernel_down_inverse_and_ragged_tail(H, cuda, tiles_everywhere):
+    """K = 8 tables (stride-2 conv and its inverse, rows without any tap), a row count that is not a multiple of 16,
+    and the accumulate form the executor's backward uses"""
+    rng = np.random.default_rng(99)
+    shape = [33, 40, 37]
+    idx = synth.random_sparse_indices(rng, 2, shape, 4001)
+    N = idx.shape[0]
+    d = O.rulebook_down(idx, shape)
+    No = d["out_indices"].shape[0]
+    _, _, rb_f, rb_b = H.rulebook_down(dev(idx, cuda), shape, 2)
+    for cin, cout in ((16, 32), (48, 64)):
+        f = rng.normal(size=(N, cin)).astype(np.float32)
+        W = (rng.normal(size=(8, cin, cout)) / np.sqrt(8 * cin)).astype(np.float32)
+        for ordered in (False, True):
+            for rb in (rb_f, rb_b):
+                rb.perm, rb.nbr_p = H.tile_order(rb.nbr, 8, rb.n_dst) if ordered else (None, None)
+            out = host(H.conv_fwd_ordered(dev(f, cuda), dev(W, cuda), rb_f))
+            ref = O.spconv_fwd(f, W, d["fwd"], No)
+            assert np.allclose(out, ref, atol=FP_TOL, rtol=1e-4)
+            Wi = (rng.normal(size=(8, cout, cin)) / np.sqrt(cout)).astype(np.float32)
+            up = host(H.conv_fwd_ordered(dev(ref, cuda), dev(Wi, cuda), rb_b))
+            assert np.allclose(up, O.spconv_fwd(ref, Wi, d["bwd"], N), atol=FP_TOL, rtol=1e-4)
+
+
 def test_conv_large_batch_uses_wide_tiles(H, cuda):
     """>= 4096 32-row tiles selects the 64-row wave tile variant."""
     rng = np.random.default_rng(11)
@@ -439,7 +504,7 @@ def test_grid_ball_query_is_bit_exact(H, cuda, case):
 
 
 def test_tile_ordered_conv_is_bit_equal(H, cuda):
-    """the rulebook's tile order (rows sorted by neighbour mask inside 4096-row blocks) changes which taps a tile skips,
+    """the rulebook's tile order (rows sorted by neighbour mask inside 16384-row blocks) changes which taps a tile skips,
     not a single output bit: forward and dgrad through (nbr_p, perm) == through the plain table"""
     import ctypes
     from gapartnet_amd import _C
@@ -455,7 +520,7 @@ def test_tile_ordered_conv_is_bit_equal(H, cuda):
     assert torch.equal(torch.sort(perm)[0], torch.arange(n, device=cuda)), "perm is a permutation"
     assert torch.equal(rb.nbr_p[:27 * n].view(27, n), rb.nbr[:27 * n].view(27, n)[:, perm])
     blocks = perm // H.TILE_ORDER_BLOCK
-    assert torch.equal(blocks, torch.sort(blocks)[0]), "rows stay inside their 4096-row block"
+    assert torch.equal(blocks, torch.sort(blocks)[0]), "rows stay inside their 16384-row block"
     L = _C.lib()
     for cin, cout in ((16, 16), (32, 32), (48, 48)):
         x = dev(rng.normal(size=(n, cin)).astype(np.float32), cuda)
