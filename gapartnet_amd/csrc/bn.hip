@@ -13,6 +13,7 @@
 // Small matrices (N <= kSmallRows: the deep levels of the U-Net, where a layer's kernels run at the
 // launch-latency floor) take a single-launch form instead: one workgroup per float4 column computes the statistics of
 // its four channels and applies them in a second sweep over the (L2-resident) column - one launch instead of three.
+#include "bn_stats.h"
 #include "gpn_common.h"
 
 namespace {
@@ -130,6 +131,27 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ partial
   __syncthreads();
 }
 
+// the same totals from a slab of fixed-point words a conv launch accumulated (bn_stats.h): word-threads (q, c) sum their
+// word over the 32 slot sets (coalesced across c), thread c combines the four exact integer sums
+template <bool BWD>
+__device__ __forceinline__ void fold_fixed(const unsigned long long* __restrict__ slab, int C, long long (*words)[kFoldMaxC],
+                                           double (*sums)[kFoldMaxC]) {
+  constexpr gpn::StatScale sc = BWD ? gpn::kStatScaleBwd() : gpn::kStatScaleFwd();
+  for (int e = threadIdx.x; e < 4 * C; e += kApplyThreads) {
+    const int q = e / C, c = e - q * C;
+    long long w = 0;
+#pragma unroll 8
+    for (int sl = 0; sl < gpn::kStatSlots; ++sl) w += (long long)slab[((size_t)sl * 4 + q) * C + c];
+    words[q][c] = w;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += kApplyThreads) {
+    sums[0][c] = ldexp((double)words[0][c], -sc.h0) + ldexp((double)words[1][c], -sc.l0);
+    sums[1][c] = ldexp((double)words[2][c], -sc.h1) + ldexp((double)words[3][c], -sc.l1);
+  }
+  __syncthreads();
+}
+
 // one 64-thread workgroup per channel sums the per-workgroup partials: strided per-lane sums, then a fixed-order
 // shuffle tree (deterministic); a serial loop over up to 512 partials per channel cost 25 us per layer
 __device__ __forceinline__ void sum_partials(const double* __restrict__ partial, int blocks, int C, int c, double& s,
@@ -227,16 +249,20 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ x, const float* __
 
 // ---- apply passes that fold the finalize (training; C <= kFoldMaxC) ------------------------------------------------------
 // thread t walks elements t, t + G*T, ...: its float4 column advances by (G*T) % C4 per step (no 64-bit modulo in the loop)
+template <bool FIXED>  // FIXED: `partial` is a slab of fixed-point words a conv launch accumulated (bn_stats.h)
 __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(
-    const float* __restrict__ x, const float* __restrict__ res, const double* __restrict__ partial, int blocks, int64_t N,
+    const float* __restrict__ x, const float* __restrict__ res, const void* __restrict__ partial, int blocks, int64_t N,
     const float* __restrict__ weight, const float* __restrict__ bias, int64_t total4, int C4, float eps, float momentum,
     int relu, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ invstd,
     float* __restrict__ running_mean, float* __restrict__ running_var) {
   __shared__ double red[2][kApplyThreads][4];
   __shared__ double sums[2][kFoldMaxC];
   __shared__ __attribute__((aligned(16))) float stat[2][kFoldMaxC];
-  fold_partials(partial, blocks, C4, red, sums);
   const int C = C4 * 4;
+  if constexpr (FIXED)
+    fold_fixed<false>(static_cast<const unsigned long long*>(partial), C, reinterpret_cast<long long (*)[kFoldMaxC]>(&red[0][0][0]), sums);
+  else
+    fold_partials(static_cast<const double*>(partial), blocks, C4, red, sums);
   for (int c = threadIdx.x; c < C; c += kApplyThreads) {
     const double m = sums[0][c] / (double)N;
     double var = sums[1][c] / (double)N - m * m;
@@ -275,16 +301,20 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(
   }
 }
 
+template <bool FIXED>
 __global__ __launch_bounds__(kApplyThreads) void bn_apply_bwd_fold_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-    const double* __restrict__ partial, int blocks, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const void* __restrict__ partial, int blocks, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ weight, int64_t total4, int C4, float inv_n, int relu, int training,
     float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dweight, float* __restrict__ dbias) {
   __shared__ double red[2][kApplyThreads][4];
   __shared__ double sums[2][kFoldMaxC];
   __shared__ __attribute__((aligned(16))) float grad[2][kFoldMaxC];  // dbias, dweight
-  fold_partials(partial, blocks, C4, red, sums);
   const int C = C4 * 4;
+  if constexpr (FIXED)
+    fold_fixed<true>(static_cast<const unsigned long long*>(partial), C, reinterpret_cast<long long (*)[kFoldMaxC]>(&red[0][0][0]), sums);
+  else
+    fold_partials(static_cast<const double*>(partial), blocks, C4, red, sums);
   for (int c = threadIdx.x; c < C; c += kApplyThreads) {
     const float db = (float)sums[0][c], dw = (float)sums[1][c];
     grad[0][c] = db;
@@ -530,8 +560,8 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
   GPN_CHECK_LAUNCH();
   const int64_t total4 = N * C4;
   if (C <= kFoldMaxC) {
-    hipLaunchKernelGGL(bn_apply_fwd_fold_kernel, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, res, partial,
-                       blocks, N, weight, bias, total4, C4, eps, momentum, relu, y, mean, invstd, running_mean,
+    hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<false>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, res,
+                       (const void*)partial, blocks, N, weight, bias, total4, C4, eps, momentum, relu, y, mean, invstd, running_mean,
                        running_var);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
@@ -590,8 +620,8 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
   GPN_CHECK_LAUNCH();
   const int64_t total4 = N * C4;
   if (C <= kFoldMaxC) {
-    hipLaunchKernelGGL(bn_apply_bwd_fold_kernel, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, y, dy, partial,
-                       blocks, mean, invstd, weight, total4, C4, 1.0f / (float)N, relu, training, dx, dres, dweight,
+    hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<false>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, y, dy,
+                       (const void*)partial, blocks, mean, invstd, weight, total4, C4, 1.0f / (float)N, relu, training, dx, dres, dweight,
                        dbias);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
@@ -601,6 +631,34 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
   GPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, y, dy, mean, invstd,
                      weight, dweight, dbias, total4, C4, 1.0f / (float)N, relu, training, dx, dres);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+// ---- apply passes over sums the producing conv launch accumulated (bn_stats.h; used by the network executor) ----------------
+bool gpn::bn_two_pass(int64_t N, int C) { return N > kSmallRows && C % 4 == 0 && C <= kFoldMaxC; }
+
+int gpn::bn_fwd_train_fused(const float* x, const float* res, const float* weight, const float* bias, int64_t N, int C,
+                            float eps, float momentum, int relu, float* y, float* mean, float* invstd, float* running_mean,
+                            float* running_var, const unsigned long long* slab, hipStream_t stream) {
+  GPN_CHECK_ARG(gpn::bn_two_pass(N, C) && x && weight && bias && y && mean && invstd && slab);
+  GPN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  const int64_t total4 = N * (C / 4);
+  hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<true>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, res,
+                     (const void*)slab, 0, N, weight, bias, total4, C / 4, eps, momentum, relu, y, mean, invstd, running_mean,
+                     running_var);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+int gpn::bn_bwd_fused(const float* x, const float* y, const float* dy, const float* weight, const float* mean,
+                      const float* invstd, int64_t N, int C, int relu, int training, float* dx, float* dres, float* dweight,
+                      float* dbias, const unsigned long long* slab, hipStream_t stream) {
+  GPN_CHECK_ARG(gpn::bn_two_pass(N, C) && x && dy && weight && mean && invstd && dx && dweight && dbias && slab && (y || !relu));
+  const int64_t total4 = N * (C / 4);
+  hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<true>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, y, dy,
+                     (const void*)slab, 0, mean, invstd, weight, total4, C / 4, 1.0f / (float)N, relu, training, dx, dres, dweight,
+                     dbias);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

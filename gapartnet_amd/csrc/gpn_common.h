@@ -43,14 +43,39 @@ struct WsCarver {
   bool ok() const { return used <= cap && (base != nullptr || used == 0); }
 };
 
-// gpn_spconv_fwd_ordered with an "add to out" mode (spconv_fwd.hip); used by the network executor's backward (net.hip)
-int spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p, const int32_t* perm, int K,
-                    int64_t n_dst, int cin, int cout, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+// BatchNorm column sums accumulated by the producing conv launch (bn_stats.h): what a conv's epilogue adds to.
+// slab == nullptr: nothing.  x == nullptr: statistics of the conv's OUTPUT (sum out, sum out^2; forward).  x != nullptr: the
+// launch is a dgrad that writes the final gradient g of a BatchNorm's output y = act(bn(x) [+ res]): sum g', sum g' xhat with
+// g' = g masked by the ReLU (y > 0) and xhat = (x - mean) invstd (backward).
+constexpr int kStatSlots = 32;
+struct ConvStats {
+  unsigned long long* slab = nullptr;  // [kStatSlots][4][C] fixed-point words, zeroed by the caller
+  const float* x = nullptr;
+  const float* y = nullptr;
+  const float* mean = nullptr;
+  const float* invstd = nullptr;
+  int relu = 0;
+};
+inline size_t stat_slab_bytes(int C) { return align_up((size_t)kStatSlots * 4 * C * sizeof(unsigned long long)); }
 
+// gpn_spconv_fwd_ordered with an "add to out" mode and optional BatchNorm sums (spconv_fwd.hip); used by the network executor
+int spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p, const int32_t* perm, int K,
+                    int64_t n_dst, int cin, int cout, float* out, int accumulate, const ConvStats& stats, void* ws,
+                    size_t ws_bytes, hipStream_t stream);
+// true if a conv of this shape runs on a kernel whose epilogue can accumulate ConvStats (masked-tile or direct kernel)
+bool spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout);
 // the masked-tile kernel (spconv_tiles.hip): which shapes it takes, and its launch
 bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout);
 int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
-                        int cin, int cout, int accumulate, float* out, hipStream_t stream);
+                        int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream);
+// BatchNorm apply passes over sums a conv launch accumulated (bn.hip); bn_two_pass: the shapes that take them
+bool bn_two_pass(int64_t N, int C);
+int bn_fwd_train_fused(const float* x, const float* res, const float* weight, const float* bias, int64_t N, int C, float eps,
+                       float momentum, int relu, float* y, float* mean, float* invstd, float* running_mean,
+                       float* running_var, const unsigned long long* slab, hipStream_t stream);
+int bn_bwd_fused(const float* x, const float* y, const float* dy, const float* weight, const float* mean, const float* invstd,
+                 int64_t N, int C, int relu, int training, float* dx, float* dres, float* dweight, float* dbias,
+                 const unsigned long long* slab, hipStream_t stream);
 
 }  // namespace gpn
 

@@ -12,6 +12,8 @@
 // of the small, deep levels leaves idle.
 #include <unistd.h>
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -26,6 +28,13 @@
 namespace {
 
 constexpr int kThreads = 256;
+
+// BatchNorm sums in the conv epilogues (bn_stats.h) on / off: env GPN_BN_FUSE=0 or gpn_net_bn_fusion(0) restores the separate
+// statistics launches (A/B measurements, and the tests that compare the two forms)
+std::atomic<int> g_bn_fusion{[] {
+  const char* e = getenv("GPN_BN_FUSE");
+  return e ? atoi(e) : 1;
+}()};
 
 // dst[r, 0:ca] = a[r, :], dst[r, ca:ca+cb] = b[r, :]   (float4 granularity; channel counts are multiples of 4)
 __global__ __launch_bounds__(kThreads) void concat_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
@@ -105,6 +114,7 @@ struct Need {
   size_t op = 0;      // largest per-op workspace of the main chain (conv tap-split partials, BN partials)
   size_t wgrad = 0;   // largest wgrad workspace (side stream)
   size_t packed = 0;  // all packed weights of the program
+  size_t stats = 0;   // BatchNorm sum slabs the conv epilogues add to (bn_stats.h), one per BN op
 };
 
 Need workspace_need(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, const gpn_net_rulebook_t* rbs,
@@ -124,6 +134,7 @@ Need workspace_need(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* sl
       n.tmp = std::max(n.tmp, slot_bytes(s0));
     } else if (op.kind == GPN_NET_BN) {
       n.op = std::max(n.op, gpn_bn_ws_bytes(s0.rows, s0.channels));
+      n.stats += gpn::stat_slab_bytes(s0.channels);
       if (op.src1 >= 0) n.tmp = std::max(n.tmp, slot_bytes(slots[op.src1]));
     }
   }
@@ -240,12 +251,17 @@ int check_program(const char* who, const gpn_net_op_t* ops, int n_ops, const gpn
 
 }  // namespace
 
+// conv-epilogue BatchNorm sums on (1, default) / off (0); on < 0 queries.  Returns the previous setting.
+extern "C" int gpn_net_bn_fusion(int on) {
+  return on < 0 ? g_bn_fusion.load(std::memory_order_relaxed) : g_bn_fusion.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
+
 extern "C" size_t gpn_net_ws_bytes(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, int n_slots,
                                    const gpn_net_rulebook_t* rulebooks, const gpn_net_conv_t* convs) {
   (void)n_slots;
   if (!ops || !slots) return 0;
   const Need n = workspace_need(ops, n_ops, slots, rulebooks, convs);
-  return n.tmp + n.op + n.wgrad + n.packed;
+  return n.tmp + n.op + n.wgrad + n.packed + n.stats;
 }
 
 extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
@@ -256,15 +272,37 @@ extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_
   int rc = check_program(__func__, ops, n_ops, slots, n_slots, rbs, n_rbs, convs, n_convs, bns, n_bns);
   if (rc) return rc;
   const Need need = workspace_need(ops, n_ops, slots, rbs, convs);
-  if (!ws || ws_bytes < need.packed + need.op) {
-    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, need.packed + need.op, ws_bytes);
+  if (!ws || ws_bytes < need.packed + need.stats + need.op) {
+    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, need.packed + need.stats + need.op, ws_bytes);
     return GPN_ERR_WS;
   }
   std::vector<const float*> packed_of;
   rc = pack_program(ops, n_ops, rbs, convs, false, static_cast<char*>(ws), packed_of, stream);
   if (rc) return rc;
-  void* op_ws = static_cast<char*>(ws) + need.packed;
-  const size_t op_ws_bytes = ws_bytes - need.packed;
+  void* op_ws = static_cast<char*>(ws) + need.packed + need.stats;
+  const size_t op_ws_bytes = ws_bytes - need.packed - need.stats;
+  // training: a BatchNorm that directly follows a conv whose kernel has the sum epilogue gets its statistics from that
+  // launch (bn_stats.h) and keeps only its apply pass
+  std::vector<unsigned long long*> slab_of(n_ops, nullptr);  // by BN op: where its sums are accumulated; by CONV op: same slab
+  if (training && g_bn_fusion.load(std::memory_order_relaxed)) {
+    std::vector<int> readers(n_slots, 0);
+    for (int i = 0; i < n_ops; ++i) {
+      readers[ops[i].src0]++;
+      if (ops[i].src1 >= 0) readers[ops[i].src1]++;
+    }
+    char* area = static_cast<char*>(ws) + need.packed;
+    size_t off = 0;
+    for (int i = 0; i + 1 < n_ops; ++i) {
+      const gpn_net_op_t &cv_op = ops[i], &bn_op = ops[i + 1];
+      if (cv_op.kind != GPN_NET_CONV || bn_op.kind != GPN_NET_BN || bn_op.src0 != cv_op.dst || readers[cv_op.dst] != 1) continue;
+      const gpn_net_rulebook_t& rb = rbs[cv_op.rulebook];
+      const gpn_net_conv_t& cv = convs[cv_op.param];
+      if (!gpn::bn_two_pass(rb.n_dst, cv.cout) || !gpn::spconv_fwd_accumulates_stats(rb.K, rb.n_dst, cv.cin, cv.cout)) continue;
+      slab_of[i] = slab_of[i + 1] = reinterpret_cast<unsigned long long*>(area + off);
+      off += gpn::stat_slab_bytes(cv.cout);
+    }
+    if (off) GPN_CHECK_HIP(hipMemsetAsync(area, 0, off, stream));
+  }
   for (int i = 0; i < n_ops; ++i) {
     const gpn_net_op_t& op = ops[i];
     const gpn_net_slot_t &s0 = slots[op.src0], &d = slots[op.dst];
@@ -275,13 +313,18 @@ extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_
     if (op.kind == GPN_NET_CONV) {
       const gpn_net_rulebook_t& rb = rbs[op.rulebook];
       const gpn_net_conv_t& cv = convs[op.param];
-      rc = gpn_spconv_fwd_ordered(s0.data, packed_of[i], rb.nbr, rb.nbr_p, rb.perm, rb.K, rb.n_dst, cv.cin, cv.cout, d.data,
-                                  op_ws, op_ws_bytes, stream_);
+      gpn::ConvStats st;
+      st.slab = slab_of[i];
+      rc = gpn::spconv_fwd_into(s0.data, packed_of[i], rb.nbr, rb.nbr_p, rb.perm, rb.K, rb.n_dst, cv.cin, cv.cout, d.data, 0, st,
+                                op_ws, op_ws_bytes, stream);
     } else if (op.kind == GPN_NET_BN) {
       const gpn_net_bn_t& bn = bns[op.param];
       const float* res = op.src1 >= 0 ? slots[op.src1].data : nullptr;
       const int relu = (op.flags & GPN_NET_RELU) ? 1 : 0;
-      if (training) {
+      if (training && slab_of[i]) {
+        rc = gpn::bn_fwd_train_fused(s0.data, res, bn.weight, bn.bias, s0.rows, bn.C, bn.eps, bn.momentum, relu, d.data,
+                                     bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, slab_of[i], stream);
+      } else if (training) {
         rc = gpn_bn_fwd_train(s0.data, res, bn.weight, bn.bias, s0.rows, bn.C, bn.eps, bn.momentum, relu, d.data,
                               bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, op_ws, op_ws_bytes, stream_);
       } else {
@@ -463,20 +506,49 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
   int rc = check_program(__func__, ops, n_ops, slots, n_slots, rbs, n_rbs, convs, n_convs, bns, n_bns);
   if (rc) return rc;
   const Need need = workspace_need(ops, n_ops, slots, rbs, convs);
-  const size_t total_need = need.tmp + need.packed + need.op + need.wgrad;
+  const size_t total_need = need.tmp + need.packed + need.stats + need.op + need.wgrad;
   if (!ws || ws_bytes < total_need) {
     gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, total_need, ws_bytes);
     return GPN_ERR_WS;
   }
   char* base = static_cast<char*>(ws);
   float* tmp = reinterpret_cast<float*>(base);
-  void* op_ws = base + need.tmp + need.packed;
+  char* stats_area = base + need.tmp + need.packed;
+  void* op_ws = base + need.tmp + need.packed + need.stats;
   const size_t op_ws_bytes = need.op;
-  void* wgrad_ws = base + need.tmp + need.packed + need.op;
-  const size_t wgrad_ws_bytes = ws_bytes - (need.tmp + need.packed + need.op);
+  void* wgrad_ws = base + need.tmp + need.packed + need.stats + need.op;
+  const size_t wgrad_ws_bytes = ws_bytes - (need.tmp + need.packed + need.stats + need.op);
   std::vector<const float*> packed_of;
   rc = pack_program(ops, n_ops, rbs, convs, true, base + need.tmp, packed_of, stream);
   if (rc) return rc;
+  // A dgrad conv that writes the FINAL gradient of a BatchNorm's output (it is the slot's first reader in program order, so
+  // the last one of this reverse walk) adds that BatchNorm's backward sums in its epilogue (bn_stats.h); the BatchNorm then
+  // runs only its apply pass.  bn_slab[j]: the slab of BN op j; fused_by[i]: the BN op a CONV op i accumulates for.
+  std::vector<unsigned long long*> bn_slab(n_ops, nullptr);
+  std::vector<int> fused_by(n_ops, -1);
+  std::vector<char> sums_done(n_ops, 0);
+  if (g_bn_fusion.load(std::memory_order_relaxed)) {
+    std::vector<int> first_reader(n_slots, -1), producer(n_slots, -1);
+    for (int i = n_ops - 1; i >= 0; --i) {
+      first_reader[ops[i].src0] = i;
+      if (ops[i].src1 >= 0) first_reader[ops[i].src1] = i;
+      producer[ops[i].dst] = i;
+    }
+    size_t off = 0;
+    for (int i = 0; i < n_ops; ++i) {
+      if (ops[i].kind != GPN_NET_CONV) continue;
+      const int j = producer[ops[i].src0];
+      if (j < 0 || ops[j].kind != GPN_NET_BN || first_reader[ops[i].src0] != i) continue;
+      if (ops[i].src0 == 0 && !need_input_grad) continue;
+      const gpn_net_rulebook_t& rb = rbs[ops[i].rulebook];
+      const gpn_net_conv_t& cv = convs[ops[i].param];
+      if (!gpn::bn_two_pass(rb.n_src, cv.cin) || !gpn::spconv_fwd_accumulates_stats(rb.K, rb.n_src, cv.cout, cv.cin)) continue;
+      bn_slab[j] = reinterpret_cast<unsigned long long*>(stats_area + off);
+      off += gpn::stat_slab_bytes(cv.cin);
+      fused_by[i] = j;
+    }
+    if (off) GPN_CHECK_HIP(hipMemsetAsync(stats_area, 0, off, stream));
+  }
   SideStream* side = side_stream();
   if (!side) {
     gpn::set_error("%s: could not create the weight-gradient stream", __func__);
@@ -534,8 +606,20 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
           return GPN_ERR_ARG;
         }
         // a slot that already holds a gradient takes this one added in place (no staging buffer, no accumulate launch)
+        gpn::ConvStats st;
+        if (fused_by[i] >= 0) {
+          const gpn_net_op_t& bo = ops[fused_by[i]];
+          const gpn_net_bn_t& bn = bns[bo.param];
+          st.slab = bn_slab[fused_by[i]];
+          st.x = slots[bo.src0].data;
+          st.y = s0.data;
+          st.mean = training ? bn.save_mean : bn.running_mean;
+          st.invstd = bn.save_invstd;
+          st.relu = (bo.flags & GPN_NET_RELU) ? 1 : 0;
+          sums_done[fused_by[i]] = 1;
+        }
         rc = gpn::spconv_fwd_into(d.grad, packed_of[i], rb.nbr_t, rb.nbr_t_p, rb.perm_t, rb.K, rb.n_src, cv.cout, cv.cin, s0.grad,
-                                  s0.grad_state ? 1 : 0, op_ws, op_ws_bytes, stream);
+                                  s0.grad_state ? 1 : 0, st, op_ws, op_ws_bytes, stream);
         if (rc) return rc;
         s0.grad_state = 1;
       }
@@ -561,9 +645,14 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
         tr = grad_target(slots[op.src1], tmp);
         dres = tr.ptr;
       }
-      rc = gpn_bn_bwd(s0.data, d.data, d.grad, bn.weight, mean, bn.save_invstd, s0.rows, bn.C,
-                      (op.flags & GPN_NET_RELU) ? 1 : 0, training ? 1 : 0, tx.ptr, dres, bn.dweight, bn.dbias, op_ws,
-                      op_ws_bytes, stream_);
+      if (sums_done[i])
+        rc = gpn::bn_bwd_fused(s0.data, d.data, d.grad, bn.weight, mean, bn.save_invstd, s0.rows, bn.C,
+                               (op.flags & GPN_NET_RELU) ? 1 : 0, training ? 1 : 0, tx.ptr, dres, bn.dweight, bn.dbias, bn_slab[i],
+                               stream);
+      else
+        rc = gpn_bn_bwd(s0.data, d.data, d.grad, bn.weight, mean, bn.save_invstd, s0.rows, bn.C,
+                        (op.flags & GPN_NET_RELU) ? 1 : 0, training ? 1 : 0, tx.ptr, dres, bn.dweight, bn.dbias, op_ws,
+                        op_ws_bytes, stream_);
       if (rc) return rc;
       s0.grad_state = 1;
       if (dres) {

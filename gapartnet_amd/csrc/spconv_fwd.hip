@@ -23,6 +23,7 @@
 #include <atomic>
 #include <cstdlib>
 
+#include "bn_stats.h"
 #include "gpn_common.h"
 
 namespace {
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
                                                                 const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
                                                                 int64_t units, size_t packed_bytes,
                                                                 const int32_t* __restrict__ perm, int accumulate,
-                                                                float* __restrict__ out) {
+                                                                gpn::ConvStats stats, float* __restrict__ out) {
   constexpr int S = KT * CB;
   constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;  // prefetch depth in stages
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -396,23 +397,40 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
     if (tap + DI < KT) ireg[tap % DI] = load_idx(tap + DI);
     asm volatile("" ::: "memory");
   }
+  // store; BatchNorm column sums of the tile when the launch carries a slab (bn_stats.h)
+  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr, st_bwd = stats.slab != nullptr && stats.x != nullptr;
+  const uint32_t col = (uint32_t)(nt * 16 + i16);
+  float s0 = 0.f, s1 = 0.f, mu = 0.f, is = 1.f;
+  if (st_bwd) mu = stats.mean[col], is = stats.invstd[col];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + 4 * g + r;
     if (row < n_dst) {
-      float* o = out + ((uint32_t)orow[r] * (uint32_t)cout + (uint32_t)(nt * 16 + i16));
-      *o = accumulate ? *o + acc[r] : acc[r];  // (accumulate: a second gradient of the same rows, added in place)
+      const uint32_t e = (uint32_t)orow[r] * (uint32_t)cout + col;
+      float v = acc[r];
+      if (accumulate) v += out[e];  // (a second gradient of the same rows, added in place)
+      out[e] = v;
+      if (st_fwd) {
+        s0 += v;
+        s1 += v * v;
+      } else if (st_bwd) {
+        const float gm = (stats.relu && !(stats.y[e] > 0.f)) ? 0.f : v;
+        s0 += gm;
+        s1 += gm * ((stats.x[e] - mu) * is);
+      }
     }
   }
+  if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(unit & (gpn::kStatSlots - 1)), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+  else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(unit & (gpn::kStatSlots - 1)), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
 }
 
 template <int KT, int CB>
 int launch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int nt_total,
-                  int accumulate, float* out, hipStream_t stream) {
+                  int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
   hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4), 8) * 8)), dim3(256), 0, stream, in, packed,
-                     nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, out);
+                     nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -435,18 +453,18 @@ bool use_direct(int K, int64_t n_dst, int cin, int cout) {
 
 template <int KT>
 int dispatch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int cin,
-                    int nt_total, int accumulate, float* out, hipStream_t stream) {
+                    int nt_total, int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
   switch (cin / 16) {
-    case 1: return launch_direct<KT, 1>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
-    case 2: return launch_direct<KT, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
-    case 3: return launch_direct<KT, 3>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
-    case 4: return launch_direct<KT, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
-    case 5: return launch_direct<KT, 5>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
-    case 6: return launch_direct<KT, 6>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
-    case 7: return launch_direct<KT, 7>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
-    case 8: return launch_direct<KT, 8>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
-    case 10: return launch_direct<KT, 10>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
-    default: return launch_direct<KT, 12>(in, packed, nbr, perm, n_dst, nt_total, accumulate, out, stream);
+    case 1: return launch_direct<KT, 1>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    case 2: return launch_direct<KT, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    case 3: return launch_direct<KT, 3>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    case 4: return launch_direct<KT, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    case 5: return launch_direct<KT, 5>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    case 6: return launch_direct<KT, 6>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    case 7: return launch_direct<KT, 7>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    case 8: return launch_direct<KT, 8>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    case 10: return launch_direct<KT, 10>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    default: return launch_direct<KT, 12>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
   }
 }
 
@@ -462,14 +480,19 @@ extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cou
 extern "C" int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p,
                                       const int32_t* perm, int K, int64_t n_dst, int cin, int cout, float* out,
                                       void* ws, size_t ws_bytes, gpn_stream_t stream) {
-  return gpn::spconv_fwd_into(in, packed_w, nbr, nbr_p, perm, K, n_dst, cin, cout, out, 0, ws, ws_bytes, (hipStream_t)stream);
+  return gpn::spconv_fwd_into(in, packed_w, nbr, nbr_p, perm, K, n_dst, cin, cout, out, 0, gpn::ConvStats(), ws, ws_bytes,
+                              (hipStream_t)stream);
 }
 
 // out = conv (accumulate == 0) or out += conv (the network executor's second gradient of a slot: same value as staging the
 // conv's result and adding it with a separate launch, which is what it replaces)
+bool gpn::spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout) {
+  return n_dst > 0 && (gpn::spconv_tiles_supported(K, n_dst, cin, cout) || use_direct(K, n_dst, cin, cout));
+}
+
 int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p, const int32_t* perm,
-                         int K, int64_t n_dst, int cin, int cout, float* out, int accumulate, void* ws, size_t ws_bytes,
-                         hipStream_t stream) {
+                         int K, int64_t n_dst, int cin, int cout, float* out, int accumulate, const gpn::ConvStats& stats,
+                         void* ws, size_t ws_bytes, hipStream_t stream) {
   GPN_CHECK_ARG((nbr_p == nullptr) == (perm == nullptr));
   GPN_CHECK_ARG(K >= 1 && n_dst >= 0);
   GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
@@ -478,13 +501,17 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
   const int nt = cout / 16;
   if (gpn::spconv_tiles_supported(K, n_dst, cin, cout)) {  // the masked-tile kernel (spconv_tiles.hip): every layer of >= 16 tiles
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
-    return gpn::spconv_tiles_launch(in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, cout, accumulate, out, stream);
+    return gpn::spconv_tiles_launch(in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, cout, accumulate, stats, out, stream);
   }
   if (use_direct(K, n_dst, cin, cout)) {
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
     const int32_t* table = nbr_p ? nbr_p : nbr;
-    return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, out, stream)
-                   : dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, out, stream);
+    return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream)
+                   : dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream);
+  }
+  if (stats.slab) {
+    gpn::set_error("gpn_spconv_fwd: this shape runs on a kernel without a BatchNorm-sum epilogue (see spconv_fwd_accumulates_stats)");
+    return GPN_ERR_ARG;
   }
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   float* target = out;

@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "bn_stats.h"
 #include "gpn_common.h"
 
 namespace {
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
                                                            const int32_t* __restrict__ nbr, const int32_t* __restrict__ perm,
                                                            int K, int64_t n_dst, int n_tiles, int n_units, int nt_total,
                                                            int col_groups, size_t packed_bytes, int accumulate,
-                                                           float* __restrict__ out) {
+                                                           gpn::ConvStats stats, float* __restrict__ out) {
   constexpr int U = cfg_group(CB, R, NT);
   constexpr int RW = R * 16;        // rows of a wave
   constexpr int TPI = 64 / RW;      // taps covered by one table load of the prologue
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
     }
   }
 
-  // ---- D[row = 4g + r][col = i16] of every (row tile, column tile) -> out ----------------------------------------------
+  // ---- D[row = 4g + r][col = i16] of every (row tile, column tile) -> out; BatchNorm column sums of the tile (bn_stats.h) ----
+  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr, st_bwd = stats.slab != nullptr && stats.x != nullptr;
 #pragma unroll
   for (int t = 0; t < R; ++t) {
     const int tile = tile0 + t;
@@ -203,14 +205,29 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
         for (int r = 0; r < 4; ++r) orow[r] = tile * 16 + 4 * g + r;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if ((int64_t)tile * 16 + 4 * g + r < n_dst) {
+      for (int nt = 0; nt < NT; ++nt) {
+        const uint32_t col = (uint32_t)((nt0 + nt) * 16 + i16);
+        float s0 = 0.f, s1 = 0.f, mu = 0.f, is = 1.f;
+        if (st_bwd) mu = stats.mean[col], is = stats.invstd[col];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            float* o = out + ((uint32_t)orow[r] * (uint32_t)cout + (uint32_t)((nt0 + nt) * 16 + i16));
-            *o = accumulate ? *o + acc[t][nt][r] : acc[t][nt][r];  // (accumulate: a second gradient of the same rows, added in place)
+        for (int r = 0; r < 4; ++r) {
+          if ((int64_t)tile * 16 + 4 * g + r < n_dst) {
+            const uint32_t e = (uint32_t)orow[r] * (uint32_t)cout + col;
+            float v = acc[t][nt][r];
+            if (accumulate) v += out[e];  // (a second gradient of the same rows, added in place)
+            out[e] = v;
+            if (st_fwd) {
+              s0 += v;
+              s1 += v * v;
+            } else if (st_bwd) {
+              const float gm = (stats.relu && !(stats.y[e] > 0.f)) ? 0.f : v;
+              s0 += gm;
+              s1 += gm * ((stats.x[e] - mu) * is);
+            }
           }
         }
+        if (st_fwd) gpn::stat_add<false>(stats.slab, cout, unit & (gpn::kStatSlots - 1), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+        else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, unit & (gpn::kStatSlots - 1), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
       }
     }
   }
@@ -238,7 +255,7 @@ int min_waves() {  // a launch takes as many column tiles per wave as still leav
 
 template <int CB, int NT>
 int launch_tiles(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
-                 int nt_total, int accumulate, float* out, hipStream_t stream) {
+                 int nt_total, int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
   constexpr int R = 1;
   const int n_tiles = (int)gpn::cdiv(n_dst, 16);
   const int col_groups = nt_total / NT;
@@ -246,7 +263,7 @@ int launch_tiles(const float* in, const float* packed, const int32_t* nbr, const
   const size_t packed_bytes = (size_t)K * CB * nt_total * 1024;
   const dim3 grid((unsigned)(gpn::cdiv(gpn::cdiv(n_units, 4), 8) * 8));
   hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
-                     n_units, nt_total, col_groups, packed_bytes, accumulate, out);
+                     n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -277,15 +294,15 @@ bool supported_width(int CB) {
 
 template <int CB>
 int dispatch_cols(int NT, const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
-                  int nt_total, int accumulate, float* out, hipStream_t stream) {
+                  int nt_total, int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
   switch (NT) {
-    case 1: return launch_tiles<CB, 1>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
-    case 2: return launch_tiles<CB, 2>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
-    case 3: return launch_tiles<CB, 3>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
-    case 4: return launch_tiles<CB, 4>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
-    case 5: return launch_tiles<CB, 5>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
-    case 6: return launch_tiles<CB, 6>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
-    default: return launch_tiles<CB, 7>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+    case 1: return launch_tiles<CB, 1>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
+    case 2: return launch_tiles<CB, 2>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
+    case 3: return launch_tiles<CB, 3>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
+    case 4: return launch_tiles<CB, 4>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
+    case 5: return launch_tiles<CB, 5>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
+    case 6: return launch_tiles<CB, 6>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
+    default: return launch_tiles<CB, 7>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
   }
 }
 
@@ -307,11 +324,11 @@ bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout) {
 }
 
 int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
-                        int cin, int cout, int accumulate, float* out, hipStream_t stream) {
+                        int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream) {
   const int CB = cin / 16, nt_total = cout / 16;
   const int NT = cols_per_wave(gpn::cdiv(n_dst, 16), nt_total);
 #define GPN_X(cb) \
-  if (CB == cb) return dispatch_cols<cb>(NT, in, packed, nbr, perm, K, n_dst, nt_total, accumulate, out, stream);
+  if (CB == cb) return dispatch_cols<cb>(NT, in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
   GPN_TILES_CB(GPN_X)
 #undef GPN_X
   gpn::set_error("gpn_spconv_fwd: no masked-tile kernel for %d -> %d channels", cin, cout);

@@ -281,6 +281,12 @@ typedef struct gpn_net_op {
   int32_t flags;
   int32_t reserved;
 } gpn_net_op_t;
+/* training-mode BatchNorm sums (forward: sum x, sum x^2 of a conv's output; backward: sum g, sum g xhat of the gradient a dgrad
+ * conv writes) are accumulated by the epilogue of the producing conv launch as order-independent 64-bit fixed-point integers
+ * (csrc/bn_stats.h), so that a conv + BatchNorm pair costs 2 launches per direction instead of 3.  on = 0 restores the separate
+ * statistics launches (results agree to ~1e-7 relative; both forms are deterministic).  on < 0 queries.  Returns the previous
+ * setting. */
+int gpn_net_bn_fusion(int on);
 size_t gpn_net_ws_bytes(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, int n_slots,
                         const gpn_net_rulebook_t* rulebooks, const gpn_net_conv_t* convs);
 int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,

@@ -133,13 +133,26 @@ def _unet_case(cuda, without_stem):
     return net, idx, feats, spconv
 
 
+@pytest.fixture
+def bn_fusion(request):
+    """conv-epilogue BatchNorm sums (csrc/bn_stats.h) on / off for one test"""
+    from gapartnet_amd import _C
+    prev = _C.lib().gpn_net_bn_fusion(1 if request.param else 0)
+    yield bool(request.param)
+    _C.lib().gpn_net_bn_fusion(prev)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("without_stem", [False, True])
 @pytest.mark.parametrize("training", [True, False])
-def test_native_executor_matches_per_layer_path(cuda, without_stem, training):
-    """kernel family U: one-call forward/backward of the whole U-Net == the module-by-module walk (same kernels)"""
+@pytest.mark.parametrize("bn_fusion", [False, True], indirect=True)
+def test_native_executor_matches_per_layer_path(cuda, without_stem, training, bn_fusion):
+    """kernel family U: one-call forward/backward of the whole U-Net == the module-by-module walk (same kernels).  With the
+    BatchNorm sums taken in the conv epilogues (fixed-point accumulation, bn_stats.h) the training-mode statistics differ
+    from the separate statistics pass in the last bits: equal to 1e-5 instead of bit-equal."""
     from gapartnet_amd.network import net_exec
     net, idx, feats, spconv = _unet_case(cuda, without_stem)
+    exact = not (bn_fusion and training)
     assert net_exec.program_for(net) is not None, "the reference U-Net must be expressible as a program"
     ref = copy.deepcopy(net)
     ref.use_native_executor = False
@@ -155,13 +168,51 @@ def test_native_executor_matches_per_layer_path(cuda, without_stem, training):
         in_grads.append(f.grad)
         grads.append({k: p.grad for k, p in model.named_parameters()})
         assert torch.equal(y.indices, idx)
-    assert torch.equal(outs[0], outs[1]), "forward: identical kernels in identical order -> bit-equal"
-    assert torch.allclose(in_grads[0], in_grads[1], rtol=1e-5, atol=1e-6)
+    if exact:
+        assert torch.equal(outs[0], outs[1]), "forward: identical kernels in identical order -> bit-equal"
+    else:
+        assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-5), (outs[0] - outs[1]).abs().max()
+    scale = float(in_grads[1].abs().max())
+    assert torch.allclose(in_grads[0], in_grads[1], rtol=1e-5, atol=1e-6 if exact else 1e-5 * scale)
     for k in grads[1]:
         assert grads[0][k] is not None, k
-        assert torch.allclose(grads[0][k], grads[1][k], rtol=1e-4, atol=1e-6), k
+        gs = float(grads[1][k].abs().max())
+        assert torch.allclose(grads[0][k], grads[1][k], rtol=1e-4, atol=1e-6 if exact else 1e-4 * gs + 1e-6), k
     for (k, a), (_, b) in zip(net.state_dict().items(), ref.state_dict().items()):
-        assert torch.equal(a, b), f"buffer / parameter {k} diverged (running statistics, num_batches_tracked)"
+        if exact:
+            assert torch.equal(a, b), f"buffer / parameter {k} diverged (running statistics, num_batches_tracked)"
+        else:
+            assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.gpu
+def test_conv_epilogue_batchnorm_sums_are_deterministic_and_used(cuda):
+    """the fused form (BatchNorm sums accumulated by the producing conv launch as fixed-point integers): two runs are
+    bit-identical although thousands of waves add to one channel in arbitrary order, and the profile shows no separate
+    statistics launch for the levels above 1024 rows"""
+    from gapartnet_amd import _C
+    assert _C.lib().gpn_net_bn_fusion(-1) == 1, "fusion is the default"
+    net, idx, feats, spconv = _unet_case(cuda, True)
+    net.train(True)
+    runs = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        f = feats.clone().requires_grad_(True)
+        y = net(spconv.SparseConvTensor(f, idx, [64, 64, 64], 3))
+        y.features.square().sum().backward()
+        runs.append((y.features.detach().clone(), f.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        f = feats.clone().requires_grad_(True)
+        net(spconv.SparseConvTensor(f, idx, [64, 64, 64], 3)).features.square().sum().backward()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    reduces = sum(e.count for e in prof.key_averages() if "bn_reduce_kernel" in e.key)
+    applies = sum(e.count for e in prof.key_averages() if "bn_apply_fwd_fold_kernel" in e.key)
+    assert applies > 0, names
+    # only BatchNorms behind a k = 1 conv (lock-step kernel, no sum epilogue) keep their statistics launches
+    assert reduces <= applies, (reduces, applies, names)
 
 
 @pytest.mark.gpu
@@ -173,12 +224,14 @@ def test_native_executor_no_grad_and_frozen_input(cuda):
     with torch.no_grad():
         a = net(spconv.SparseConvTensor(feats, idx, [64, 64, 64], 3)).features
         b = ref(spconv.SparseConvTensor(feats, idx, [64, 64, 64], 3)).features
-    assert torch.equal(a, b)
+    # (training-mode BatchNorm: the executor takes the statistics from the conv epilogues, csrc/bn_stats.h - equal to
+    # rounding, bit-equal with gpn_net_bn_fusion(0): test_native_executor_matches_per_layer_path)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
     # input that does not require grad: parameters still get their gradients
     net(spconv.SparseConvTensor(feats, idx, [64, 64, 64], 3)).features.square().sum().backward()
     ref(spconv.SparseConvTensor(feats, idx, [64, 64, 64], 3)).features.square().sum().backward()
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
-        assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6), k
+        assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-4 * float(q.grad.abs().max()) + 1e-6), k
 
 
 @pytest.mark.gpu
