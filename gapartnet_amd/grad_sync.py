@@ -67,6 +67,7 @@ class GradSync:
         self._buckets: Optional[List[List[int]]] = None
         self.stats = {"in_place": 0, "flattened": 0, "skipped": 0, "steps": 0, "host_ms": 0.0}
         self._verify_always = os.environ.get("GPN_GRAD_SYNC_VERIFY") == "1"
+        self._verified = {}  # id(program) -> [slice-by-slice walks of the whole-buffer shortcut done, on which buffer]
         # (gloo has no coalescing: its buckets go one call each, as before)
         self._coalesce = self.backend == "nccl" and os.environ.get("GPN_GRAD_SYNC_NO_COALESCE") != "1"
 
@@ -109,7 +110,8 @@ class GradSync:
     def _executor_flat(self, prog, grads, total) -> Optional[torch.Tensor]:
         """the executor's own gradient buffer of this step if the bucket's ``.grad`` tensors are exactly its slices, back
         to back (autograd hands the slices over without copying when ``.grad`` was None).  First and last slice are checked
-        on every step (O(1)); every slice on the first VERIFY_STEPS steps, because a middle parameter whose ``.grad`` is
+        on every step (O(1)); every slice on the first VERIFY_STEPS steps THIS bucket takes the shortcut (and again whenever
+        the executor hands out a new buffer), because a middle parameter whose ``.grad`` is
         NOT a slice (tied parameter, accumulation into an existing ``.grad``, a hook that made AccumulateGrad clone) would
         otherwise be left un-averaged without any error."""
         flat = getattr(prog, "last_pgrad", None)
@@ -118,7 +120,13 @@ class GradSync:
         base = flat.data_ptr()
         if grads[0].data_ptr() != base or grads[-1].data_ptr() + grads[-1].numel() * 4 != base + total * 4:
             return None
-        if self.stats["steps"] <= self.VERIFY_STEPS or self._verify_always:
+        # per bucket: the score / NPCS U-Nets first run at epochs start_scorenet / start_npcs, long after the first steps
+        # of the run, and the executor retires its buffer when somebody keeps a reference to it (new base address)
+        seen = self._verified.setdefault(id(prog), [0, 0])  # [full walks done, base address they were done on]
+        if seen[1] != base:
+            seen[0], seen[1] = 0, base
+        if seen[0] < self.VERIFY_STEPS or self._verify_always:
+            seen[0] += 1
             ptr = base
             for g in grads:
                 if g is None or g.data_ptr() != ptr or g.dtype != torch.float32 or not g.is_contiguous():

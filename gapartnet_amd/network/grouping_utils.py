@@ -358,8 +358,9 @@ def compute_ap_multi(proposals: List[Instances], num_classes: int, iou_threshold
     rank = torch.arange(n_total, device=dev)
     big = torch.full((max(key_base, 1),), n_total, dtype=torch.int64, device=dev)
     out = []
-    for thr in thresholds:
-        cand = ranked_iou > thr
+    ranked_iou64 = ranked_iou.double()  # the reference compares numpy float IoUs with Python-float thresholds in double:
+    for thr in thresholds:               # in float32 an IoU on a threshold boundary (0.5, 0.55, ...) can flip TP / FP
+        cand = ranked_iou64 > float(thr)
         first = big.scatter_reduce(0, ranked_key, torch.where(cand, rank, rank.new_full((), n_total)), "amin")
         tp = cand & (first[ranked_key] == rank)
         tp_c = (of_class & tp[None, :]).float().cumsum(1)

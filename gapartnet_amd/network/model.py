@@ -263,7 +263,13 @@ class GAPartNet(LightningModule):
 
     def _proposals_fused(self, ops, pt_xyz, batch_indices, pt_features, sem_preds, offset_preds, instance_labels, batch_size):
         jitter = self.revoxelize_jitter
+        rng_before = None
         if jitter is None:  # the reference's two torch.rand(3) draws, in its order, from the device generator
+            # (the reference - and the unfused path - draw them inside segmented_voxelize, i.e. only when a proposal survives;
+            # here they are needed before that is known, so the generator is put back if none does: same random stream)
+            gen = torch.cuda.default_generators[pt_xyz.device.index if pt_xyz.device.index is not None else torch.cuda.current_device()] \
+                if pt_xyz.is_cuda else torch.default_generator
+            rng_before = (gen, gen.get_state())
             jitter = (torch.rand(3, dtype=torch.float32, device=pt_xyz.device),
                       torch.rand(3, dtype=torch.float32, device=pt_xyz.device))
         built = ops.proposals_build(pt_xyz, offset_preds, sem_preds, instance_labels, batch_indices, batch_size,
@@ -271,6 +277,8 @@ class GAPartNet(LightningModule):
                                     self.max_num_points_per_query_shift, self.min_num_points_per_proposal,
                                     float(self.score_fullscale), float(self.score_scale), jitter)
         if built is None:
+            if rng_before is not None:
+                rng_before[0].set_state(rng_before[1])
             return None, None, None
         if built["dropped"] != 0:
             raise RuntimeError("re-voxelisation dropped points: a proposal left its score_fullscale^3 grid "

@@ -12,6 +12,8 @@ Results are those of the per-layer path (same kernels, same order); gradients of
 summed in reverse program order.
 """
 import ctypes
+import os
+import sys
 from typing import List, Optional
 
 import numpy as np
@@ -253,7 +255,9 @@ class NetProgram:
     def grad_buffer(self, device, params, fresh: bool):
         """-> (flat fp32 buffer of grad_total elements, per-parameter views of it in params() order).  The persistent pair
         is created once per device and handed out again every step (the kernels overwrite it); ``fresh`` asks for a
-        private buffer instead (gradient accumulation)."""
+        private buffer instead (gradient accumulation, parameters as autograd inputs).  A persistent pair that somebody
+        else still references - a ``.grad`` kept past ``zero_grad(set_to_none=True)`` for accumulation or deferred logging,
+        a view or ``detach()`` of one - is retired (it stays alive with its holder, untouched) and replaced by a new one."""
         def make():
             flat = torch.empty((self.grad_total,), dtype=torch.float32, device=device)
             pieces = flat.split(self.grad_sizes)
@@ -261,10 +265,24 @@ class NetProgram:
         if fresh:
             return make()
         cached = self._grad_cache.get(device)
-        if cached is None or any(v.shape != p.shape for v, p in zip(cached[1], params)):
+        if cached is None or any(v.shape != p.shape for v, p in zip(cached[1], params)) or _shared(cached, params):
             cached = make()
             self._grad_cache[device] = cached
         return cached
+
+
+def _shared(pair, params) -> bool:
+    """is the persistent gradient buffer (or one of its per-parameter views) referenced by anything but the cache, the
+    parameters' own ``.grad`` and the program's ``last_pgrad``?"""
+    flat, views = pair
+    # storage holders: the flat tensor, one per view, the temporary wrapper made by untyped_storage()
+    if torch._C._storage_Use_Count(flat.untyped_storage()._cdata) > len(views) + 2:
+        return True
+    for v, p in zip(views, params):
+        # references to the view object: the list slot, the loop variable, getrefcount's argument (+ the parameter's .grad)
+        if sys.getrefcount(v) > 3 + (1 if p.grad is v else 0):
+            return True
+    return False
 
 
 def _vp(a: np.ndarray):
@@ -288,100 +306,144 @@ def _call(fn_name, prog, slots, rb_table, conv_table, bn_table, extra, device):
         raise _C.GpnError(f"{fn_name} failed: {L.gpn_last_error().decode('utf-8', 'replace')}")
 
 
+# Gradient hand-over contract of the executor (read this before relying on autograd features for U-Net parameters):
+#   default ("direct") form - the ~110 parameters of a U-Net are NOT autograd inputs of the program.  backward() writes all
+#   their gradients into ONE persistent flat buffer per program and assigns each parameter's ``.grad`` to its slice.
+#   Consequences: (1) ``torch.autograd.grad(loss, unet_parameters)`` raises "not used in the graph" and
+#   ``backward(inputs=[...])`` still fills the parameters' ``.grad``; (2) tensor hooks / post-accumulate-grad hooks on these
+#   parameters would not fire - a parameter WITH such a hook switches the call to the autograd form automatically;
+#   (3) the buffer is reused by the next backward: a reference kept past ``zero_grad(set_to_none=True)`` is detected
+#   (grad_buffer / _shared) and the buffer retired instead of overwritten; (4) parameters with ``requires_grad=False`` get
+#   no gradient and their weight-gradient launches are skipped.  GradSync and FusedAdam build on the flat buffer.
+#   autograd form - ``GPN_NET_AUTOGRAD_PARAMS=1`` or ``set_autograd_parameters(True)``: parameters are autograd inputs,
+#   gradients come back through AccumulateGrad like any other op's (everything of (1)-(2) works; ~3 ms of host time per
+#   training step for the three U-Nets, and no in-place gradient exchange).
+_AUTOGRAD_PARAMS = os.environ.get("GPN_NET_AUTOGRAD_PARAMS") == "1"
+
+
+def set_autograd_parameters(on: bool) -> bool:
+    """route U-Net parameters through autograd (True) or hand their gradients over directly (False, default); returns the
+    previous setting"""
+    global _AUTOGRAD_PARAMS
+    prev, _AUTOGRAD_PARAMS = _AUTOGRAD_PARAMS, bool(on)
+    return prev
+
+
+def _has_hooks(p) -> bool:
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+
+
+def _forward_impl(ctx, features, prog: NetProgram, rt, training):
+    params = prog.params()
+    rows, rb_table, rb_objs = rt
+    features = features.contiguous()
+    dev = features.device
+    n_slots = len(prog.slot_level)
+    slot_rows = rows[prog.slot_level_np]
+    sizes = slot_rows * prog.slot_channels_np
+    sizes[0] = 0  # slot 0 is the caller's tensor
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    arena = torch.empty((int(offs[-1]),), dtype=torch.float32, device=dev)
+    base = arena.data_ptr()
+    slots = np.zeros(n_slots, SLOT_DT)
+    slots["data"] = base + offs[:-1] * 4
+    slots["data"][0] = features.data_ptr()
+    slots["rows"] = slot_rows
+    slots["channels"] = prog.slot_channels_np
+    n_conv, n_bn = len(prog.convs), len(prog.bns)
+    total_c = int(prog.bn_off[-1])
+    stats = torch.empty((2, total_c), dtype=torch.float32, device=dev)
+    conv_table = np.zeros(n_conv, CONV_DT)
+    conv_table["W"] = [p.data_ptr() for p in params[:n_conv]]
+    conv_table["cin"] = [c.in_channels for c in prog.convs]
+    conv_table["cout"] = [c.out_channels for c in prog.convs]
+    bn_table = np.zeros(n_bn, BN_DT)
+    bn_table["weight"] = [p.data_ptr() for p in params[n_conv:n_conv + n_bn]]
+    bn_table["bias"] = [p.data_ptr() for p in params[n_conv + n_bn:]]
+    bn_table["running_mean"] = [b.running_mean.data_ptr() for b in prog.bns]
+    bn_table["running_var"] = [b.running_var.data_ptr() for b in prog.bns]
+    bn_table["save_mean"] = stats.data_ptr() + prog.bn_off[:-1] * 4
+    bn_table["save_invstd"] = stats.data_ptr() + (total_c + prog.bn_off[:-1]) * 4
+    bn_table["eps"] = [b.eps for b in prog.bns]
+    bn_table["momentum"] = [b.momentum for b in prog.bns]
+    bn_table["C"] = prog.bn_C
+    _call("gpn_net_forward", prog, slots, rb_table, conv_table, bn_table, (1 if training else 0,), dev)
+    if GF.CONV_LOG is not None:
+        for _, op in prog.conv_ops:
+            conv, (rb, _rb_t) = prog.convs[op[5]], rb_objs[op[4]]
+            GF._log(rb, conv.in_channels, conv.out_channels, "fwd")
+    o = prog.out_slot
+    out = arena[int(offs[o]):int(offs[o + 1])].view(int(slot_rows[o]), int(prog.slot_channels_np[o]))
+    ctx.prog, ctx.rt, ctx.training = prog, rt, training
+    ctx.state = (features, arena, stats, slots, conv_table, bn_table, sizes, params)
+    return out
+
+
+def _backward_impl(ctx, dout, fresh: bool, need_in: bool):
+    """runs gpn_net_backward; -> (din or None, flat parameter-gradient buffer, its per-parameter views, params)"""
+    prog = ctx.prog
+    rows, rb_table, rb_objs = ctx.rt
+    features, arena, stats, slots, conv_table, bn_table, sizes, params = ctx.state
+    dev = features.device
+    dout = dout.contiguous()
+    gsizes = sizes.copy()
+    gsizes[0] = features.numel()
+    gsizes[prog.out_slot] = 0  # the incoming gradient is used in place
+    goffs = np.concatenate([[0], np.cumsum(gsizes)])
+    garena = torch.empty((int(goffs[-1]),), dtype=torch.float32, device=dev)
+    slots = slots.copy()
+    slots["grad"] = garena.data_ptr() + goffs[:-1] * 4
+    slots["grad_state"] = 0
+    slots["grad"][prog.out_slot] = dout.data_ptr()
+    slots["grad_state"][prog.out_slot] = 1
+    n_conv = len(prog.convs)
+    total_w, total_c = int(prog.conv_off[-1]), int(prog.bn_off[-1])
+    pgrad, views = prog.grad_buffer(dev, params, fresh)
+    pbase = pgrad.data_ptr()
+    conv_table = conv_table.copy()
+    conv_table["dW"] = pbase + prog.conv_off[:-1] * 4
+    frozen = [i for i, p in enumerate(params[:n_conv]) if not p.requires_grad]
+    if frozen:
+        conv_table["dW"][frozen] = 0  # no weight-gradient launch for a frozen conv
+    bn_table = bn_table.copy()
+    bn_table["dweight"] = pbase + (total_w + prog.bn_off[:-1]) * 4
+    bn_table["dbias"] = pbase + (total_w + total_c + prog.bn_off[:-1]) * 4
+    _call("gpn_net_backward", prog, slots, rb_table, conv_table, bn_table,
+          (1 if ctx.training else 0, 1 if need_in else 0), dev)
+    if GF.CONV_LOG is not None:
+        for _, op in prog.conv_ops:
+            conv, (rb, rb_t) = prog.convs[op[5]], rb_objs[op[4]]
+            if op[1] != 0 or need_in:
+                GF._log(rb_t, conv.out_channels, conv.in_channels, "dgrad")
+            if conv.weight.requires_grad:
+                GF._log(rb, conv.in_channels, conv.out_channels, "wgrad")
+    din = garena[:features.numel()].view_as(features) if need_in else None
+    ctx.state = None
+    return din, pgrad, views, params
+
+
 class _NetFn(torch.autograd.Function):
-    """the whole program as one differentiable op.  Only the features (and an anchor, below) are autograd inputs; the ~110
-    parameters of a U-Net are not: backward() hands each of them its slice of ONE flat gradient buffer by assigning
-    ``.grad`` directly.  With the parameters as autograd inputs every backward pass cost ~3 dispatches per parameter
-    (slice views, AccumulateGrad's detach) - ~1000 per training step for the three U-Nets, 3 ms of host time
-    (tools/op_count.py) for handing over buffers that already exist.  The flat buffer and the per-parameter views are
-    allocated once per program and reused while ``.grad`` is None at backward time (optimizer.zero_grad(set_to_none=True),
-    the default); a parameter that still holds a gradient gets the new one added, as autograd would.
+    """the whole program as one differentiable op, direct gradient hand-over (see the contract above).  Only the features
+    (and an anchor, below) are autograd inputs; the ~110 parameters of a U-Net are not: backward() hands each of them its
+    slice of ONE flat gradient buffer by assigning ``.grad`` directly.  With the parameters as autograd inputs every
+    backward pass cost ~3 dispatches per parameter (slice views, AccumulateGrad's detach) - ~1000 per training step for the
+    three U-Nets, 3 ms of host time (tools/op_count.py) for handing over buffers that already exist.  The flat buffer and
+    the per-parameter views are allocated once per program and reused while ``.grad`` is None at backward time
+    (optimizer.zero_grad(set_to_none=True), the default) and nobody else holds them; a parameter that still holds a
+    gradient gets the new one added, as autograd would.
     ``anchor`` is a one-element leaf that requires grad: it makes autograd call backward() even when the input features
     do not require a gradient (the backbone's voxel features)."""
 
     @staticmethod
     def forward(ctx, features, anchor, prog: NetProgram, rt, training):
-        params = prog.params()
-        rows, rb_table, rb_objs = rt
-        features = features.contiguous()
-        dev = features.device
-        n_slots = len(prog.slot_level)
-        slot_rows = rows[prog.slot_level_np]
-        sizes = slot_rows * prog.slot_channels_np
-        sizes[0] = 0  # slot 0 is the caller's tensor
-        offs = np.concatenate([[0], np.cumsum(sizes)])
-        arena = torch.empty((int(offs[-1]),), dtype=torch.float32, device=dev)
-        base = arena.data_ptr()
-        slots = np.zeros(n_slots, SLOT_DT)
-        slots["data"] = base + offs[:-1] * 4
-        slots["data"][0] = features.data_ptr()
-        slots["rows"] = slot_rows
-        slots["channels"] = prog.slot_channels_np
-        n_conv, n_bn = len(prog.convs), len(prog.bns)
-        total_c = int(prog.bn_off[-1])
-        stats = torch.empty((2, total_c), dtype=torch.float32, device=dev)
-        conv_table = np.zeros(n_conv, CONV_DT)
-        conv_table["W"] = [p.data_ptr() for p in params[:n_conv]]
-        conv_table["cin"] = [c.in_channels for c in prog.convs]
-        conv_table["cout"] = [c.out_channels for c in prog.convs]
-        bn_table = np.zeros(n_bn, BN_DT)
-        bn_table["weight"] = [p.data_ptr() for p in params[n_conv:n_conv + n_bn]]
-        bn_table["bias"] = [p.data_ptr() for p in params[n_conv + n_bn:]]
-        bn_table["running_mean"] = [b.running_mean.data_ptr() for b in prog.bns]
-        bn_table["running_var"] = [b.running_var.data_ptr() for b in prog.bns]
-        bn_table["save_mean"] = stats.data_ptr() + prog.bn_off[:-1] * 4
-        bn_table["save_invstd"] = stats.data_ptr() + (total_c + prog.bn_off[:-1]) * 4
-        bn_table["eps"] = [b.eps for b in prog.bns]
-        bn_table["momentum"] = [b.momentum for b in prog.bns]
-        bn_table["C"] = prog.bn_C
-        _call("gpn_net_forward", prog, slots, rb_table, conv_table, bn_table, (1 if training else 0,), dev)
-        if GF.CONV_LOG is not None:
-            for _, op in prog.conv_ops:
-                conv, (rb, _rb_t) = prog.convs[op[5]], rb_objs[op[4]]
-                GF._log(rb, conv.in_channels, conv.out_channels, "fwd")
-        o = prog.out_slot
-        out = arena[int(offs[o]):int(offs[o + 1])].view(int(slot_rows[o]), int(prog.slot_channels_np[o]))
-        ctx.prog, ctx.rt, ctx.training = prog, rt, training
-        ctx.state = (features, arena, stats, slots, conv_table, bn_table, sizes, params)
-        return out
+        return _forward_impl(ctx, features, prog, rt, training)
 
     @staticmethod
     def backward(ctx, dout):
         prog = ctx.prog
-        rows, rb_table, rb_objs = ctx.rt
-        features, arena, stats, slots, conv_table, bn_table, sizes, params = ctx.state
-        dev = features.device
-        dout = dout.contiguous()
-        gsizes = sizes.copy()
-        gsizes[0] = features.numel()
-        gsizes[prog.out_slot] = 0  # the incoming gradient is used in place
-        goffs = np.concatenate([[0], np.cumsum(gsizes)])
-        garena = torch.empty((int(goffs[-1]),), dtype=torch.float32, device=dev)
-        slots = slots.copy()
-        slots["grad"] = garena.data_ptr() + goffs[:-1] * 4
-        slots["grad_state"] = 0
-        slots["grad"][prog.out_slot] = dout.data_ptr()
-        slots["grad_state"][prog.out_slot] = 1
-        n_conv, n_bn = len(prog.convs), len(prog.bns)
-        total_w, total_c = int(prog.conv_off[-1]), int(prog.bn_off[-1])
+        params = ctx.state[-1]
         fresh = any(p.grad is not None for p in params)  # accumulation into existing gradients: temporary buffer, then add
-        pgrad, views = prog.grad_buffer(dev, params, fresh)
-        pbase = pgrad.data_ptr()
-        conv_table = conv_table.copy()
-        conv_table["dW"] = pbase + prog.conv_off[:-1] * 4
-        bn_table = bn_table.copy()
-        bn_table["dweight"] = pbase + (total_w + prog.bn_off[:-1]) * 4
-        bn_table["dbias"] = pbase + (total_w + total_c + prog.bn_off[:-1]) * 4
-        need_in = bool(ctx.needs_input_grad[0])
-        _call("gpn_net_backward", prog, slots, rb_table, conv_table, bn_table,
-              (1 if ctx.training else 0, 1 if need_in else 0), dev)
-        if GF.CONV_LOG is not None:
-            for _, op in prog.conv_ops:
-                conv, (rb, rb_t) = prog.convs[op[5]], rb_objs[op[4]]
-                if op[1] != 0 or need_in:
-                    GF._log(rb_t, conv.out_channels, conv.in_channels, "dgrad")
-                GF._log(rb, conv.in_channels, conv.out_channels, "wgrad")
-        din = garena[:features.numel()].view_as(features) if need_in else None
+        din, pgrad, views, params = _backward_impl(ctx, dout, fresh, bool(ctx.needs_input_grad[0]))
         if fresh:
             for p, g in zip(params, views):
                 if not p.requires_grad:
@@ -396,8 +458,25 @@ class _NetFn(torch.autograd.Function):
                 if p.requires_grad:
                     p.grad = g
             prog.last_pgrad = pgrad  # grad_sync all-reduces this buffer in place (its slices are the parameters' .grad)
-        ctx.state = None
         return din, None, None, None, None
+
+
+class _NetFnAutograd(torch.autograd.Function):
+    """the same program with its parameters as autograd inputs (``set_autograd_parameters(True)``, GPN_NET_AUTOGRAD_PARAMS=1,
+    or any parameter carrying a tensor hook): gradients are returned to autograd from a private buffer, so
+    ``torch.autograd.grad``, ``backward(inputs=...)``, hooks and retained gradients behave as for any other op."""
+
+    @staticmethod
+    def forward(ctx, features, prog: NetProgram, rt, training, *params):
+        return _forward_impl(ctx, features, prog, rt, training)
+
+    @staticmethod
+    def backward(ctx, dout):
+        prog = ctx.prog
+        din, _pgrad, views, params = _backward_impl(ctx, dout, True, bool(ctx.needs_input_grad[0]))
+        prog.last_pgrad = None
+        grads = tuple(g if ctx.needs_input_grad[4 + i] else None for i, g in enumerate(views))
+        return (din, None, None, None) + grads
 
 
 def program_for(unet) -> Optional[NetProgram]:
@@ -438,7 +517,11 @@ def run(unet, x):
     if training:
         with torch.no_grad():
             torch._foreach_add_([bn.num_batches_tracked for bn in prog.bns], 1)
-    out = _NetFn.apply(x.features, prog._anchor, prog, (rows, rb_table, rb_objs), training)
+    params = prog.params()
+    if _AUTOGRAD_PARAMS or any(_has_hooks(p) for p in params):
+        out = _NetFnAutograd.apply(x.features, prog, (rows, rb_table, rb_objs), training, *params)
+    else:
+        out = _NetFn.apply(x.features, prog._anchor, prog, (rows, rb_table, rb_objs), training)
     lvl = prog.slot_level[prog.out_slot]
     idx, shape = levels[lvl]
     return spconv.SparseConvTensor(out, idx, shape, x.batch_size, x.indice_dict)

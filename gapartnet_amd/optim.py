@@ -20,14 +20,18 @@ _TABLE_DT = np.dtype([("param", np.uint64), ("grad", np.uint64), ("exp_avg", np.
 
 
 class FusedAdam(torch.optim.Adam):
+    _MAX_TABLE_SETS = 4  # device-table sets kept per parameter group (alternating proposal / no-proposal steps reuse theirs)
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **kw):
         kw.pop("fused", None)
         super().__init__(params, lr=lr, betas=betas, eps=eps, **kw)
-        self._cache = {}     # group index -> (gradient signature, [(table, block_first, n_blocks, params)] per step count)
+        # group index -> {signature: table sets}: a signature covers everything the device tables point at (see _signature)
+        self._cache = {}
         self._nstep = {}     # parameter -> steps taken (the ``step`` tensors of the state are refreshed on state_dict())
         # gradients whose address changes from step to step (allocated by autograd for the few non-U-Net tensors) are
         # copied into buffers of their own before the update (one foreach copy), so that the device table stays valid
         self._own_grad = {}
+        self._last_sig = {}  # group index -> signature of the previous step (to see which gradients moved)
 
     # ---------------------------------------------------------------------------------------------- state (de)serialisation
     def _sync_step_tensors(self):
@@ -42,8 +46,24 @@ class FusedAdam(torch.optim.Adam):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        # a checkpoint written by torch's own Adam may carry fused / foreach / capturable = True: this class decides per step
+        # whether its kernel or torch's single-tensor path runs, and the latter must not see fused=True next to CPU step tensors
+        for group in self.param_groups:
+            group["fused"] = None
+            group["foreach"] = None
+            group["capturable"] = False
+        for st in self.state.values():
+            if "step" in st and torch.is_tensor(st["step"]) and st["step"].is_cuda:
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
         self._cache.clear()
+        self._last_sig.clear()
         self._nstep = {p: int(st["step"]) for p, st in self.state.items() if "step" in st}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_cache"):
+            self._cache.clear()
+            self._last_sig.clear()
 
     # ---------------------------------------------------------------------------------------------- step
     @staticmethod
@@ -56,6 +76,28 @@ class FusedAdam(torch.optim.Adam):
     def _grad_ptr(self, p):
         own = self._own_grad.get(p)
         return own.data_ptr() if own is not None else p.grad.data_ptr()
+
+    def _signature(self, group):
+        """everything a table set depends on: per parameter the addresses of gradient (1 = a buffer of this class), value and
+        the two moment tensors, plus the group's switches that decide between the kernel and torch's path.  One cheap host
+        pass per step; without the value / state addresses a ``model.float()``, ``p.data = ...``,
+        ``load_state_dict(assign=True)`` or a cleared ``optimizer.state`` would leave the kernel writing through stale
+        pointers."""
+        own, state = self._own_grad, self.state
+        sig = []
+        for p in group["params"]:
+            g = p.grad
+            if g is None:
+                sig.append(0)
+                continue
+            st = state.get(p)
+            if st and "exp_avg" in st:
+                sig.append((1 if p in own else g.data_ptr(), p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
+            else:
+                sig.append((1 if p in own else g.data_ptr(), p.data_ptr(), 0, 0))
+        hyper = (bool(group["amsgrad"]), group["weight_decay"], bool(group["maximize"]), bool(group.get("capturable", False)),
+                 bool(group.get("differentiable", False)))
+        return hyper, tuple(sig)
 
     def _build(self, group, params):
         """device tables for the parameters that have a gradient, one per distinct step count (parameters the training
@@ -87,6 +129,18 @@ class FusedAdam(torch.optim.Adam):
             subs.append((h_table.to(dev, non_blocking=True), h_first.to(dev, non_blocking=True), blocks, plist, (h_table, h_first)))
         return subs
 
+    def _torch_step(self, group, params):
+        """torch's own implementation, for this group only (CPU tensors, amsgrad, weight decay, ...)"""
+        self._sync_step_tensors()
+        saved = self.param_groups
+        self.param_groups = [group]
+        try:
+            super().step()
+        finally:
+            self.param_groups = saved
+        for p in params:
+            self._nstep[p] = int(self.state[p]["step"])
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -99,37 +153,41 @@ class FusedAdam(torch.optim.Adam):
                 moved = [p for p in own if p.grad is not None]
                 if moved:
                     torch._foreach_copy_([own[p] for p in moved], [p.grad for p in moved])
-            ptrs = [0 if p.grad is None else (1 if p in own else p.grad.data_ptr()) for p in group["params"]]
-            cached = self._cache.get(gi)
-            if cached is None or cached[0] != ptrs:
+            sig = self._signature(group)
+            sets = self._cache.setdefault(gi, {})
+            tables = sets.get(sig)
+            if tables is None:
                 params = [p for p in group["params"] if p.grad is not None]
                 if not params:
                     continue
-                if cached is not None:  # which gradients moved since the tables were built?  they get buffers of their own
-                    for p, old, new in zip(group["params"], cached[0], ptrs):
-                        if old > 1 and new > 1 and old != new and p.grad.is_cuda:
+                # which gradients moved since the previous step?  they get buffers of their own (their tables stay valid)
+                last = self._last_sig.get(gi)
+                if last is not None and len(last[1]) == len(sig[1]):
+                    changed = False
+                    for p, old, new in zip(group["params"], last[1], sig[1]):
+                        if old and new and old[0] > 1 and new[0] > 1 and old[0] != new[0] and p.grad.is_cuda:
                             own[p] = p.grad.detach().clone()
-                    ptrs = [0 if p.grad is None else (1 if p in own else p.grad.data_ptr()) for p in group["params"]]
-                if not self._native_ok(group, params):
-                    self._cache.pop(gi, None)
-                    self._sync_step_tensors()
-                    saved = self.param_groups
-                    self.param_groups = [group]  # torch's implementation, for this group only
-                    try:
-                        super().step()
-                    finally:
-                        self.param_groups = saved
-                    for p in params:
-                        self._nstep[p] = int(self.state[p]["step"])
-                    continue
-                cached = (ptrs, self._build(group, params))
-                self._cache[gi] = cached
+                            changed = True
+                    if changed:
+                        sig = self._signature(group)
+                        tables = sets.get(sig)
+                if tables is None:
+                    if not self._native_ok(group, params):
+                        self._last_sig[gi] = sig
+                        self._torch_step(group, params)
+                        continue
+                    tables = self._build(group, params)
+                    sig = self._signature(group)  # (the moment tensors may have been created by _build)
+                    while len(sets) >= self._MAX_TABLE_SETS:
+                        sets.pop(next(iter(sets)))
+                    sets[sig] = tables
+            self._last_sig[gi] = sig
             L = _C.lib()
-            dev = cached[1][0][3][0].device
+            dev = tables[0][3][0].device
             stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
             beta1, beta2 = group["betas"]
             nstep = self._nstep
-            for table, first, blocks, plist, _pinned in cached[1]:
+            for table, first, blocks, plist, _pinned in tables:
                 n = nstep[plist[0]] + 1
                 _C.check(L.gpn_adam_step(ctypes.c_void_p(table.data_ptr()), ctypes.c_void_p(first.data_ptr()), len(plist), blocks,
                                          ctypes.c_double(group["lr"]), ctypes.c_double(beta1), ctypes.c_double(beta2),

@@ -103,7 +103,9 @@ def test_full_size_properties(cuda, n_scenes, n_points):
 
 
 def test_full_size_train_step_runs_and_is_deterministic(cuda):
-    batch = [pc.to(cuda) for pc in make_batch(4, 20000)]
+    """BASELINE config 3's per-GPU shape at FULL size: batch 8 x 20k-point scenes, every head on - finite loss, every
+    parameter receives a finite gradient, two runs are bit-identical (losses and every gradient)"""
+    batch = [pc.to(cuda) for pc in make_batch(8, 20000)]
     jitter = (torch.tensor([0.3, 0.6, 0.1], device=cuda), torch.tensor([0.5, 0.2, 0.9], device=cuda))
     losses, grads = [], []
     for _ in range(2):
@@ -112,9 +114,111 @@ def test_full_size_train_step_runs_and_is_deterministic(cuda):
         loss = model.training_step(batch, 0)
         loss.backward()
         losses.append(float(loss))
-        grads.append(model.backbone.stem[0].weight.grad.clone())
+        missing = [k for k, p in model.named_parameters() if p.grad is None]
+        assert not missing, f"parameters without a gradient in the full pipeline: {missing[:5]}"
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
     assert np.isfinite(losses[0]) and losses[0] == losses[1], losses
-    assert torch.equal(grads[0], grads[1]), "conv fwd / dgrad / wgrad are fixed-order: bitwise reproducible"
+    for k in grads[0]:
+        assert bool(torch.isfinite(grads[0][k]).all()), k
+        assert torch.equal(grads[0][k], grads[1][k]), f"{k}: conv / BatchNorm sums / wgrad are order-independent: bitwise reproducible"
+
+
+@pytest.mark.parametrize("epoch,expect", [(0, (False, False)), (5, (True, False)), (10, (True, True))])
+def test_training_schedule_phases_on_the_full_model(cuda, epoch, expect):
+    """gapartnet.yaml's training_schedule [5, 10] on the full 7-level model (network/model.py:466-659 of the reference):
+    epoch < 5 trains backbone + point heads only, 5-9 adds ScoreNet, >= 10 adds NPCS-Net - which sub-networks receive
+    gradients and which loss terms are logged"""
+    score_on, npcs_on = expect
+    model = make_model((5, 10)).to(cuda)
+    model._current_epoch = epoch
+    model.revoxelize_jitter = (torch.tensor([0.3, 0.6, 0.1], device=cuda), torch.tensor([0.5, 0.2, 0.9], device=cuda))
+    logged = {}
+    model._log_sink = lambda name, value, bs, sync: logged.setdefault(name, float(value))
+    batch = [pc.to(cuda) for pc in make_batch(4, 20000)]
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    assert np.isfinite(float(loss))
+
+    def has_grad(prefix):
+        ps = [p for k, p in model.named_parameters() if k.startswith(prefix)]
+        assert ps, prefix
+        got = [p.grad is not None and bool((p.grad != 0).any()) for p in ps]
+        assert all(got) or not any(got), f"{prefix}: some parameters trained, some not"
+        return all(got)
+
+    assert has_grad("backbone.") and has_grad("sem_seg_head.") and has_grad("offset_head.")
+    assert has_grad("score_unet.") == score_on and has_grad("score_head.") == score_on
+    assert has_grad("npcs_unet.") == npcs_on and has_grad("npcs_head.") == npcs_on
+    # the reference logs all five loss terms in every phase (a switched-off term is the constant 0.0), model.py:572-590 there
+    want = {f"train_loss/{k}" for k in ("total_loss", "loss_sem_seg", "loss_offset_dist", "loss_offset_dir", "loss_prop_score",
+                                        "loss_prop_npcs")} | {"train/all_accu", "train/pixel_accu"}
+    assert want <= set(logged), sorted(logged)
+    assert (logged["train_loss/loss_prop_score"] > 0) == score_on, logged
+    assert (logged["train_loss/loss_prop_npcs"] > 0) == npcs_on, logged
+    assert logged["train_loss/loss_sem_seg"] > 0 and logged["train_loss/loss_offset_dist"] > 0
+    assert all(np.isfinite(v) for v in logged.values()), logged
+
+
+def test_executor_gradient_hand_over_contract(cuda):
+    """network/net_exec.py hands U-Net parameter gradients over directly (persistent flat buffer, ``.grad`` assigned, no
+    AccumulateGrad nodes).  What that must not break: a gradient somebody keeps is not overwritten by the next backward, a
+    frozen parameter gets none, a tensor hook fires (the call switches to the autograd form), and with
+    ``set_autograd_parameters(True)`` ``torch.autograd.grad`` works and agrees."""
+    from gapartnet_amd.network import net_exec
+    net, idx, feats, spconv = _unet_case(cuda, True)
+    net.train(True)
+    names = [k for k, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+
+    def run(scale=1.0, retain=False):
+        f = feats.clone().requires_grad_(True)
+        y = net(spconv.SparseConvTensor(f, idx, [64, 64, 64], 3)).features
+        loss = (y.square().sum()) * scale
+        return loss, f
+
+    loss, _ = run()
+    loss.backward()
+    ref = {k: p.grad.clone() for k, p in zip(names, params)}
+    kept = params[0].grad                       # somebody holds on to a gradient (accumulation, deferred logging)
+    kept_copy = kept.clone()
+    net.zero_grad(set_to_none=True)
+    loss, _ = run(scale=3.0)
+    loss.backward()
+    assert torch.equal(kept, kept_copy), "a retained gradient must survive the next backward"
+    assert params[0].grad is not kept and torch.allclose(params[0].grad, 3.0 * kept_copy, rtol=1e-4, atol=1e-6)
+    # frozen parameter
+    net.zero_grad(set_to_none=True)
+    params[0].requires_grad_(False)
+    loss, _ = run()
+    loss.backward()
+    assert params[0].grad is None and all(p.grad is not None for p in params[1:])
+    assert torch.allclose(params[1].grad, ref[names[1]], rtol=1e-4, atol=1e-5 * float(ref[names[1]].abs().max()))
+    params[0].requires_grad_(True)
+    # a hook switches the call to the autograd form and fires
+    net.zero_grad(set_to_none=True)
+    fired = []
+    h = params[2].register_hook(lambda g: fired.append(g.shape))
+    loss, _ = run()
+    loss.backward()
+    h.remove()
+    assert fired == [params[2].shape]
+    for k, p in zip(names, params):
+        assert torch.allclose(p.grad, ref[k], rtol=1e-4, atol=1e-5 * float(ref[k].abs().max()) + 1e-7), k
+    # autograd form on request: torch.autograd.grad on U-Net parameters
+    net.zero_grad(set_to_none=True)
+    prev = net_exec.set_autograd_parameters(True)
+    try:
+        loss, _ = run()
+        got = torch.autograd.grad(loss, params)
+    finally:
+        net_exec.set_autograd_parameters(prev)
+    assert all(p.grad is None for p in params), "autograd.grad must not populate .grad"
+    for k, g in zip(names, got):
+        assert torch.allclose(g, ref[k], rtol=1e-4, atol=1e-5 * float(ref[k].abs().max()) + 1e-7), k
+    # ... and in the default form the same request fails loudly (documented contract), it does not return garbage
+    loss, _ = run()
+    with pytest.raises(RuntimeError):
+        torch.autograd.grad(loss, params[:1])
 
 
 def _unet_case(cuda, without_stem):
@@ -378,6 +482,61 @@ def test_prefetcher_prepares_raw_scenes_on_the_gpu(cuda, augment):
     loss = model.training_step(batch, 0)
     loss.backward()
     assert torch.isfinite(loss)
+
+
+@pytest.mark.gpu
+def test_fused_adam_follows_moved_storage_and_changed_switches(cuda):
+    """the device tables hold raw addresses of value / gradient / moments: replacing a parameter's storage (``p.data = ...``
+    as ``model.float()`` / ``load_state_dict(assign=True)`` do), replacing a moment tensor, clearing the state of one
+    parameter and switching weight decay on mid-run must all be picked up (the step signature covers them) - same
+    trajectory as torch.optim.Adam, no write through a stale pointer"""
+    from gapartnet_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(16, 27, 16), (32,), (4096, 3)]
+    base = [torch.randn(s, generator=g).to(cuda) for s in shapes]
+    a = [torch.nn.Parameter(t.clone()) for t in base]
+    b = [torch.nn.Parameter(t.clone()) for t in base]
+    opt_a = FusedAdam(a, lr=1e-2)
+    opt_b = torch.optim.Adam(b, lr=1e-2, foreach=False, fused=False)
+    grad_bufs = [torch.empty_like(p) for p in a]  # persistent gradient buffers, like the executor's
+
+    def both_step():
+        for p, q, buf in zip(a, b, grad_bufs):
+            buf.copy_(torch.randn(p.shape, generator=g).to(cuda))
+            p.grad, q.grad = buf, buf.clone()
+        opt_a.step()
+        opt_b.step()
+
+    both_step()
+    both_step()
+    old_storage = a[0].data
+    a[0].data = a[0].data.clone()                                   # the parameter's storage moves
+    both_step()
+    assert torch.equal(old_storage, old_storage.clone()) and not torch.equal(old_storage, a[0].data), "old storage untouched"
+    opt_a.state[a[2]]["exp_avg"] = opt_a.state[a[2]]["exp_avg"].clone()  # a moment tensor is replaced
+    both_step()
+    for group in (opt_a.param_groups[0], opt_b.param_groups[0]):
+        group["weight_decay"] = 0.01                                # needs torch's path from now on
+    both_step()
+    both_step()
+    opt_a.state_dict()
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-6), float((p - q).abs().max())
+        assert float(opt_a.state[p]["step"]) == float(opt_b.state[q]["step"]) == 6.0
+        assert torch.allclose(opt_a.state[p]["exp_avg"], opt_b.state[q]["exp_avg"], rtol=1e-5, atol=1e-7)
+    # a checkpoint of torch's fused Adam (fused=True, device step tensors) loads and keeps training on either path
+    opt_f = torch.optim.Adam([torch.nn.Parameter(t.clone()) for t in base], lr=1e-2, fused=True)
+    for p in opt_f.param_groups[0]["params"]:
+        p.grad = torch.ones_like(p)
+    opt_f.step()
+    opt_d = FusedAdam([torch.nn.Parameter(t.clone()) for t in base], lr=1e-2)
+    opt_d.load_state_dict(opt_f.state_dict())
+    assert not opt_d.param_groups[0].get("fused") and not opt_d.param_groups[0].get("capturable")
+    for p in opt_d.param_groups[0]["params"]:
+        p.grad = torch.ones_like(p)
+    opt_d.step()
+    opt_d.param_groups[0]["weight_decay"] = 0.1
+    opt_d.step()  # torch's single-tensor path with the loaded (now CPU) step tensors
 
 
 @pytest.mark.gpu

@@ -86,3 +86,36 @@ def test_batched_fit_on_the_gpu_matches_the_cpu(cuda):
     ok = want["valid"]
     for name in ("scale", "rotation", "translation", "transform", "bbox"):
         assert torch.allclose(got[name].cpu()[ok], want[name][ok], atol=1e-8), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 3])
+def test_batched_fit_on_the_gpu_equals_the_sequential_fit_for_the_same_picks(cuda, seed, monkeypatch):
+    """the device run against the sequential per-proposal function (misc/pose_fitting.py, pinned to the reference by
+    tests/golden/umeyama.npz) with identical sample picks: same inlier sets, same pose to 1e-8 (float64 on the device)"""
+    rng = np.random.default_rng(seed)
+    specs = [(200, 0.0, 0.0), (150, 0.01, 0.0), (300, 0.02, 0.3), (7, 0.0, 0.0), (40, 0.05, 0.1), (600, 0.01, 0.25)]
+    clouds = [_proposal(rng, *sp) for sp in specs]
+    sizes = [c[0].shape[0] for c in clouds]
+    np.random.seed(seed)
+    picks = draw_picks(sizes, 100)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]))
+    xyz = torch.from_numpy(np.concatenate([c[0] for c in clouds]))
+    npcs = torch.from_numpy(np.concatenate([c[1] for c in clouds]))
+    got = estimate_pose_from_npcs_batched(xyz.to(cuda), npcs.to(cuda), offsets.to(cuda), picks=picks.to(cuda))
+    got = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in got.items()}
+    for p, (cx, cn) in enumerate(clouds):
+        bbox, scale, rot, trans, transform, idx = _sequential_with_picks(cx, cn, picks[p].numpy(), monkeypatch)
+        if scale[0] is None:
+            assert not bool(got["valid"][p]), p
+            continue
+        assert bool(got["valid"][p]), p
+        lo, hi = int(offsets[p]), int(offsets[p + 1])
+        mask = np.zeros(hi - lo, bool)
+        mask[idx] = True
+        assert np.array_equal(got["inlier_mask"][lo:hi].numpy(), mask), p
+        assert np.allclose(got["scale"][p].item(), scale[0], rtol=1e-8)
+        assert np.allclose(got["rotation"][p].numpy(), rot, atol=1e-8)
+        assert np.allclose(got["translation"][p].numpy(), trans, atol=1e-8)
+        assert np.allclose(got["transform"][p].numpy(), transform, atol=1e-8)
+        assert np.allclose(got["bbox"][p].numpy(), bbox, atol=1e-7)
