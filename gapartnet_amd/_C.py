@@ -56,6 +56,7 @@ def lib():
         _lib.gpn_scatter_rows_csr.argtypes = [vp, vp, vp, i64t, i32t, vp, vp]
         _lib.gpn_spconv_tiles_min_tiles.argtypes = [i64t]
         _lib.gpn_spconv_tiles_min_tiles.restype = i64t
+        _lib.gpn_spconv_direct_split.argtypes = [i64t, i64t]
     return _lib
 
 

@@ -541,6 +541,7 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
   GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
   GPN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   const int C4 = C / 4;
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (res ? 4 : 3));  // x twice (statistics, apply) [+ res], y
   if (N <= kSmallRows) {
     // (the forward kernel stays at 256 threads: at 1024 it measured 51 us instead of 10 - every thread carries the
     // double-precision mean / 1/sqrt epilogue; the backward kernel, three streams and no epilogue, gains from 1024)
@@ -599,6 +600,7 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
   GPN_CHECK_ARG(x && dy && weight && mean && invstd && dx && dweight && dbias && ws && (y || !relu));
   GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
   const int C4 = C / 4;
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (7 + (dres ? 1 : 0)));  // x, y, dy twice each; dx [, dres]
   if (N <= kSmallRows) {
     // few workgroups, each a serial chain of row loads: 1024 threads per workgroup keep the chain one batch long
     if (C4 % 4 == 0 && N > 256)
@@ -644,6 +646,7 @@ int gpn::bn_fwd_train_fused(const float* x, const float* res, const float* weigh
   GPN_CHECK_ARG(gpn::bn_two_pass(N, C) && x && weight && bias && y && mean && invstd && slab);
   GPN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   const int64_t total4 = N * (C / 4);
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (res ? 3 : 2));  // x [+ res] read, y written
   hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<true>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, res,
                      (const void*)slab, 0, N, weight, bias, total4, C / 4, eps, momentum, relu, y, mean, invstd, running_mean,
                      running_var);
@@ -656,6 +659,7 @@ int gpn::bn_bwd_fused(const float* x, const float* y, const float* dy, const flo
                       float* dbias, const unsigned long long* slab, hipStream_t stream) {
   GPN_CHECK_ARG(gpn::bn_two_pass(N, C) && x && dy && weight && mean && invstd && dx && dweight && dbias && slab && (y || !relu));
   const int64_t total4 = N * (C / 4);
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (4 + (dres ? 1 : 0)));  // x, y, dy read; dx [, dres] written
   hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<true>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, y, dy,
                      (const void*)slab, 0, mean, invstd, weight, total4, C / 4, 1.0f / (float)N, relu, training, dx, dres, dweight,
                      dbias);

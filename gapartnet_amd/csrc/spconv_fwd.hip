@@ -424,10 +424,173 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(unit & (gpn::kStatSlots - 1)), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
 }
 
+// Tap-split form of the direct kernel for layers with FEW (tile, column tile) units (round 3).  A level of a few thousand
+// rows gives a launch of the direct kernel fewer waves than the chip has SIMDs (1.8k rows x 80 channels: 575), and each wave
+// then is one serial chain of KT x CB dependent (gather, weight fragment, 4 MFMA) stages - 17k cycles of matrix pipe for
+// that wave alone while three quarters of the SIMDs idle.  Here the SP (2 or 4) waves of a unit each walk a contiguous
+// SP-th of the taps with the same register rings, leave their accumulators in LDS, and the unit's first wave adds them in
+// wave order and stores (plus the BatchNorm sums): SP x the waves, chains 1 / SP as long, one launch, fixed summation order
+// (per wave: taps ascending, two-level as in the direct kernel; then (((p0 + p1) + p2) + p3)) => deterministic.
+template <int KT, int CB, int SP>
+__global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __restrict__ in, const float* __restrict__ packed,
+                                                               const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
+                                                               int64_t units, size_t packed_bytes,
+                                                               const int32_t* __restrict__ perm, int accumulate,
+                                                               gpn::ConvStats stats, float* __restrict__ out) {
+  constexpr int TP = (KT + SP - 1) / SP;  // taps per wave
+  constexpr int S = TP * CB;              // stages per wave
+  constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;
+  constexpr int UPW = 4 / SP;             // units per workgroup
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int64_t wg = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t unit = wg * UPW + wave / SP;
+  const int part = wave % SP;
+  const int tap0 = part * TP;
+  const bool active = unit < units;  // (no early return: every wave reaches the barrier below)
+  const int64_t tile = active ? unit / nt_total : 0;
+  const int nt = active ? (int)(unit - tile * nt_total) : 0;
+  const int cin = CB * 16, cout = nt_total * 16;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t nbr_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(nbr), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed), 0, (int)packed_bytes, 0x00020000);
+  const uint32_t col_bytes = (uint32_t)n_dst * 4u;
+  const int64_t row0 = tile * 16;
+  const bool row_ok = active && row0 + i16 < n_dst;
+  const uint32_t rc = (uint32_t)(row_ok ? row0 + i16 : n_dst - 1);
+
+  constexpr int DI = TP < 10 ? TP : 10;
+  static_assert(DI == TP || DI >= D + 2, "the index of a stage issued D stages ahead must already be in the ring");
+  int32_t ireg[DI];
+  auto load_idx = [&](int j) -> int32_t {  // local tap j = global tap tap0 + j (past the last tap: tap KT - 1 re-read, masked below)
+    const int tap = tap0 + j < KT ? tap0 + j : KT - 1;
+    return __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(nbr_rsrc, (int)(rc * 4u), (int)((uint32_t)tap * col_bytes), 0));
+  };
+  auto tap_idx = [&](int j) -> int32_t { return (row_ok && tap0 + j < KT) ? ireg[j % DI] : -1; };
+#pragma unroll
+  for (int u = 0; u < DI; ++u) ireg[u] = load_idx(u);
+  f32x4 areg[D], breg[D];
+  auto issue = [&](int s, int slot) {  // s = local tap * CB + cb: compile-time after unrolling
+    const int j = s / CB, cb = s - j * CB;
+    const int32_t idx = tap_idx(j);
+    const bool live = __builtin_amdgcn_sicmp(idx, -1, 38 /* ICMP_SGT */) != 0;  // wave-uniform: some row of the tile has the tap
+    const uint32_t off = idx < 0 ? 0x80000000u : ((uint32_t)idx * (uint32_t)cin + 4u * (uint32_t)g) * 4u;
+    const int tap = tap0 + j < KT ? tap0 + j : KT - 1;
+    const uint32_t boff = live ? (uint32_t)(((tap * CB + cb) * nt_total + nt) * 1024 + lane * 16) : 0x80000000u;
+    areg[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, cb * 64, 0));
+    breg[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)boff, 0, 0));
+  };
+#pragma unroll
+  for (int s = 0; s < D; ++s) issue(s, s);
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    if (__builtin_amdgcn_sicmp(tap_idx(j), -1, 38 /* ICMP_SGT */) != 0) {  // some row of the tile has this tap
+      f32x4 part_sum = zero;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int s = j * CB + cb;
+        const f32x4 a = areg[s % D], b = breg[s % D];
+        if (s + D < S) issue(s + D, s % D);
+        part_sum = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, part_sum, 0, 0, 0);
+        part_sum = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, part_sum, 0, 0, 0);
+        part_sum = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, part_sum, 0, 0, 0);
+        part_sum = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, part_sum, 0, 0, 0);
+      }
+      acc += part_sum;  // (in the MFMAs' block: see the compiler trap noted at the direct kernel)
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int s = j * CB + cb;
+        if (s + D < S) issue(s + D, s % D);
+      }
+    }
+    if (j + DI < TP) ireg[j % DI] = load_idx(j + DI);
+    asm volatile("" ::: "memory");
+  }
+  // the unit's partial sums -> its first wave, added in wave order
+  if (part != 0) red[wave][lane] = acc;
+  __syncthreads();
+  if (part != 0 || !active) return;
+#pragma unroll
+  for (int q = 1; q < SP; ++q) acc += red[wave + q][lane];
+
+  int32_t orow[4];
+  if (perm) {
+    const int4 pv = *reinterpret_cast<const int4*>(perm + row0 + 4 * g);
+    orow[0] = pv.x, orow[1] = pv.y, orow[2] = pv.z, orow[3] = pv.w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + 4 * g + r;
+      orow[r] = (int32_t)(row < n_dst ? row : n_dst - 1);
+    }
+  }
+  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr, st_bwd = stats.slab != nullptr && stats.x != nullptr;
+  const uint32_t col = (uint32_t)(nt * 16 + i16);
+  float s0 = 0.f, s1 = 0.f, mu = 0.f, is = 1.f;
+  if (st_bwd) mu = stats.mean[col], is = stats.invstd[col];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = row0 + 4 * g + r;
+    if (row < n_dst) {
+      const uint32_t e = (uint32_t)orow[r] * (uint32_t)cout + col;
+      float v = acc[r];
+      if (accumulate) v += out[e];
+      out[e] = v;
+      if (st_fwd) {
+        s0 += v;
+        s1 += v * v;
+      } else if (st_bwd) {
+        const float gm = (stats.relu && !(stats.y[e] > 0.f)) ? 0.f : v;
+        s0 += gm;
+        s1 += gm * ((stats.x[e] - mu) * is);
+      }
+    }
+  }
+  if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(unit & (gpn::kStatSlots - 1)), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+  else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(unit & (gpn::kStatSlots - 1)), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+}
+
+// units below which a layer takes the 4-way / 2-way tap-split form (0 = never).  tools/conv_split_sweep.py
+// (profiles/r03_conv_split.txt, us per launch unsplit / 2-way / 4-way): 487 rows 192->96 48 / 18 / 11, 1.8k rows 160->80
+// 67 / 28 / 22, 6.9k rows 64->64 23.2 / 23.4 / 21.1, 25k rows 96->48 75 / 75 / 71, 80k rows 32->32 58.8 / 59.0 / 57.5: the
+// 4-way form never loses, the 2-way form never wins over it => 4-way for every layer the direct kernel takes.
+// env GPN_DIRECT_SPLIT4_UNITS / GPN_DIRECT_SPLIT2_UNITS, or gpn_spconv_direct_split().
+constexpr int64_t kSplit4Units = 12000, kSplit2Units = 0;
+std::atomic<int64_t> g_split4_units{[] {
+  const char* e = getenv("GPN_DIRECT_SPLIT4_UNITS");
+  return (int64_t)(e ? atoll(e) : kSplit4Units);
+}()};
+std::atomic<int64_t> g_split2_units{[] {
+  const char* e = getenv("GPN_DIRECT_SPLIT2_UNITS");
+  return (int64_t)(e ? atoll(e) : kSplit2Units);
+}()};
+
+template <int KT, int CB, int SP>
+int launch_split(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int nt_total,
+                 int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
+  const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
+  const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
+  hipLaunchKernelGGL((spconv_fwd_split_kernel<KT, CB, SP>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4 / SP), 8) * 8)), dim3(256), 0,
+                     stream, in, packed, nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
 template <int KT, int CB>
 int launch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int nt_total,
                   int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
+  if (units < g_split4_units.load(std::memory_order_relaxed))
+    return launch_split<KT, CB, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+  if (units < g_split2_units.load(std::memory_order_relaxed))
+    return launch_split<KT, CB, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
   hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4), 8) * 8)), dim3(256), 0, stream, in, packed,
                      nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out);
@@ -469,6 +632,15 @@ int dispatch_direct(const float* in, const float* packed, const int32_t* nbr, co
 }
 
 }  // namespace
+
+// (tile, column tile) unit counts below which the direct kernel runs in its 4-way / 2-way tap-split form; a negative
+// argument leaves that threshold unchanged; 0 disables the form.  Results of the split forms differ from the unsplit kernel
+// in the order of the last additions only (both deterministic).
+extern "C" int gpn_spconv_direct_split(int64_t split4_below_units, int64_t split2_below_units) {
+  if (split4_below_units >= 0) g_split4_units.store(split4_below_units, std::memory_order_relaxed);
+  if (split2_below_units >= 0) g_split2_units.store(split2_below_units, std::memory_order_relaxed);
+  return GPN_OK;
+}
 
 extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout) {
   if (n_dst <= 0 || cin < 16 || cout < 16) return 0;

@@ -47,7 +47,8 @@ enum {
   GPN_K_RULEBOOK = 3,
   GPN_K_BALL_QUERY = 4,
   GPN_K_CCL = 5,
-  GPN_K_COUNT = 6
+  GPN_K_BN = 6, /* BatchNorm passes (statistics where not taken by a conv epilogue, apply forward / backward) */
+  GPN_K_COUNT = 7
 };
 /* fixed cost of a (start event, launch, stop event) bracket, measured around an empty kernel on `stream` (median, us):
  * subtract it from hipEvent-measured launch durations before comparing them with a profiler's kernel durations. */
@@ -175,6 +176,9 @@ int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, const int32_t
 /* kernel selection knob: layers of >= min_tiles 16-row tiles run on the masked-tile kernel (csrc/spconv_tiles.hip), smaller
  * ones on the direct / lock-step kernels; results are identical.  min_tiles < 0 queries.  Returns the previous value. */
 int64_t gpn_spconv_tiles_min_tiles(int64_t min_tiles);
+/* layers with few (16-row tile, 16-column tile) units run the direct kernel in a tap-split form (2 or 4 waves per unit,
+ * partial sums added in LDS in wave order; csrc/spconv_fwd.hip): thresholds in units, negative = unchanged, 0 = never. */
+int gpn_spconv_direct_split(int64_t split4_below_units, int64_t split2_below_units);
 size_t gpn_spconv_fwd_w_ws_bytes(int K, int64_t n_dst, int cin, int cout);
 int gpn_spconv_fwd_w(const float* in, const float* W, int K, int cin_w, int cout_w, int pack_flags, const int32_t* nbr,
                      int64_t n_dst, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream);

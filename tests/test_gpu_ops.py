@@ -226,11 +226,46 @@ def test_masked_tile_kernel_fwd_dgrad(H, cuda, tiles_everywhere, cin, cout):
         assert np.allclose(host(outs[-1]), ref_out, atol=FP_TOL, rtol=1e-4)
         assert np.allclose(host(dins[-1]), ref_din, atol=FP_TOL, rtol=1e-4)
     assert torch.equal(outs[0], outs[1]) and torch.equal(dins[0], dins[1]), "the tile order must not change a bit"
-    prev = _C.lib().gpn_spconv_tiles_min_tiles(1 << 40)  # the direct kernel on the same inputs
+    prev = _C.lib().gpn_spconv_tiles_min_tiles(1 << 40)  # the (unsplit) direct kernel on the same inputs
+    _C.lib().gpn_spconv_direct_split(0, 0)
     try:
         assert torch.equal(outs[0], H.conv_fwd_ordered(dev(f, cuda), dev(W, cuda), rb))
     finally:
         _C.lib().gpn_spconv_tiles_min_tiles(prev)
+        _C.lib().gpn_spconv_direct_split(12000, 0)
+
+
+@pytest.mark.parametrize("ways", [2, 4])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (48, 48), (80, 80), (160, 80), (96, 112)])
+def test_tap_split_direct_kernel(H, cuda, ways, cin, cout):
+    """the direct kernel's tap-split forms (2 / 4 waves per (tile, column) unit, partial sums added in LDS in wave order):
+    oracle values at 1e-4 for SubM (27 taps: 14 + 13 / 7 + 7 + 7 + 6) and stride-2 (8 taps) tables, two runs bit-equal"""
+    from gapartnet_amd import _C
+    big = 1 << 40
+    _C.lib().gpn_spconv_direct_split(big if ways == 4 else 0, big if ways == 2 else 0)
+    try:
+        rng = np.random.default_rng(cin + 3 * cout + ways)
+        shape = [40, 40, 40]
+        idx = synth.surface_indices(rng, 2, shape, 1500)
+        N = idx.shape[0]
+        f = rng.normal(size=(N, cin)).astype(np.float32)
+        W = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+        rb_ref = O.rulebook_subm3(idx, shape)
+        rb = H.rulebook_subm3(dev(idx, cuda), shape)
+        out = H.conv_fwd(dev(f, cuda), dev(W, cuda), rb)
+        assert np.allclose(host(out), O.spconv_fwd(f, W, rb_ref, N), atol=FP_TOL, rtol=1e-4)
+        assert torch.equal(out, H.conv_fwd(dev(f, cuda), dev(W, cuda), rb)), "fixed summation order"
+        g = rng.normal(size=(N, cout)).astype(np.float32)
+        din = host(H.conv_dgrad(dev(g, cuda), dev(W, cuda), rb, rb, True))
+        assert np.allclose(din, O.spconv_dgrad(g, W, rb_ref, N, N), atol=FP_TOL, rtol=1e-4)
+        if cin <= 96 and cout <= 112:
+            d = O.rulebook_down(idx, shape)
+            _, _, rb_f, _rb_b = H.rulebook_down(dev(idx, cuda), shape, 2)
+            W8 = (rng.normal(size=(8, cin, cout)) / np.sqrt(8 * cin)).astype(np.float32)
+            down = host(H.conv_fwd(dev(f, cuda), dev(W8, cuda), rb_f))
+            assert np.allclose(down, O.spconv_fwd(f, W8, d["fwd"], d["out_indices"].shape[0]), atol=FP_TOL, rtol=1e-4)
+    finally:
+        _C.lib().gpn_spconv_direct_split(12000, 0)
 
 
 def test_masked_tile_kernel_down_inverse_and_ragged_tail(H, cuda, tiles_everywhere):
