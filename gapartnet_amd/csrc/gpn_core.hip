@@ -32,7 +32,7 @@ const char* kEntryPoints[] = {
     "gpn_pn2_furthest_point_sampling", "gpn_pn2_furthest_point_sampling_ws_bytes",
     "gpn_pn2_furthest_point_sampling_ws", "gpn_pn2_three_nn", "gpn_pn2_knn", "gpn_pn2_three_interpolate",
     "gpn_pn2_three_interpolate_grad", "gpn_proposals_max_proposals", "gpn_proposals_build_ws_bytes", "gpn_proposals_build", "gpn_proposals_voxel_mean",
-    "gpn_proposals_voxel_mean_bwd", "gpn_adam_blocks", "gpn_adam_step", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get",
+    "gpn_proposals_voxel_mean_bwd", "gpn_pose_fit_ws_bytes", "gpn_pose_fit", "gpn_adam_blocks", "gpn_adam_step", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get",
     "gpn_last_error", "gpn_version"};
 }  // namespace
 

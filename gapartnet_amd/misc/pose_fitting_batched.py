@@ -1,4 +1,7 @@
-"""NPCS -> camera-frame similarity fit for ALL proposals of a batch at once, on the tensors' device.
+"""NPCS -> camera-frame similarity fit for ALL proposals of a batch at once.  On the GPU the work is
+the HIP entry point ``gpn_pose_fit`` (csrc/pose.hip: every 5-point hypothesis of every proposal in one launch, selection +
+inlier fit + box in a second); the torch formulation below is the same procedure on CPU tensors (the host-side restatement the
+CPU tests compare with the sequential function) and documents the algorithm.
 
 ``misc/pose_fitting.py`` restates the reference (gapartnet/misc/pose_fitting.py:4-147): per proposal, a Python loop of up
 to 100 RANSAC iterations, each a 5-point Umeyama fit (3x3 SVD) and a residual pass over the proposal's points, on CPU
@@ -64,6 +67,26 @@ def _umeyama(src: torch.Tensor, dst: torch.Tensor, weight: Optional[torch.Tensor
     return scale, rotation, translation, torch.where(finite[:, None, None], transform, nan[:, None, None])
 
 
+def _fit_hip(xyz, npcs, offsets, picks, P, M, H, stop_thrsh):
+    import ctypes
+    from .. import _C
+    from ..hip_ops import _stream, _ws, i64, i32, ptr, szt
+    dev, f64 = xyz.device, torch.float64
+    out = {"valid": torch.empty(P, dtype=torch.uint8, device=dev), "scale": torch.empty(P, dtype=f64, device=dev),
+           "rotation": torch.empty(P, 3, 3, dtype=f64, device=dev), "translation": torch.empty(P, 3, dtype=f64, device=dev),
+           "transform": torch.empty(P, 4, 4, dtype=f64, device=dev), "bbox": torch.empty(P, 8, 3, dtype=f64, device=dev),
+           "inlier_mask": torch.empty(M, dtype=torch.uint8, device=dev),
+           "best_iteration": torch.empty(P, dtype=torch.int64, device=dev), "residual": torch.empty(P, H, dtype=f64, device=dev)}
+    L = _C.lib()
+    ws = _ws(L.gpn_pose_fit_ws_bytes(i64(P), i32(H)), dev)
+    _C.check(L.gpn_pose_fit(ptr(xyz), ptr(npcs), ptr(offsets), ptr(picks), i64(P), i64(M), i32(H), ctypes.c_double(stop_thrsh),
+                            ptr(out["valid"]), ptr(out["scale"]), ptr(out["rotation"]), ptr(out["translation"]),
+                            ptr(out["transform"]), ptr(out["bbox"]), ptr(out["inlier_mask"]), ptr(out["best_iteration"]),
+                            ptr(out["residual"]), ptr(ws), szt(ws.numel()), _stream()), "gpn_pose_fit")
+    out["valid"], out["inlier_mask"] = out["valid"].bool(), out["inlier_mask"].bool()
+    return out
+
+
 @torch.no_grad()
 def estimate_pose_from_npcs_batched(xyz: torch.Tensor, npcs: torch.Tensor, offsets: torch.Tensor,
                                     picks: Optional[torch.Tensor] = None, stop_thrsh: float = 0.5, max_iters: int = 100,
@@ -79,6 +102,9 @@ def estimate_pose_from_npcs_batched(xyz: torch.Tensor, npcs: torch.Tensor, offse
         picks = draw_picks(sizes.tolist(), max_iters)
     picks = picks.to(dev).long()
     H = picks.shape[1]
+    if xyz.is_cuda:  # the HIP entry point (csrc/pose.hip): two launches for all proposals and hypotheses
+        return _fit_hip(xyz.to(f64).contiguous(), npcs.to(f64).contiguous(), offsets.contiguous(), picks.contiguous(), P, M, H,
+                        stop_thrsh)
     src_pts, dst_pts = npcs.to(f64), xyz.to(f64)
     pid = torch.repeat_interleave(torch.arange(P, device=dev), sizes, output_size=M)
     local = torch.arange(M, device=dev) - offsets[:-1][pid]

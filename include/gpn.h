@@ -484,6 +484,21 @@ int gpn_adam_blocks(int64_t numel);
 int gpn_adam_step(const gpn_adam_tensor_t* table_dev, const int32_t* block_first_dev, int n_tensors, int n_blocks, double lr,
                   double beta1, double beta2, double eps, int64_t step, gpn_stream_t stream);
 
+/* ================================================================================================
+ * PF - pose fitting.  replaces the per-proposal numpy loop of gapartnet/misc/pose_fitting.py:4-147 (estimate_pose_from_npcs:
+ * 5-point RANSAC over Umeyama similarity fits, Umeyama on the inliers, NPCS-aligned box; callers network/model.py:966-980,
+ * structure/utils.py:172-188) for ALL proposals of a batch: two launches, float64 like the reference.
+ * xyz / npcs [M,3] f64 (proposal p = rows offsets[p]:offsets[p+1], non-empty), picks [P,H,5] i64 = the reference's
+ * np.random.randint(n, size=5) draws per iteration (drawn by the caller: gapartnet_amd.misc.pose_fitting_batched.draw_picks).
+ * outputs: valid [P] u8, scale [P], rotation [P,3,3], translation [P,3], transform [P,4,4], bbox [P,8,3] (NaN where not
+ * valid), inlier_mask [M] u8, best_iteration [P] i64, residual [P,H] (of every hypothesis, as the reference computes it).
+ * ================================================================================================ */
+size_t gpn_pose_fit_ws_bytes(int64_t P, int H);
+int gpn_pose_fit(const double* xyz, const double* npcs, const int64_t* offsets, const int64_t* picks, int64_t P, int64_t M,
+                 int H, double stop_thrsh, uint8_t* valid, double* scale, double* rotation, double* translation,
+                 double* transform, double* bbox, uint8_t* inlier_mask, int64_t* best_iteration, double* residual, void* ws,
+                 size_t ws_bytes, gpn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
