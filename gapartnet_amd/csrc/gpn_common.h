@@ -68,6 +68,10 @@ bool spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout);
 bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout);
 int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
                         int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream);
+// gpn_rulebook_level_counts with row count and level-0 extent on the device (rulebook.hip; used by gpn_voxelize_scenes)
+int rulebook_level_counts_dev(const int32_t* indices, int64_t n_max, const int64_t* n_dev, int64_t batch_size,
+                              const int64_t* max_coord_dev, int n_levels, int64_t* counts, void* ws, size_t ws_bytes,
+                              hipStream_t stream);
 // BatchNorm apply passes over sums a conv launch accumulated (bn.hip); bn_two_pass: the shapes that take them
 bool bn_two_pass(int64_t N, int C);
 int bn_fwd_train_fused(const float* x, const float* res, const float* weight, const float* bias, int64_t N, int C, float eps,

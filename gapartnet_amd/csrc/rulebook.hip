@@ -222,9 +222,15 @@ size_t iscan_temp_bytes(int64_t n) {
 // voxel that inserted it also inserts the coarser ones.  New keys are counted per wave (ballot) with one atomic each.
 __global__ __launch_bounds__(kThreads) void level_counts_kernel(const int32_t* __restrict__ indices, int64_t n_max,
                                                                 const int64_t* __restrict__ n_dev, int nb, int s0, int s1,
-                                                                int s2, int n_levels, uint64_t* __restrict__ tables,
-                                                                uint64_t cap, int64_t* __restrict__ counts) {
+                                                                int s2, const int64_t* __restrict__ max_coord_dev, int n_levels,
+                                                                uint64_t* __restrict__ tables, uint64_t cap,
+                                                                int64_t* __restrict__ counts) {
   const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (max_coord_dev) {  // the level-0 extent from the voxeliser's device statistics: max(largest cell index + 1, 128) per axis
+    s0 = (int)(max_coord_dev[0] + 1 > 128 ? max_coord_dev[0] + 1 : 128);
+    s1 = (int)(max_coord_dev[1] + 1 > 128 ? max_coord_dev[1] + 1 : 128);
+    s2 = (int)(max_coord_dev[2] + 1 > 128 ? max_coord_dev[2] + 1 : 128);
+  }
   const int64_t n = n_dev ? (*n_dev < n_max ? *n_dev : n_max) : n_max;
   bool active = i < n;
   int4 c = make_int4(0, 0, 0, 0);
@@ -534,8 +540,28 @@ extern "C" int gpn_rulebook_level_counts(const int32_t* indices, int64_t n_max, 
   GPN_CHECK_HIP(hipMemsetAsync(ws, 0xff, need, stream));
   gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 16.0 * (double)n_max);
   hipLaunchKernelGGL(level_counts_kernel, dim3((unsigned)gpn::cdiv(n_max, kThreads)), dim3(kThreads), 0, stream, indices, n_max,
-                     n_dev, (int)batch_size, spatial_shape_host[0], spatial_shape_host[1], spatial_shape_host[2], n_levels,
+                     n_dev, (int)batch_size, spatial_shape_host[0], spatial_shape_host[1], spatial_shape_host[2], nullptr, n_levels,
                      static_cast<uint64_t*>(ws), cap, counts);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+// the same with the row count and the level-0 extent still on the device (gpn_voxelize_scenes: no host read in between);
+// counts must be zeroed by the caller
+int gpn::rulebook_level_counts_dev(const int32_t* indices, int64_t n_max, const int64_t* n_dev, int64_t batch_size,
+                                   const int64_t* max_coord_dev, int n_levels, int64_t* counts, void* ws, size_t ws_bytes,
+                                   hipStream_t stream) {
+  GPN_CHECK_ARG(indices && n_dev && max_coord_dev && counts && n_levels >= 1 && n_levels <= 16 && n_max >= 1);
+  const uint64_t cap = level_table_cap(n_max);
+  const size_t need = (size_t)cap * (size_t)n_levels * sizeof(uint64_t);
+  if (!ws || ws_bytes < need) {
+    gpn::set_error("gpn_voxelize_scenes: workspace too small for the level counts (%zu needed, %zu given)", need, ws_bytes);
+    return GPN_ERR_WS;
+  }
+  GPN_CHECK_HIP(hipMemsetAsync(ws, 0xff, need, stream));
+  gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 16.0 * (double)n_max);
+  hipLaunchKernelGGL(level_counts_kernel, dim3((unsigned)gpn::cdiv(n_max, kThreads)), dim3(kThreads), 0, stream, indices, n_max,
+                     n_dev, (int)batch_size, 0, 0, 0, max_coord_dev, n_levels, static_cast<uint64_t*>(ws), cap, counts);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

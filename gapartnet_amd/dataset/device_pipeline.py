@@ -115,8 +115,8 @@ def inst_info_batch(points: torch.Tensor, instance_labels: torch.Tensor, sem_lab
 
 
 @torch.no_grad()
-def prepare_batch(raw: Sequence[PointCloud], voxel_size: Sequence[float], augmentation: Optional[Dict[str, float]] = None
-                  ) -> PointCloudBatch:
+def prepare_batch(raw: Sequence[PointCloud], voxel_size: Sequence[float], augmentation: Optional[Dict[str, float]] = None,
+                  pyramid_levels: int = 0) -> PointCloudBatch:
     """raw scenes (tensors on one device: points, sem_labels, instance_labels, gt_npcs; nothing derived) -> the
     ``PointCloudBatch`` the model trains on: what ``GAPartNetDataset._prepare`` + ``PointCloud.collate`` produce."""
     from ..structure.point_cloud import spconv, voxelize_scenes
@@ -142,8 +142,15 @@ def prepare_batch(raw: Sequence[PointCloud], voxel_size: Sequence[float], augmen
         mats, shifts = draw_augmentation(n_scenes, color_channels=points.shape[1] - 3, **augmentation)
         points = augment_points(points, batch_indices, mats, shifts)
     info = inst_info_batch(points, ins, sem, batch_indices, num_instances)
-    indices, voxel_features, spatial_shape, pc_voxel_id, csr = voxelize_scenes(points[:, :3], points, counts, voxel_size)
+    level_counts = None
+    if pyramid_levels:
+        indices, voxel_features, spatial_shape, pc_voxel_id, csr, level_counts = voxelize_scenes(points[:, :3], points, counts,
+                                                                                                 voxel_size, pyramid_levels)
+    else:
+        indices, voxel_features, spatial_shape, pc_voxel_id, csr = voxelize_scenes(points[:, :3], points, counts, voxel_size)
     voxel_tensor = spconv.SparseConvTensor(voxel_features, indices, spatial_shape, n_scenes)
+    if level_counts:
+        voxel_tensor.level_counts = list(level_counts)
     return PointCloudBatch(
         pc_ids=[pc.pc_id for pc in raw], points=points, batch_indices=batch_indices, batch_size=n_scenes, device=dev,
         voxel_tensor=voxel_tensor, pc_voxel_id=pc_voxel_id, pc_voxel_csr=csr, sem_labels=sem,

@@ -62,14 +62,19 @@ class DevicePrefetcher:
         if raw is None:
             return None
         with torch.cuda.stream(self.stream):
+            backbone = getattr(self.model, "backbone", None)
             if isinstance(raw, PointCloudBatch):
                 batch = raw
             else:
                 pcs = [pc.to(self.device) if hasattr(pc, "to") else pc for pc in raw]
                 raw_scenes = pcs[0].num_instances is None and pcs[0].instance_labels is not None
+                levels = 0  # the backbone's coarse levels: their row counts come back with the voxelisation's one host read
+                if backbone is not None and getattr(backbone, "use_native_executor", False):
+                    from ..network import net_exec
+                    prog = net_exec.program_for(backbone)
+                    levels = prog.n_levels - 1 if prog is not None and prog.n_levels > 2 else 0
                 batch = PointCloud.collate(pcs, voxel_size=self.model.voxel_size,
-                                           augmentation=self.augmentation if raw_scenes else None)
-            backbone = getattr(self.model, "backbone", None)
+                                           augmentation=self.augmentation if raw_scenes else None, pyramid_levels=levels)
             if backbone is not None and getattr(backbone, "use_native_executor", False) and batch.voxel_tensor is not None:
                 from ..network import net_exec
                 prog = net_exec.program_for(backbone)

@@ -389,7 +389,12 @@ class GAPartNet(LightningModule):
     def _collate(self, point_clouds: Union[Sequence[PointCloud], PointCloudBatch]) -> PointCloudBatch:
         if isinstance(point_clouds, PointCloudBatch):
             return point_clouds
-        return PointCloud.collate(point_clouds, voxel_size=self.voxel_size)
+        levels = 0  # the backbone's coarse levels: their row counts ride on the voxelisation's single host read
+        if getattr(self.backbone, "use_native_executor", False) and point_clouds and point_clouds[0].points.is_cuda:
+            from . import net_exec
+            prog = net_exec.program_for(self.backbone)
+            levels = prog.n_levels - 1 if prog is not None and prog.n_levels > 2 else 0
+        return PointCloud.collate(point_clouds, voxel_size=self.voxel_size, pyramid_levels=levels)
 
     def _training_or_validation_step(self, point_clouds, batch_idx: int, running_mode: str):
         data_batch = self._collate(point_clouds)

@@ -510,7 +510,10 @@ def run(unet, x):
         if bn.training != training:
             return None
     if prog.python_stem_conv is not None:
+        known = getattr(x, "level_counts", None)
         x = prog.python_stem_conv(x)
+        if known is not None:
+            x.level_counts = known  # same voxel set: the coarse levels' row counts that came with the voxelisation's read
     rows, rb_table, rb_objs, levels = prog.rulebooks(x)
     if int(rows.min()) < 1 or x.features.shape[1] != prog.slot_channels[0]:
         return None

@@ -75,7 +75,9 @@ class PointCloud:
     # -------------------------------------------------------------------------------------------------
     @staticmethod
     def collate(point_clouds: Sequence["PointCloud"], voxel_size: Optional[Sequence[float]] = None,
-                augmentation: Optional[Dict[str, float]] = None) -> PointCloudBatch:
+                augmentation: Optional[Dict[str, float]] = None, pyramid_levels: int = 0) -> PointCloudBatch:
+        """``pyramid_levels`` (the caller's U-Net depth - 1; the device prefetcher passes it): the row counts of that many
+        stride-2 levels come back with the voxelisation's single host read and ride on ``voxel_tensor.level_counts``"""
         n_scenes = len(point_clouds)
         first = point_clouds[0]
         if first.num_instances is None and first.instance_labels is not None and first.voxel_coords is None:
@@ -83,7 +85,7 @@ class PointCloud:
             # statistics run here, per batch, on the scenes' device
             from ..dataset.device_pipeline import prepare_batch
             assert voxel_size is not None, "un-voxelised scenes need voxel_size"
-            return prepare_batch(point_clouds, voxel_size, augmentation)
+            return prepare_batch(point_clouds, voxel_size, augmentation, pyramid_levels=pyramid_levels)
         assert not augmentation, "augmentation at collate time needs raw scenes (GAPartNetDataset(device_pipeline=True))"
         device = first.points.device
         counts = [int(pc.points.shape[0]) for pc in point_clouds]
@@ -130,9 +132,16 @@ class PointCloud:
             pc_voxel_id = torch.cat(shifted, dim=0)
         else:
             assert voxel_size is not None, "un-voxelised scenes need voxel_size"
-            indices, voxel_features, spatial_shape, pc_voxel_id, csr = voxelize_scenes(points[:, :3], points, counts, voxel_size)
+            level_counts = None
+            if pyramid_levels:
+                indices, voxel_features, spatial_shape, pc_voxel_id, csr, level_counts = voxelize_scenes(
+                    points[:, :3], points, counts, voxel_size, pyramid_levels)
+            else:
+                indices, voxel_features, spatial_shape, pc_voxel_id, csr = voxelize_scenes(points[:, :3], points, counts, voxel_size)
 
         voxel_tensor = spconv.SparseConvTensor(voxel_features, indices, spatial_shape, n_scenes)
+        if first.voxel_coords is None and level_counts:
+            voxel_tensor.level_counts = list(level_counts)  # rows of the backbone's coarse levels: no read when they are built
         return PointCloudBatch(
             pc_ids=[pc.pc_id for pc in point_clouds], points=points, batch_indices=batch_indices,
             batch_size=n_scenes, device=device, voxel_tensor=voxel_tensor, pc_voxel_id=pc_voxel_id,
@@ -157,12 +166,28 @@ def _voxel_size_on(device, voxel_size):
 
 
 @torch.no_grad()
-def voxelize_scenes(xyz: torch.Tensor, feats: torch.Tensor, counts: Sequence[int], voxel_size: Sequence[float]):
+def voxelize_scenes(xyz: torch.Tensor, feats: torch.Tensor, counts: Sequence[int], voxel_size: Sequence[float],
+                    pyramid_levels: int = 0):
     """Batched scene voxelisation with the reference's per-scene conventions (dataset/gapartnet.py:179-205):
     range = [min - 1e-4, max + 1e-4] per scene, spatial extent per scene = (max coord + 1).clamp(min=128), batch
-    extent = elementwise max over scenes.  One kernel-V launch sequence for the whole batch; one host sync."""
+    extent = elementwise max over scenes.  On the HIP backend the whole preparation is one library call and ONE host read
+    (gpn_voxelize_scenes: per-scene ranges reduced on the device, keys that need no grid extent, the voxel count, the
+    extent and - with ``pyramid_levels`` - the row counts of the backbone's coarse levels in the same read); returns
+    (indices, features, spatial_shape, pc_voxel_id, csr[, level_counts])."""
     device = xyz.device
     n_scenes = len(counts)
+    ops = backend.raw()
+    if xyz.is_cuda and hasattr(ops, "voxelize_scenes"):
+        if len(set(counts)) == 1:
+            offsets_dev = torch.arange(n_scenes + 1, dtype=torch.int64, device=device) * int(counts[0])
+        else:
+            offsets_dev = torch.as_tensor([0] + list(np.cumsum(counts)), dtype=torch.int64).to(device, non_blocking=True)
+        got = ops.voxelize_scenes(xyz, feats, offsets_dev, [float(v) for v in voxel_size], pyramid_levels)
+        if got is not None:
+            vf, indices, pid, order, starts, max_coord, _dropped, level_counts = got
+            spatial_shape = [max(int(m) + 1, 128) for m in max_coord] if indices.shape[0] > 0 else [128] * 3
+            out = (indices, vf, spatial_shape, pid, (order, starts))
+            return out + (level_counts,) if pyramid_levels else out
     offsets = torch.zeros((n_scenes + 1,), dtype=torch.int64)
     offsets[1:] = torch.as_tensor(counts, dtype=torch.int64).cumsum(0)
     if len(set(counts)) == 1:  # equal-size scenes (the 20k-point contract): one strided reduction, offsets made on the device
@@ -184,4 +209,5 @@ def voxelize_scenes(xyz: torch.Tensor, feats: torch.Tensor, counts: Sequence[int
     # (max coord + 1).clamp(min=128) per scene then max over scenes == max over the batch, clamped; the maxima come
     # back with the voxel count in the kernel wrapper's single host read
     spatial_shape = [max(int(m) + 1, 128) for m in stats["max_coord"]] if vc.shape[0] > 0 else [128] * 3
-    return indices, vf, spatial_shape, pid, (order, starts)
+    out = (indices, vf, spatial_shape, pid, (order, starts))
+    return out + (None,) if pyramid_levels else out

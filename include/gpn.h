@@ -88,6 +88,19 @@ int gpn_voxelize_ex(const float* points, const float* feats, const int64_t* seg_
                     int32_t* point_order, int32_t* voxel_point_start, void* ws, size_t ws_bytes,
                     gpn_stream_t stream);
 
+/* scene batches with the reference's per-scene conventions (dataset/gapartnet.py:179-205: range = [min - 1e-4, max + 1e-4]
+ * of each scene, cell = floor((p - range_min) / voxel_size)) WITHOUT a host read before or between the launches: per-scene
+ * range reduced on the device, keys packed with 10 bits per axis, and ONE read of `stats` [8 + n_levels] i64 afterwards:
+ *   [0] #voxels, [1..3] largest cell index per axis (spatial extent = max(that + 1, 128)), [4] dropped points,
+ *   [5] != 0: a cell index >= 1024 occurred (results incomplete: use gpn_voxelize_ex with the true extent),
+ *   [8 + l] rows of stride-2 level l + 1 below the voxel set (= gpn_rulebook_level_counts), l < n_levels.
+ * indices4 [M,4] i32 = (segment, x, y, z) per voxel; the other outputs as gpn_voxelize_ex; same order, same means. */
+size_t gpn_voxelize_scenes_ws_bytes(int64_t M, int C, int64_t S, int n_levels);
+int gpn_voxelize_scenes(const float* points, const float* feats, const int64_t* seg_offsets, int64_t M, int C, int64_t S,
+                        const float* voxel_size_host, int n_levels, float* voxel_feats, int32_t* indices4,
+                        int32_t* pc_voxel_id, int32_t* point_order, int32_t* voxel_point_start, int64_t* stats, void* ws,
+                        size_t ws_bytes, gpn_stream_t stream);
+
 /* ================================================================================================
  * K1/K2 — rulebooks.   replace the indice-pair construction inside spconv.pytorch.SubMConv3d /
  * SparseConv3d / SparseInverseConv3d (call sites network/backbone.py:19-36,74-90,149-152).

@@ -138,6 +138,41 @@ def test_identity_rulebook_equals_the_torch_formulation(H, cuda, n):
     assert (rb.K, rb.n_src, rb.n_dst) == (1, n, n)
 
 
+def test_scene_batch_voxelisation_with_one_host_read(H, cuda):
+    """gpn_voxelize_scenes (per-scene ranges on the device, packed keys, voxel count + extent + coarse-level row counts in
+    ONE read) == the two-read path (torch min / max, grid extent read, gpn_voxelize_ex, separate level-count call): same
+    voxel order, bit-equal means, same extent and level counts; ragged scene sizes; a grid too fine for the packed keys
+    falls back"""
+    from gapartnet_amd.structure import point_cloud as PC
+    from gapartnet_amd import backend
+    rng = np.random.default_rng(21)
+    for counts in ([5000] * 4, [3000, 1, 4500, 777]):
+        M = sum(counts)
+        xyz = torch.from_numpy(rng.uniform(-1, 1, (M, 3)).astype(np.float32)).to(cuda)
+        n7 = xyz[3::7].shape[0]
+        xyz[0:7 * n7:7] = xyz[3::7]  # duplicates: voxels with several points
+        feats = torch.cat([xyz, torch.from_numpy(rng.uniform(0, 1, (M, 3)).astype(np.float32)).to(cuda)], 1)
+        one = PC.voxelize_scenes(xyz, feats, counts, (0.01, 0.01, 0.01), pyramid_levels=5)
+        import gapartnet_amd.hip_ops as HO
+        saved = HO.voxelize_scenes
+        del HO.voxelize_scenes
+        try:
+            two = PC.voxelize_scenes(xyz, feats, counts, (0.01, 0.01, 0.01))
+        finally:
+            HO.voxelize_scenes = saved
+        assert torch.equal(one[0], two[0]), "indices (scene, x, y, z) in the same order"
+        assert torch.equal(one[1], two[1]), "ordered means: bit-equal"
+        assert one[2] == two[2] and torch.equal(one[3], two[3])
+        assert torch.equal(one[4][0], two[4][0]) and torch.equal(one[4][1], two[4][1])
+        ref_counts = H.rulebook_level_counts(two[0], two[2], len(counts), 5).tolist()
+        assert list(one[5]) == ref_counts, (one[5], ref_counts)
+    # 0.001 voxels on a 2 m scene: 2000 cells per axis do not fit 10-bit packed coordinates -> the generic path answers
+    xyz = torch.from_numpy(rng.uniform(-1, 1, (4000, 3)).astype(np.float32)).to(cuda)
+    assert H.voxelize_scenes(xyz, xyz, torch.tensor([0, 4000], device=cuda), [0.001] * 3) is None
+    out = PC.voxelize_scenes(xyz, xyz, [4000], (0.001, 0.001, 0.001), pyramid_levels=3)
+    assert out[5] is None and out[0].shape[0] > 3900 and max(out[2]) > 1024
+
+
 # ------------------------------------------------------------------------------------------------ C
 CONV_SHAPES = [(16, 16), (32, 32), (48, 48), (64, 64), (80, 80), (96, 96), (112, 112), (32, 16), (64, 32), (96, 48),
                (128, 64), (160, 80), (192, 96), (16, 32), (96, 112)]
