@@ -201,6 +201,107 @@ __global__ void down_scatter_tables_kernel(const int32_t* __restrict__ fine_to_c
   tb[(int64_t)k * N + i] = o;
 }
 
+// ---- stride-2 level through an occupancy BITMAP of the coarse grid (round 3): no sort ----------------------------------------
+// The coarse rows must come out in ascending linear-key order.  Sorting the N coarse keys of the fine rows (radix sort, a
+// dozen launches) is one way; the coarse grid of a level is small (8 scenes x 93 x 98 x 97 cells = 7 M bits = 0.9 MB at the
+// first level, less below), so here every fine row sets the bit of its coarse cell, a two-kernel prefix sum over the
+// popcounts of the 64-bit words ranks the set bits - bit order IS key order - and each fine row reads its coarse row back
+// as prefix[word] + popcount(bits below).  Four small launches, deterministic, identical output.
+constexpr int kScanBlock = 1024;  // words per block of the word-popcount scan
+
+__global__ void down_mark_kernel(const int32_t* __restrict__ indices, int64_t N, int nb, int o0, int o1, int o2,
+                                 unsigned long long* __restrict__ bitmap, int32_t* __restrict__ tap) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int4 c = reinterpret_cast<const int4*>(indices)[i];
+  const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
+  tap[i] = (c.y & 1) * 4 + (c.z & 1) * 2 + (c.w & 1);
+  const bool ok = c.x >= 0 && c.x < nb && c.y >= 0 && c.z >= 0 && c.w >= 0 && x < o0 && y < o1 && z < o2;
+  if (!ok) return;
+  const uint64_t key = lin_key(c.x, x, y, z, o0, o1, o2);
+  atomicOr(bitmap + (key >> 6), 1ull << (key & 63));
+}
+
+// exclusive prefix of the word popcounts inside blocks of kScanBlock words; block totals to `block_sum`
+__global__ __launch_bounds__(256) void bitmap_scan_blocks_kernel(const unsigned long long* __restrict__ bitmap, int64_t n_words,
+                                                                 int32_t* __restrict__ prefix, int32_t* __restrict__ block_sum) {
+  __shared__ int32_t wave_tot[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + t * 4;
+  int32_t c[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c[q] = base + q < n_words ? __popcll(bitmap[base + q]) : 0;
+  const int32_t mine = c[0] + c[1] + c[2] + c[3];
+  int32_t incl = mine;  // inclusive scan over the wave (ballot-free shuffle tree, fixed order)
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+  int32_t run = wbase + incl - mine;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (base + q < n_words) prefix[base + q] = run;
+    run += c[q];
+  }
+  if (t == 255) block_sum[blockIdx.x] = wbase + incl;
+}
+
+// exclusive scan of the block totals by one workgroup (<= 256 K blocks); total -> num_out
+__global__ __launch_bounds__(1024) void bitmap_scan_totals_kernel(int32_t* __restrict__ block_sum, int64_t n_blocks,
+                                                                  int64_t* __restrict__ num_out) {
+  __shared__ int32_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n_blocks + 1023) / 1024;
+  const int64_t b = t * per, e = b + per < n_blocks ? b + per : n_blocks;
+  int32_t s = 0;
+  for (int64_t i = b; i < e; ++i) s += block_sum[i];
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    int32_t run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const int32_t v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    num_out[0] = run;
+  }
+  __syncthreads();
+  int32_t run = part[t];
+  for (int64_t i = b; i < e; ++i) {
+    const int32_t v = block_sum[i];
+    block_sum[i] = run;
+    run += v;
+  }
+}
+
+__global__ void down_rank_kernel(const int32_t* __restrict__ indices, int64_t N, int nb, int o0, int o1, int o2,
+                                 const unsigned long long* __restrict__ bitmap, const int32_t* __restrict__ prefix,
+                                 const int32_t* __restrict__ block_sum, int32_t* __restrict__ out_indices,
+                                 int32_t* __restrict__ fine_to_coarse) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int4 c = reinterpret_cast<const int4*>(indices)[i];
+  const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
+  const bool ok = c.x >= 0 && c.x < nb && c.y >= 0 && c.z >= 0 && c.w >= 0 && x < o0 && y < o1 && z < o2;
+  if (!ok) {
+    fine_to_coarse[i] = -1;
+    return;
+  }
+  const uint64_t key = lin_key(c.x, x, y, z, o0, o1, o2);
+  const uint64_t word = key >> 6;
+  const int32_t v = block_sum[word / kScanBlock] + prefix[word] + __popcll(bitmap[word] & ((1ull << (key & 63)) - 1ull));
+  fine_to_coarse[i] = v;
+  reinterpret_cast<int4*>(out_indices)[v] = make_int4(c.x, x, y, z);  // (every child writes the same row: idempotent)
+}
+
+constexpr uint64_t kBitmapMaxWords = (uint64_t)kScanBlock * 256 * 1024;  // one totals workgroup covers 256 K blocks
+
 size_t sort_temp_bytes(int64_t n) {
   size_t bytes = 0;
   rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
@@ -437,6 +538,29 @@ extern "C" int gpn_rulebook_down(const int32_t* indices, int64_t N, int64_t batc
   unsigned key_bits = 1;
   while (key_bits < 64 && (invalid_key >> key_bits) != 0) ++key_bits;
 
+  // the coarse grid as a bitmap when it is small enough (always, for the network's levels): no sort
+  const uint64_t n_words = (invalid_key + 63) / 64;
+  const int64_t n_blocks = gpn::cdiv((int64_t)n_words, kScanBlock);
+  gpn::WsCarver wb(ws, ws_bytes);
+  unsigned long long* bitmap = wb.take<unsigned long long>((size_t)n_words);
+  int32_t* prefix = wb.take<int32_t>((size_t)n_words);
+  int32_t* block_sum = wb.take<int32_t>((size_t)n_blocks);
+  if (n_words <= kBitmapMaxWords && wb.ok()) {
+    const int gridN = (int)gpn::cdiv(N, kThreads);
+    gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 16.0 * (double)N * 2 + 8.0 * (double)N);
+    GPN_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_words * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(down_mark_kernel, dim3(gridN), dim3(kThreads), 0, stream, indices, N, (int)batch_size, o0, o1, o2, bitmap, tap);
+    GPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bitmap_scan_blocks_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, bitmap, (int64_t)n_words, prefix,
+                       block_sum);
+    GPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bitmap_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, block_sum, n_blocks, num_out);
+    GPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(down_rank_kernel, dim3(gridN), dim3(kThreads), 0, stream, indices, N, (int)batch_size, o0, o1, o2, bitmap,
+                       prefix, block_sum, out_indices, fine_to_coarse);
+    GPN_CHECK_LAUNCH();
+    return GPN_OK;
+  }
   gpn::WsCarver w(ws, ws_bytes);
   uint64_t* keys = w.take<uint64_t>((size_t)N);
   uint64_t* ks = w.take<uint64_t>((size_t)N);

@@ -85,19 +85,38 @@ class FusedAdam(torch.optim.Adam):
         pointers."""
         own, state = self._own_grad, self.state
         sig = []
+        add = sig.append
         for p in group["params"]:
             g = p.grad
             if g is None:
-                sig.append(0)
+                add(0)
                 continue
-            st = state.get(p)
-            if st and "exp_avg" in st:
-                sig.append((1 if p in own else g.data_ptr(), p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
-            else:
-                sig.append((1 if p in own else g.data_ptr(), p.data_ptr(), 0, 0))
+            add(1 if p in own else g.data_ptr()) if own else add(g.data_ptr())
+            add(p.data_ptr())
+            try:
+                st = state[p]
+                add(st["exp_avg"].data_ptr())
+                add(st["exp_avg_sq"].data_ptr())
+            except KeyError:  # no moments yet (first step of this parameter)
+                add(-1)
         hyper = (bool(group["amsgrad"]), group["weight_decay"], bool(group["maximize"]), bool(group.get("capturable", False)),
                  bool(group.get("differentiable", False)))
         return hyper, tuple(sig)
+
+    @staticmethod
+    def _grad_entries(group, flat):
+        """parameter -> gradient entry of a flat signature (0 = no gradient: one slot; else four slots, or two before the
+        moments exist)"""
+        out, i = {}, 0
+        for p in group["params"]:
+            if i >= len(flat):
+                break
+            if flat[i] == 0:
+                i += 1
+                continue
+            out[p] = flat[i]
+            i += 3 if flat[i + 2] == -1 else 4
+        return out
 
     def _build(self, group, params):
         """device tables for the parameters that have a gradient, one per distinct step count (parameters the training
@@ -162,10 +181,13 @@ class FusedAdam(torch.optim.Adam):
                     continue
                 # which gradients moved since the previous step?  they get buffers of their own (their tables stay valid)
                 last = self._last_sig.get(gi)
-                if last is not None and len(last[1]) == len(sig[1]):
+                if last is not None:
                     changed = False
-                    for p, old, new in zip(group["params"], last[1], sig[1]):
-                        if old and new and old[0] > 1 and new[0] > 1 and old[0] != new[0] and p.grad.is_cuda:
+                    old_grads = self._grad_entries(group, last[1])
+                    new_grads = self._grad_entries(group, sig[1])
+                    for p in group["params"]:
+                        old, new = old_grads.get(p, 0), new_grads.get(p, 0)
+                        if old > 1 and new > 1 and old != new and p.grad.is_cuda:
                             own[p] = p.grad.detach().clone()
                             changed = True
                     if changed:
