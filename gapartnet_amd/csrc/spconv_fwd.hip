@@ -587,10 +587,12 @@ template <int KT, int CB>
 int launch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int nt_total,
                   int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
-  if (units < g_split4_units.load(std::memory_order_relaxed))
-    return launch_split<KT, CB, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-  if (units < g_split2_units.load(std::memory_order_relaxed))
-    return launch_split<KT, CB, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+  if constexpr (KT >= 8) {  // (a k = 1 layer has no taps to split)
+    if (units < g_split4_units.load(std::memory_order_relaxed))
+      return launch_split<KT, CB, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    if (units < g_split2_units.load(std::memory_order_relaxed))
+      return launch_split<KT, CB, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+  }
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
   hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4), 8) * 8)), dim3(256), 0, stream, in, packed,
                      nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out);
@@ -607,7 +609,10 @@ bool use_direct(int K, int64_t n_dst, int cin, int cout) {
   static const bool disabled = getenv("GPN_CONV_NO_DIRECT") != nullptr;  // A/B switch for measurements
   if (disabled) return false;
   const int CB = cin / 16;
-  if (!(K == 27 || K == 8)) return false;
+  // k = 1 layers (the residual blocks' shortcut convs, linear heads) take it too since round 3: its epilogue carries the
+  // BatchNorm sums (bn_stats.h), the lock-step kernel's does not
+  static const bool k1_direct = getenv("GPN_K1_LOCKSTEP") == nullptr;
+  if (!(K == 27 || K == 8 || (K == 1 && k1_direct))) return false;
   if (!(CB >= 1 && (CB <= 8 || CB == 10 || CB == 12))) return false;
   // 32-bit byte offsets: source rows (at most 8 n_dst of them, for a stride-2 conv), output rows, the neighbour table
   if (n_dst * (int64_t)8 * std::max(cin, cout) * 4 >= ((int64_t)1 << 31) || (int64_t)K * n_dst * 4 >= ((int64_t)1 << 31)) return false;
@@ -679,7 +684,8 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
     const int32_t* table = nbr_p ? nbr_p : nbr;
     return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream)
-                   : dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream);
+           : K == 8 ? dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream)
+                    : dispatch_direct<1>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream);
   }
   if (stats.slab) {
     gpn::set_error("gpn_spconv_fwd: this shape runs on a kernel without a BatchNorm-sum epilogue (see spconv_fwd_accumulates_stats)");

@@ -278,9 +278,10 @@ def _shared(pair, params) -> bool:
     # storage holders: the flat tensor, one per view, the temporary wrapper made by untyped_storage()
     if torch._C._storage_Use_Count(flat.untyped_storage()._cdata) > len(views) + 2:
         return True
-    for v, p in zip(views, params):
-        # references to the view object: the list slot, the loop variable, getrefcount's argument (+ the parameter's .grad)
-        if sys.getrefcount(v) > 3 + (1 if p.grad is v else 0):
+    for i in range(len(views)):
+        v = views[i]
+        # references to the view object: the list slot, `v`, getrefcount's argument (+ the parameter's .grad)
+        if sys.getrefcount(v) > 3 + (1 if params[i].grad is v else 0):
             return True
     return False
 

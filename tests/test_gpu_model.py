@@ -179,6 +179,12 @@ def test_executor_gradient_hand_over_contract(cuda):
     loss, _ = run()
     loss.backward()
     ref = {k: p.grad.clone() for k, p in zip(names, params)}
+    # nobody keeps a gradient: the next backward reuses the persistent buffer (no allocation, same addresses)
+    first_ptrs = [p.grad.data_ptr() for p in params]
+    net.zero_grad(set_to_none=True)
+    loss, _ = run()
+    loss.backward()
+    assert [p.grad.data_ptr() for p in params] == first_ptrs, "the persistent gradient buffer must be reused step after step"
     kept = params[0].grad                       # somebody holds on to a gradient (accumulation, deferred logging)
     kept_copy = kept.clone()
     net.zero_grad(set_to_none=True)
