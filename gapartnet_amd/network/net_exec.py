@@ -98,6 +98,11 @@ class NetProgram:
         self.slot_level_np = np.asarray(self.slot_level, np.int64)
         self.slot_channels_np = np.asarray(self.slot_channels, np.int64)
         self.bn_C = np.asarray([bn.num_features for bn in self.bns], np.int64)
+        # hyper-parameters of the modules, read once (they are not changed while a program is cached: invalidate() otherwise)
+        self.bn_eps = [bn.eps for bn in self.bns]
+        self.bn_momentum = [bn.momentum for bn in self.bns]
+        self.conv_cin = [c.in_channels for c in self.convs]
+        self.conv_cout = [c.out_channels for c in self.convs]
         self.bn_off = np.concatenate([[0], np.cumsum(self.bn_C)])  # float offsets into the flat per-BN vectors
         self.conv_numel = np.asarray([c.weight.numel() for c in self.convs], np.int64)
         self.conv_off = np.concatenate([[0], np.cumsum(self.conv_numel)])
@@ -250,7 +255,12 @@ class NetProgram:
         return rows, table, objs, levels
 
     def params(self):
-        return [c.weight for c in self.convs] + [b.weight for b in self.bns] + [b.bias for b in self.bns]
+        # (straight from the modules' parameter dicts: nn.Module.__getattr__ costs ~0.25 us per access, ~1000 accesses a step)
+        return ([c._parameters["weight"] for c in self.convs] + [b._parameters["weight"] for b in self.bns] +
+                [b._parameters["bias"] for b in self.bns])
+
+    def buffers(self, name):
+        return [b._buffers[name] for b in self.bns]
 
     def grad_buffer(self, device, params, fresh: bool):
         """-> (flat fp32 buffer of grad_total elements, per-parameter views of it in params() order).  The persistent pair
@@ -356,17 +366,17 @@ def _forward_impl(ctx, features, prog: NetProgram, rt, training):
     stats = torch.empty((2, total_c), dtype=torch.float32, device=dev)
     conv_table = np.zeros(n_conv, CONV_DT)
     conv_table["W"] = [p.data_ptr() for p in params[:n_conv]]
-    conv_table["cin"] = [c.in_channels for c in prog.convs]
-    conv_table["cout"] = [c.out_channels for c in prog.convs]
+    conv_table["cin"] = prog.conv_cin
+    conv_table["cout"] = prog.conv_cout
     bn_table = np.zeros(n_bn, BN_DT)
     bn_table["weight"] = [p.data_ptr() for p in params[n_conv:n_conv + n_bn]]
     bn_table["bias"] = [p.data_ptr() for p in params[n_conv + n_bn:]]
-    bn_table["running_mean"] = [b.running_mean.data_ptr() for b in prog.bns]
-    bn_table["running_var"] = [b.running_var.data_ptr() for b in prog.bns]
+    bn_table["running_mean"] = [t.data_ptr() for t in prog.buffers("running_mean")]
+    bn_table["running_var"] = [t.data_ptr() for t in prog.buffers("running_var")]
     bn_table["save_mean"] = stats.data_ptr() + prog.bn_off[:-1] * 4
     bn_table["save_invstd"] = stats.data_ptr() + (total_c + prog.bn_off[:-1]) * 4
-    bn_table["eps"] = [b.eps for b in prog.bns]
-    bn_table["momentum"] = [b.momentum for b in prog.bns]
+    bn_table["eps"] = prog.bn_eps
+    bn_table["momentum"] = prog.bn_momentum
     bn_table["C"] = prog.bn_C
     _call("gpn_net_forward", prog, slots, rb_table, conv_table, bn_table, (1 if training else 0,), dev)
     if GF.CONV_LOG is not None:
@@ -520,7 +530,7 @@ def run(unet, x):
         return None
     if training:
         with torch.no_grad():
-            torch._foreach_add_([bn.num_batches_tracked for bn in prog.bns], 1)
+            torch._foreach_add_(prog.buffers("num_batches_tracked"), 1)
     params = prog.params()
     if _AUTOGRAD_PARAMS or any(_has_hooks(p) for p in params):
         out = _NetFnAutograd.apply(x.features, prog, (rows, rb_table, rb_objs), training, *params)

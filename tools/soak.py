@@ -16,5 +16,5 @@ for i in range(N):
     loss.backward(); opt.step()
     if i in (20, 100, 299):
         torch.cuda.synchronize()
-        print(i, f"loss {float(loss):.3f} cuda alloc {torch.cuda.memory_allocated() >> 20} MB reserved {torch.cuda.memory_reserved() >> 20} MB "
+        print(i, f"loss {float(loss):.9f} cuda alloc {torch.cuda.memory_allocated() >> 20} MB reserved {torch.cuda.memory_reserved() >> 20} MB "
               f"peak {torch.cuda.max_memory_allocated() >> 20} MB host rss {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss >> 10} MB  {(time.time() - t0) / (i + 1) * 1e3:.1f} ms/step")
