@@ -14,7 +14,7 @@ def aggregate(path, prefix):
     total, launches = 0.0, 0
     lines = open(path).read().splitlines()
     for i, line in enumerate(lines):
-        if line.startswith(prefix):
+        if any(line.startswith(pre) for pre in prefix.split(",")):
             n = int(line.split("dispatches")[1])
             total += float(lines[i + 1].split()[1]) * n
             launches += n
@@ -22,7 +22,7 @@ def aggregate(path, prefix):
 
 
 fetch_path, write_path, out = sys.argv[1], sys.argv[2], sys.argv[3]
-prefix = sys.argv[4] if len(sys.argv) > 4 else "spconv_fwd"
+prefix = sys.argv[4] if len(sys.argv) > 4 else "spconv_fwd,spconv_tiles"  # comma-separated kernel-name prefixes
 f, n = aggregate(fetch_path, prefix)
 w, n2 = aggregate(write_path, prefix)
 res = {"kernel_prefix": prefix, "launches_profiled": n,
