@@ -131,23 +131,31 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ partial
   __syncthreads();
 }
 
-// the same totals from a slab of fixed-point words a conv launch accumulated (bn_stats.h): word-threads (q, c) sum their
-// word over the 32 slot sets (coalesced across c), thread c combines the four exact integer sums
+// the same totals from a slab of fixed-point words a conv launch accumulated (bn_stats.h).  The slab [slots][4][C] is read
+// linearly by the whole workgroup (coalesced, every load independent: one memory round trip for C <= 32, the serial
+// 32-slot loop per word this replaces was four) and summed per word with LDS integer atomics - integer addition, so the
+// order the threads arrive in does not matter; thread c then combines the four exact sums of its channel.
 template <bool BWD>
-__device__ __forceinline__ void fold_fixed(const unsigned long long* __restrict__ slab, int C, long long (*words)[kFoldMaxC],
+__device__ __forceinline__ void fold_fixed(const unsigned long long* __restrict__ slab, int C, int slots, unsigned long long (*words)[kFoldMaxC],
                                            double (*sums)[kFoldMaxC]) {
   constexpr gpn::StatScale sc = BWD ? gpn::kStatScaleBwd() : gpn::kStatScaleFwd();
-  for (int e = threadIdx.x; e < 4 * C; e += kApplyThreads) {
-    const int q = e / C, c = e - q * C;
-    long long w = 0;
+  const int W = 4 * C;  // words per slot set
+  for (int e = threadIdx.x; e < W; e += kApplyThreads) words[e / C][e % C] = 0ull;
+  __syncthreads();
+  const int total = W * slots;  // gpn::stat_slot_count(N) sets of the slab are in use
+  int w = threadIdx.x % W;              // word of this thread's first element; advances by kApplyThreads % W per step
+  const int step = kApplyThreads % W;
 #pragma unroll 8
-    for (int sl = 0; sl < gpn::kStatSlots; ++sl) w += (long long)slab[((size_t)sl * 4 + q) * C + c];
-    words[q][c] = w;
+  for (int e = threadIdx.x; e < total; e += kApplyThreads) {
+    const unsigned long long v = slab[e];
+    if (v) atomicAdd(&words[0][0] + (w / C) * kFoldMaxC + (w % C), v);
+    w += step;
+    w = w >= W ? w - W : w;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += kApplyThreads) {
-    sums[0][c] = ldexp((double)words[0][c], -sc.h0) + ldexp((double)words[1][c], -sc.l0);
-    sums[1][c] = ldexp((double)words[2][c], -sc.h1) + ldexp((double)words[3][c], -sc.l1);
+    sums[0][c] = ldexp((double)(long long)words[0][c], -sc.h0) + ldexp((double)(long long)words[1][c], -sc.l0);
+    sums[1][c] = ldexp((double)(long long)words[2][c], -sc.h1) + ldexp((double)(long long)words[3][c], -sc.l1);
   }
   __syncthreads();
 }
@@ -249,7 +257,9 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ x, const float* __
 
 // ---- apply passes that fold the finalize (training; C <= kFoldMaxC) ------------------------------------------------------
 // thread t walks elements t, t + G*T, ...: its float4 column advances by (G*T) % C4 per step (no 64-bit modulo in the loop)
-template <bool FIXED>  // FIXED: `partial` is a slab of fixed-point words a conv launch accumulated (bn_stats.h)
+constexpr int kApplyBatch = 4;  // elements of a thread in flight together
+
+template <bool FIXED>  // FIXED: `partial` is a slab of fixed-point words a conv launch accumulated (bn_stats.h), `blocks` its slot sets in use
 __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const void* __restrict__ partial, int blocks, int64_t N,
     const float* __restrict__ weight, const float* __restrict__ bias, int64_t total4, int C4, float eps, float momentum,
@@ -257,10 +267,27 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(
     float* __restrict__ running_mean, float* __restrict__ running_var) {
   __shared__ double red[2][kApplyThreads][4];
   __shared__ double sums[2][kFoldMaxC];
-  __shared__ __attribute__((aligned(16))) float stat[2][kFoldMaxC];
+  __shared__ __attribute__((aligned(16))) float stat[4][kFoldMaxC];  // mean, 1/std, weight, bias
+  constexpr int U = kApplyBatch;
   const int C = C4 * 4;
+  // thread t walks elements t, t + G*T, ... in batches of U whose loads are all in flight together (predicated: no
+  // remainder loop that would take one round trip per element); the first batch is requested BEFORE the fold, so its latency
+  // overlaps the fold's own round trip - the small layers of the step are one batch per thread and pay this kernel's floor
+  const int64_t stride = (int64_t)gridDim.x * kApplyThreads;
+  const int step = (int)(stride % C4);
+  int64_t t = (int64_t)blockIdx.x * kApplyThreads + threadIdx.x;
+  int c4 = (int)(t % C4);
+  f32x4 xv[U], rv[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int64_t tt = t + k * stride;
+    if (tt < total4) {
+      xv[k] = reinterpret_cast<const f32x4*>(x)[tt];
+      if (res) rv[k] = reinterpret_cast<const f32x4*>(res)[tt];
+    }
+  }
   if constexpr (FIXED)
-    fold_fixed<false>(static_cast<const unsigned long long*>(partial), C, reinterpret_cast<long long (*)[kFoldMaxC]>(&red[0][0][0]), sums);
+    fold_fixed<false>(static_cast<const unsigned long long*>(partial), C, blocks, reinterpret_cast<unsigned long long (*)[kFoldMaxC]>(&red[0][0][0]), sums);
   else
     fold_partials(static_cast<const double*>(partial), blocks, C4, red, sums);
   for (int c = threadIdx.x; c < C; c += kApplyThreads) {
@@ -270,6 +297,8 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(
     const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
     stat[0][c] = mu;
     stat[1][c] = is;
+    stat[2][c] = weight[c];
+    stat[3][c] = bias[c];
     if (blockIdx.x == 0) {
       mean[c] = mu;
       invstd[c] = is;
@@ -281,23 +310,34 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(
     }
   }
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * kApplyThreads;
-  const int step = (int)(stride % C4);
-  int64_t t = (int64_t)blockIdx.x * kApplyThreads + threadIdx.x;
-  int c4 = (int)(t % C4);
-#pragma unroll 4
-  for (; t < total4; t += stride) {
-    const f32x4 mu = reinterpret_cast<const f32x4*>(stat[0])[c4], is = reinterpret_cast<const f32x4*>(stat[1])[c4];
-    const f32x4 w = reinterpret_cast<const f32x4*>(weight)[c4], b = reinterpret_cast<const f32x4*>(bias)[c4];
-    f32x4 v = (reinterpret_cast<const f32x4*>(x)[t] - mu) * is * w + b;
-    if (res) v += reinterpret_cast<const f32x4*>(res)[t];
-    if (relu) {
+  while (true) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    for (int k = 0; k < U; ++k) {
+      const int64_t tt = t + k * stride;
+      if (tt < total4) {
+        const f32x4 mu = reinterpret_cast<const f32x4*>(stat[0])[c4], is = reinterpret_cast<const f32x4*>(stat[1])[c4];
+        const f32x4 w = reinterpret_cast<const f32x4*>(stat[2])[c4], b = reinterpret_cast<const f32x4*>(stat[3])[c4];
+        f32x4 v = (xv[k] - mu) * is * w + b;
+        if (res) v += rv[k];
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(y)[tt] = v;
+      }
+      c4 += step;
+      c4 = c4 >= C4 ? c4 - C4 : c4;
     }
-    reinterpret_cast<f32x4*>(y)[t] = v;
-    c4 += step;
-    c4 = c4 >= C4 ? c4 - C4 : c4;
+    t += U * stride;
+    if (t >= total4) break;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t tt = t + k * stride;
+      if (tt < total4) {
+        xv[k] = reinterpret_cast<const f32x4*>(x)[tt];
+        if (res) rv[k] = reinterpret_cast<const f32x4*>(res)[tt];
+      }
+    }
   }
 }
 
@@ -309,46 +349,76 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_bwd_fold_kernel(
     float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dweight, float* __restrict__ dbias) {
   __shared__ double red[2][kApplyThreads][4];
   __shared__ double sums[2][kFoldMaxC];
-  __shared__ __attribute__((aligned(16))) float grad[2][kFoldMaxC];  // dbias, dweight
+  __shared__ __attribute__((aligned(16))) float stat[5][kFoldMaxC];  // dbias, dweight, mean, 1/std, weight
+  constexpr int U = kApplyBatch;
   const int C = C4 * 4;
+  const int64_t stride = (int64_t)gridDim.x * kApplyThreads;
+  const int step = (int)(stride % C4);
+  int64_t t = (int64_t)blockIdx.x * kApplyThreads + threadIdx.x;
+  int c4 = (int)(t % C4);
+  // first batch requested before the fold (see the forward kernel)
+  f32x4 gv[U], yv[U], xv[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int64_t tt = t + k * stride;
+    if (tt < total4) {
+      gv[k] = reinterpret_cast<const f32x4*>(dy)[tt];
+      if (relu) yv[k] = reinterpret_cast<const f32x4*>(y)[tt];
+      if (training) xv[k] = reinterpret_cast<const f32x4*>(x)[tt];
+    }
+  }
   if constexpr (FIXED)
-    fold_fixed<true>(static_cast<const unsigned long long*>(partial), C, reinterpret_cast<long long (*)[kFoldMaxC]>(&red[0][0][0]), sums);
+    fold_fixed<true>(static_cast<const unsigned long long*>(partial), C, blocks, reinterpret_cast<unsigned long long (*)[kFoldMaxC]>(&red[0][0][0]), sums);
   else
     fold_partials(static_cast<const double*>(partial), blocks, C4, red, sums);
   for (int c = threadIdx.x; c < C; c += kApplyThreads) {
     const float db = (float)sums[0][c], dw = (float)sums[1][c];
-    grad[0][c] = db;
-    grad[1][c] = dw;
+    stat[0][c] = db;
+    stat[1][c] = dw;
+    stat[2][c] = mean[c];
+    stat[3][c] = invstd[c];
+    stat[4][c] = weight[c];
     if (blockIdx.x == 0) {
       dbias[c] = db;
       dweight[c] = dw;
     }
   }
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * kApplyThreads;
-  const int step = (int)(stride % C4);
-  int64_t t = (int64_t)blockIdx.x * kApplyThreads + threadIdx.x;
-  int c4 = (int)(t % C4);
-#pragma unroll 4
-  for (; t < total4; t += stride) {
-    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
-    const f32x4 w = reinterpret_cast<const f32x4*>(weight)[c4];
-    f32x4 g = reinterpret_cast<const f32x4*>(dy)[t];
-    if (relu) {
-      const f32x4 yv = reinterpret_cast<const f32x4*>(y)[t];
+  while (true) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+    for (int k = 0; k < U; ++k) {
+      const int64_t tt = t + k * stride;
+      if (tt < total4) {
+        const f32x4 is = reinterpret_cast<const f32x4*>(stat[3])[c4], w = reinterpret_cast<const f32x4*>(stat[4])[c4];
+        f32x4 g = gv[k];
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] = yv[k][j] > 0.f ? g[j] : 0.f;
+        }
+        if (dres) reinterpret_cast<f32x4*>(dres)[tt] = g;
+        f32x4 v = g;
+        if (training) {
+          const f32x4 db = reinterpret_cast<const f32x4*>(stat[0])[c4], dw = reinterpret_cast<const f32x4*>(stat[1])[c4];
+          const f32x4 mu = reinterpret_cast<const f32x4*>(stat[2])[c4];
+          const f32x4 xhat = (xv[k] - mu) * is;
+          v = g - db * inv_n - xhat * (dw * inv_n);
+        }
+        reinterpret_cast<f32x4*>(dx)[tt] = v * is * w;
+      }
+      c4 += step;
+      c4 = c4 >= C4 ? c4 - C4 : c4;
     }
-    if (dres) reinterpret_cast<f32x4*>(dres)[t] = g;
-    f32x4 v = g;
-    if (training) {
-      const f32x4 db = reinterpret_cast<const f32x4*>(grad[0])[c4], dw = reinterpret_cast<const f32x4*>(grad[1])[c4];
-      const f32x4 xhat = (reinterpret_cast<const f32x4*>(x)[t] - mu) * is;
-      v = g - db * inv_n - xhat * (dw * inv_n);
+    t += U * stride;
+    if (t >= total4) break;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t tt = t + k * stride;
+      if (tt < total4) {
+        gv[k] = reinterpret_cast<const f32x4*>(dy)[tt];
+        if (relu) yv[k] = reinterpret_cast<const f32x4*>(y)[tt];
+        if (training) xv[k] = reinterpret_cast<const f32x4*>(x)[tt];
+      }
     }
-    reinterpret_cast<f32x4*>(dx)[t] = v * is * w;
-    c4 += step;
-    c4 = c4 >= C4 ? c4 - C4 : c4;
   }
 }
 
@@ -510,8 +580,9 @@ int reduce_blocks(int64_t N, int C4) {
 }
 
 int fold_grid(int64_t total4) {
-  int64_t g = gpn::cdiv(total4, (int64_t)kApplyThreads * 4);
-  if (g > 256) g = 256;
+  // one element per thread until every CU has a workgroup; the large levels then walk ~4 elements per thread
+  int64_t g = gpn::cdiv(total4, (int64_t)kApplyThreads);
+  if (g > 320) g = 320;  // (the two largest levels of the bench then fit one batch of kApplyBatch elements per thread)
   return (int)(g < 1 ? 1 : g);
 }
 
@@ -648,7 +719,7 @@ int gpn::bn_fwd_train_fused(const float* x, const float* res, const float* weigh
   const int64_t total4 = N * (C / 4);
   gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (res ? 3 : 2));  // x [+ res] read, y written
   hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<true>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, res,
-                     (const void*)slab, 0, N, weight, bias, total4, C / 4, eps, momentum, relu, y, mean, invstd, running_mean,
+                     (const void*)slab, gpn::stat_slot_count(N), N, weight, bias, total4, C / 4, eps, momentum, relu, y, mean, invstd, running_mean,
                      running_var);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
@@ -661,7 +732,7 @@ int gpn::bn_bwd_fused(const float* x, const float* y, const float* dy, const flo
   const int64_t total4 = N * (C / 4);
   gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (4 + (dres ? 1 : 0)));  // x, y, dy read; dx [, dres] written
   hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<true>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, y, dy,
-                     (const void*)slab, 0, mean, invstd, weight, total4, C / 4, 1.0f / (float)N, relu, training, dx, dres, dweight,
+                     (const void*)slab, gpn::stat_slot_count(N), mean, invstd, weight, total4, C / 4, 1.0f / (float)N, relu, training, dx, dres, dweight,
                      dbias);
   GPN_CHECK_LAUNCH();
   return GPN_OK;

@@ -48,8 +48,18 @@ struct WsCarver {
 // launch is a dgrad that writes the final gradient g of a BatchNorm's output y = act(bn(x) [+ res]): sum g', sum g' xhat with
 // g' = g masked by the ReLU (y > 0) and xhat = (x - mean) invstd (backward).
 constexpr int kStatSlots = 32;
+// slot sets a launch over `rows` output rows spreads its contributions over (a power of two <= kStatSlots): enough that an
+// address takes <= 64 of the launch's atomics, few enough that the apply pass's fold of a small layer is one or two words
+// per thread - the deep levels (large C, few tiles) would otherwise fold 4 C x 32 words in every workgroup
+inline int stat_slot_count(int64_t rows) {
+  const int64_t tiles = (rows + 15) / 16;
+  int s = 1;
+  while (s < kStatSlots && tiles > 64 * (int64_t)s) s *= 2;
+  return s;
+}
 struct ConvStats {
-  unsigned long long* slab = nullptr;  // [kStatSlots][4][C] fixed-point words, zeroed by the caller
+  unsigned long long* slab = nullptr;  // [kStatSlots][4][C] fixed-point words (the first slot_mask + 1 sets used), zeroed by the caller
+  int slot_mask = kStatSlots - 1;      // stat_slot_count(rows of the tensor the sums are over) - 1
   const float* x = nullptr;
   const float* y = nullptr;
   const float* mean = nullptr;

@@ -315,6 +315,7 @@ extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_
       const gpn_net_conv_t& cv = convs[op.param];
       gpn::ConvStats st;
       st.slab = slab_of[i];
+      st.slot_mask = gpn::stat_slot_count(rb.n_dst) - 1;
       rc = gpn::spconv_fwd_into(s0.data, packed_of[i], rb.nbr, rb.nbr_p, rb.perm, rb.K, rb.n_dst, cv.cin, cv.cout, d.data, 0, st,
                                 op_ws, op_ws_bytes, stream);
     } else if (op.kind == GPN_NET_BN) {
@@ -611,6 +612,7 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
           const gpn_net_op_t& bo = ops[fused_by[i]];
           const gpn_net_bn_t& bn = bns[bo.param];
           st.slab = bn_slab[fused_by[i]];
+          st.slot_mask = gpn::stat_slot_count(rb.n_src) - 1;
           st.x = slots[bo.src0].data;
           st.y = s0.data;
           st.mean = training ? bn.save_mean : bn.running_mean;

@@ -420,8 +420,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
       }
     }
   }
-  if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(unit & (gpn::kStatSlots - 1)), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
-  else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(unit & (gpn::kStatSlots - 1)), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+  if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+  else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
 }
 
 // Tap-split form of the direct kernel for layers with FEW (tile, column tile) units (round 3).  A level of a few thousand
@@ -553,8 +553,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
       }
     }
   }
-  if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(unit & (gpn::kStatSlots - 1)), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
-  else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(unit & (gpn::kStatSlots - 1)), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+  if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+  else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
 }
 
 // units below which a layer takes the 4-way / 2-way tap-split form (0 = never).  tools/conv_split_sweep.py

@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
             }
           }
         }
-        if (st_fwd) gpn::stat_add<false>(stats.slab, cout, unit & (gpn::kStatSlots - 1), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
-        else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, unit & (gpn::kStatSlots - 1), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+        if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+        else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
       }
     }
   }

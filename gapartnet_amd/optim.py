@@ -9,6 +9,7 @@ after step).  Per step the host does one pass over the parameters' gradient addr
 foreach Adam spends ~1 ms per step grouping the ~330 tensors and issues 9-15 launches.
 Anything else (CPU tensors in the oracle-backed tests, amsgrad, weight decay, maximize) takes torch's own implementation."""
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -32,6 +33,7 @@ class FusedAdam(torch.optim.Adam):
         # copied into buffers of their own before the update (one foreach copy), so that the device table stays valid
         self._own_grad = {}
         self._last_sig = {}  # group index -> signature of the previous step (to see which gradients moved)
+        self._snap = {}      # group index -> (signature, tables, object snapshot) of the previous step, see _unchanged
 
     # ---------------------------------------------------------------------------------------------- state (de)serialisation
     def _sync_step_tensors(self):
@@ -57,6 +59,7 @@ class FusedAdam(torch.optim.Adam):
                 st["step"] = st["step"].detach().to("cpu", torch.float32)
         self._cache.clear()
         self._last_sig.clear()
+        self._snap.clear()
         self._nstep = {p: int(st["step"]) for p, st in self.state.items() if "step" in st}
 
     def add_param_group(self, param_group):
@@ -64,6 +67,7 @@ class FusedAdam(torch.optim.Adam):
         if hasattr(self, "_cache"):
             self._cache.clear()
             self._last_sig.clear()
+            self._snap.clear()
 
     # ---------------------------------------------------------------------------------------------- step
     @staticmethod
@@ -99,9 +103,59 @@ class FusedAdam(torch.optim.Adam):
                 add(st["exp_avg_sq"].data_ptr())
             except KeyError:  # no moments yet (first step of this parameter)
                 add(-1)
-        hyper = (bool(group["amsgrad"]), group["weight_decay"], bool(group["maximize"]), bool(group.get("capturable", False)),
-                 bool(group.get("differentiable", False)))
-        return hyper, tuple(sig)
+        return self._hyper(group), tuple(sig)
+
+    _OWN = object()  # snapshot marker: the gradient is copied into a buffer of this class every step
+
+    def _snapshot(self, group):
+        """what _unchanged compares against: per parameter the OBJECTS the signature's addresses were read from.  Gradients
+        are held WEAKLY (the executor retires a persistent gradient buffer that anybody else references, net_exec._shared);
+        a dead reference no longer matches anything, so an identity match always means the same live tensor."""
+        own, state = self._own_grad, self.state
+        snap = []
+        for p in group["params"]:
+            g = p.grad
+            if g is None:
+                snap.append(None)
+                continue
+            st = state.get(p)
+            snap.append((self._OWN if p in own else weakref.ref(g), g.data_ptr(), p.data_ptr(), st,
+                         st.get("exp_avg") if st else None, st.get("exp_avg_sq") if st else None))
+        return snap
+
+    def _unchanged(self, group, hyper, snap) -> bool:
+        """the cheap per-step test that the previous step's signature still holds: same gradient / moment tensor objects
+        (the executor's gradient slices and the moments are persistent tensors: identity plus an unchanged address, which
+        ``set_()`` could move), same value address, same per-parameter state dict.  A third of the cost of rebuilding the
+        signature (4 address reads and a tensor-keyed dict lookup per parameter, ~330 parameters); anything that does not
+        match falls through to the full signature."""
+        params = group["params"]
+        if len(params) != len(snap) or hyper != self._hyper(group):
+            return False
+        OWN, state = self._OWN, self.state
+        for p, e in zip(params, snap):
+            g = p.grad
+            if e is None:
+                if g is not None:
+                    return False
+                continue
+            if g is None:
+                return False
+            g_ref, g_ptr, v_ptr, st, m, v = e
+            if g_ref is OWN:
+                if not g.is_cuda:
+                    return False
+            elif g is not g_ref() or g.data_ptr() != g_ptr:
+                return False
+            if p.data_ptr() != v_ptr or state.get(p) is not st or st is None or st.get("exp_avg") is not m \
+                    or st.get("exp_avg_sq") is not v or m is None:
+                return False
+        return True
+
+    @staticmethod
+    def _hyper(group):
+        return (bool(group["amsgrad"]), group["weight_decay"], bool(group["maximize"]), bool(group.get("capturable", False)),
+                bool(group.get("differentiable", False)))
 
     @staticmethod
     def _grad_entries(group, flat):
@@ -172,9 +226,13 @@ class FusedAdam(torch.optim.Adam):
                 moved = [p for p in own if p.grad is not None]
                 if moved:
                     torch._foreach_copy_([own[p] for p in moved], [p.grad for p in moved])
-            sig = self._signature(group)
             sets = self._cache.setdefault(gi, {})
-            tables = sets.get(sig)
+            prev = self._snap.get(gi)
+            if prev is not None and self._unchanged(group, prev[0][0], prev[2]):
+                sig, tables = prev[0], prev[1]
+            else:
+                sig = self._signature(group)
+                tables = sets.get(sig)
             if tables is None:
                 params = [p for p in group["params"] if p.grad is not None]
                 if not params:
@@ -204,6 +262,8 @@ class FusedAdam(torch.optim.Adam):
                         sets.pop(next(iter(sets)))
                     sets[sig] = tables
             self._last_sig[gi] = sig
+            if prev is None or prev[0] is not sig:
+                self._snap[gi] = (sig, tables, self._snapshot(group))
             L = _C.lib()
             dev = tables[0][3][0].device
             stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
