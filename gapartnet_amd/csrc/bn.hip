@@ -260,11 +260,21 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ x, const float* __
 constexpr int kApplyBatch = 4;  // elements of a thread in flight together
 
 template <bool FIXED>  // FIXED: `partial` is a slab of fixed-point words a conv launch accumulated (bn_stats.h), `blocks` its slot sets in use
-__global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(
-    const float* __restrict__ x, const float* __restrict__ res, const void* __restrict__ partial, int blocks, int64_t N,
-    const float* __restrict__ weight, const float* __restrict__ bias, int64_t total4, int C4, float eps, float momentum,
-    int relu, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ invstd,
-    float* __restrict__ running_mean, float* __restrict__ running_var) {
+__global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(gpn::BnFwdPtrs pa, gpn::BnFwdPtrs pb, int blocks, int64_t N,
+                                                                         int64_t total4, int C4, float eps, float momentum,
+                                                                         int relu) {
+  // (two BatchNorms of the same shape per launch for the executor's paired passes: blockIdx.y picks the pointer set)
+  const gpn::BnFwdPtrs& pp = blockIdx.y ? pb : pa;
+  const float* __restrict__ x = pp.x;
+  const float* __restrict__ res = pp.res;
+  const void* __restrict__ partial = pp.partial;
+  const float* __restrict__ weight = pp.weight;
+  const float* __restrict__ bias = pp.bias;
+  float* __restrict__ y = pp.y;
+  float* __restrict__ mean = pp.mean;
+  float* __restrict__ invstd = pp.invstd;
+  float* __restrict__ running_mean = pp.running_mean;
+  float* __restrict__ running_var = pp.running_var;
   __shared__ double red[2][kApplyThreads][4];
   __shared__ double sums[2][kFoldMaxC];
   __shared__ __attribute__((aligned(16))) float stat[4][kFoldMaxC];  // mean, 1/std, weight, bias
@@ -342,11 +352,20 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(
 }
 
 template <bool FIXED>
-__global__ __launch_bounds__(kApplyThreads) void bn_apply_bwd_fold_kernel(
-    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-    const void* __restrict__ partial, int blocks, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ weight, int64_t total4, int C4, float inv_n, int relu, int training,
-    float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dweight, float* __restrict__ dbias) {
+__global__ __launch_bounds__(kApplyThreads) void bn_apply_bwd_fold_kernel(gpn::BnBwdPtrs pa, gpn::BnBwdPtrs pb, int blocks, int64_t total4,
+                                                                         int C4, float inv_n, int relu, int training) {
+  const gpn::BnBwdPtrs& pp = blockIdx.y ? pb : pa;
+  const float* __restrict__ x = pp.x;
+  const float* __restrict__ y = pp.y;
+  const float* __restrict__ dy = pp.dy;
+  const void* __restrict__ partial = pp.partial;
+  const float* __restrict__ mean = pp.mean;
+  const float* __restrict__ invstd = pp.invstd;
+  const float* __restrict__ weight = pp.weight;
+  float* __restrict__ dx = pp.dx;
+  float* __restrict__ dres = pp.dres;
+  float* __restrict__ dweight = pp.dweight;
+  float* __restrict__ dbias = pp.dbias;
   __shared__ double red[2][kApplyThreads][4];
   __shared__ double sums[2][kFoldMaxC];
   __shared__ __attribute__((aligned(16))) float stat[5][kFoldMaxC];  // dbias, dweight, mean, 1/std, weight
@@ -632,9 +651,11 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
   GPN_CHECK_LAUNCH();
   const int64_t total4 = N * C4;
   if (C <= kFoldMaxC) {
-    hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<false>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, res,
-                       (const void*)partial, blocks, N, weight, bias, total4, C4, eps, momentum, relu, y, mean, invstd, running_mean,
-                       running_var);
+    gpn::BnFwdPtrs pp;
+    pp.x = x, pp.res = res, pp.partial = partial, pp.weight = weight, pp.bias = bias, pp.y = y, pp.mean = mean, pp.invstd = invstd,
+    pp.running_mean = running_mean, pp.running_var = running_var;
+    hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<false>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, pp, pp, blocks, N,
+                       total4, C4, eps, momentum, relu);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
   }
@@ -693,9 +714,11 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
   GPN_CHECK_LAUNCH();
   const int64_t total4 = N * C4;
   if (C <= kFoldMaxC) {
-    hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<false>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, y, dy,
-                       (const void*)partial, blocks, mean, invstd, weight, total4, C4, 1.0f / (float)N, relu, training, dx, dres, dweight,
-                       dbias);
+    gpn::BnBwdPtrs pp;
+    pp.x = x, pp.y = y, pp.dy = dy, pp.partial = partial, pp.mean = mean, pp.invstd = invstd, pp.weight = weight, pp.dx = dx,
+    pp.dres = dres, pp.dweight = dweight, pp.dbias = dbias;
+    hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<false>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, pp, pp, blocks, total4,
+                       C4, 1.0f / (float)N, relu, training);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
   }
@@ -711,29 +734,35 @@ extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const
 // ---- apply passes over sums the producing conv launch accumulated (bn_stats.h; used by the network executor) ----------------
 bool gpn::bn_two_pass(int64_t N, int C) { return N > kSmallRows && C % 4 == 0 && C <= kFoldMaxC; }
 
-int gpn::bn_fwd_train_fused(const float* x, const float* res, const float* weight, const float* bias, int64_t N, int C,
-                            float eps, float momentum, int relu, float* y, float* mean, float* invstd, float* running_mean,
-                            float* running_var, const unsigned long long* slab, hipStream_t stream) {
-  GPN_CHECK_ARG(gpn::bn_two_pass(N, C) && x && weight && bias && y && mean && invstd && slab);
-  GPN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+int gpn::bn_fwd_train_fused(const gpn::BnFwdPtrs& p, const gpn::BnFwdPtrs* twin, int64_t N, int C, float eps, float momentum,
+                            int relu, hipStream_t stream) {
+  for (const gpn::BnFwdPtrs* q : {&p, twin}) {
+    if (!q) continue;
+    GPN_CHECK_ARG(q->x && q->weight && q->bias && q->y && q->mean && q->invstd && q->partial);
+    GPN_CHECK_ARG((q->running_mean == nullptr) == (q->running_var == nullptr));
+  }
+  GPN_CHECK_ARG(gpn::bn_two_pass(N, C));
+  GPN_CHECK_ARG(!twin || (twin->res == nullptr) == (p.res == nullptr));
   const int64_t total4 = N * (C / 4);
-  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (res ? 3 : 2));  // x [+ res] read, y written
-  hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<true>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, res,
-                     (const void*)slab, gpn::stat_slot_count(N), N, weight, bias, total4, C / 4, eps, momentum, relu, y, mean, invstd, running_mean,
-                     running_var);
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (p.res ? 3 : 2) * (twin ? 2 : 1));  // x [+ res] read, y written
+  hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<true>, dim3(fold_grid(total4), twin ? 2 : 1), dim3(kApplyThreads), 0, stream, p,
+                     twin ? *twin : p, gpn::stat_slot_count(N), N, total4, C / 4, eps, momentum, relu);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
-int gpn::bn_bwd_fused(const float* x, const float* y, const float* dy, const float* weight, const float* mean,
-                      const float* invstd, int64_t N, int C, int relu, int training, float* dx, float* dres, float* dweight,
-                      float* dbias, const unsigned long long* slab, hipStream_t stream) {
-  GPN_CHECK_ARG(gpn::bn_two_pass(N, C) && x && dy && weight && mean && invstd && dx && dweight && dbias && slab && (y || !relu));
+int gpn::bn_bwd_fused(const gpn::BnBwdPtrs& p, const gpn::BnBwdPtrs* twin, int64_t N, int C, int relu, int training,
+                      hipStream_t stream) {
+  for (const gpn::BnBwdPtrs* q : {&p, twin}) {
+    if (!q) continue;
+    GPN_CHECK_ARG(q->x && q->dy && q->weight && q->mean && q->invstd && q->dx && q->dweight && q->dbias && q->partial && (q->y || !relu));
+  }
+  GPN_CHECK_ARG(gpn::bn_two_pass(N, C));
+  GPN_CHECK_ARG(!twin || (twin->dres == nullptr) == (p.dres == nullptr));
   const int64_t total4 = N * (C / 4);
-  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (4 + (dres ? 1 : 0)));  // x, y, dy read; dx [, dres] written
-  hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<true>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, x, y, dy,
-                     (const void*)slab, gpn::stat_slot_count(N), mean, invstd, weight, total4, C / 4, 1.0f / (float)N, relu, training, dx, dres, dweight,
-                     dbias);
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (4 + (p.dres ? 1 : 0)) * (twin ? 2 : 1));  // x, y, dy read; dx [, dres] written
+  hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<true>, dim3(fold_grid(total4), twin ? 2 : 1), dim3(kApplyThreads), 0, stream, p,
+                     twin ? *twin : p, gpn::stat_slot_count(N), total4, C / 4, 1.0f / (float)N, relu, training);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

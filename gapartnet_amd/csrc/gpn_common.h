@@ -57,6 +57,19 @@ inline int stat_slot_count(int64_t rows) {
   while (s < kStatSlots && tiles > 64 * (int64_t)s) s *= 2;
   return s;
 }
+// A second, independent problem of the same shape over the same rulebook, computed by the workgroups with blockIdx.y == 1
+// of the SAME launch (the executor's paired passes over two structurally identical networks, net.hip): its operand /
+// result / BatchNorm-sum pointers.  in == nullptr: none.
+struct ConvTwin {
+  const float* in = nullptr;
+  const float* packed = nullptr;
+  float* out = nullptr;
+  unsigned long long* slab = nullptr;
+  const float* x = nullptr;
+  const float* y = nullptr;
+  const float* mean = nullptr;
+  const float* invstd = nullptr;
+};
 struct ConvStats {
   unsigned long long* slab = nullptr;  // [kStatSlots][4][C] fixed-point words (the first slot_mask + 1 sets used), zeroed by the caller
   int slot_mask = kStatSlots - 1;      // stat_slot_count(rows of the tensor the sums are over) - 1
@@ -65,6 +78,33 @@ struct ConvStats {
   const float* mean = nullptr;
   const float* invstd = nullptr;
   int relu = 0;
+  ConvTwin twin;  // (rides with the sums: both are "what else this launch does", and every launch path already carries this struct)
+};
+// pointer sets of the BatchNorm apply passes; a launch takes two and its workgroups pick by blockIdx.y (twin launches as above)
+struct BnFwdPtrs {
+  const float* x = nullptr;
+  const float* res = nullptr;
+  const void* partial = nullptr;
+  const float* weight = nullptr;
+  const float* bias = nullptr;
+  float* y = nullptr;
+  float* mean = nullptr;
+  float* invstd = nullptr;
+  float* running_mean = nullptr;
+  float* running_var = nullptr;
+};
+struct BnBwdPtrs {
+  const float* x = nullptr;
+  const float* y = nullptr;
+  const float* dy = nullptr;
+  const void* partial = nullptr;
+  const float* mean = nullptr;
+  const float* invstd = nullptr;
+  const float* weight = nullptr;
+  float* dx = nullptr;
+  float* dres = nullptr;
+  float* dweight = nullptr;
+  float* dbias = nullptr;
 };
 inline size_t stat_slab_bytes(int C) { return align_up((size_t)kStatSlots * 4 * C * sizeof(unsigned long long)); }
 
@@ -84,12 +124,10 @@ int rulebook_level_counts_dev(const int32_t* indices, int64_t n_max, const int64
                               hipStream_t stream);
 // BatchNorm apply passes over sums a conv launch accumulated (bn.hip); bn_two_pass: the shapes that take them
 bool bn_two_pass(int64_t N, int C);
-int bn_fwd_train_fused(const float* x, const float* res, const float* weight, const float* bias, int64_t N, int C, float eps,
-                       float momentum, int relu, float* y, float* mean, float* invstd, float* running_mean,
-                       float* running_var, const unsigned long long* slab, hipStream_t stream);
-int bn_bwd_fused(const float* x, const float* y, const float* dy, const float* weight, const float* mean, const float* invstd,
-                 int64_t N, int C, int relu, int training, float* dx, float* dres, float* dweight, float* dbias,
-                 const unsigned long long* slab, hipStream_t stream);
+// (partial = the slab; `twin`: a second BatchNorm of the same shape in the same launch, or nullptr)
+int bn_fwd_train_fused(const BnFwdPtrs& p, const BnFwdPtrs* twin, int64_t N, int C, float eps, float momentum, int relu,
+                       hipStream_t stream);
+int bn_bwd_fused(const BnBwdPtrs& p, const BnBwdPtrs* twin, int64_t N, int C, int relu, int training, hipStream_t stream);
 
 }  // namespace gpn
 

@@ -36,9 +36,18 @@ std::atomic<int> g_bn_fusion{[] {
   return e ? atoi(e) : 1;
 }()};
 
-// dst[r, 0:ca] = a[r, :], dst[r, ca:ca+cb] = b[r, :]   (float4 granularity; channel counts are multiples of 4)
-__global__ __launch_bounds__(kThreads) void concat_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                          int64_t rows, int ca4, int cb4, float4* __restrict__ dst) {
+// dst[r, 0:ca] = a[r, :], dst[r, ca:ca+cb] = b[r, :]   (float4 granularity; channel counts are multiples of 4).  Two pointer
+// sets per launch, picked by blockIdx.y (paired passes, see NetSet below)
+struct ConcatPtrs {
+  const float4* a;
+  const float4* b;
+  float4* dst;
+};
+__global__ __launch_bounds__(kThreads) void concat_kernel(ConcatPtrs pa, ConcatPtrs pb, int64_t rows, int ca4, int cb4) {
+  const ConcatPtrs& p = blockIdx.y ? pb : pa;
+  const float4* __restrict__ a = p.a;
+  const float4* __restrict__ b = p.b;
+  float4* __restrict__ dst = p.dst;
   const int c4 = ca4 + cb4;
   const int64_t total = rows * c4;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
@@ -49,9 +58,17 @@ __global__ __launch_bounds__(kThreads) void concat_kernel(const float4* __restri
 }
 
 // the transpose: da (+)= dsrc[:, 0:ca], db (+)= dsrc[:, ca:]; acc_a / acc_b select overwrite (0) or accumulate (1)
-__global__ __launch_bounds__(kThreads) void split_kernel(const float4* __restrict__ dsrc, int64_t rows, int ca4, int cb4,
-                                                         float4* __restrict__ da, int acc_a, float4* __restrict__ db,
+struct SplitPtrs {
+  const float4* dsrc;
+  float4* da;
+  float4* db;
+};
+__global__ __launch_bounds__(kThreads) void split_kernel(SplitPtrs pa, SplitPtrs pb, int64_t rows, int ca4, int cb4, int acc_a,
                                                          int acc_b) {
+  const SplitPtrs& pp = blockIdx.y ? pb : pa;
+  const float4* __restrict__ dsrc = pp.dsrc;
+  float4* __restrict__ da = pp.da;
+  float4* __restrict__ db = pp.db;
   const int c4 = ca4 + cb4;
   const int64_t total = rows * c4;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
@@ -264,92 +281,161 @@ extern "C" size_t gpn_net_ws_bytes(const gpn_net_op_t* ops, int n_ops, const gpn
   return n.tmp + n.op + n.wgrad + n.packed + n.stats;
 }
 
-extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
-                               const gpn_net_rulebook_t* rbs, int n_rbs, const gpn_net_conv_t* convs, int n_convs,
-                               const gpn_net_bn_t* bns, int n_bns, int training, void* ws, size_t ws_bytes,
-                               gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_program(__func__, ops, n_ops, slots, n_slots, rbs, n_rbs, convs, n_convs, bns, n_bns);
-  if (rc) return rc;
-  const Need need = workspace_need(ops, n_ops, slots, rbs, convs);
-  if (!ws || ws_bytes < need.packed + need.stats + need.op) {
-    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, need.packed + need.stats + need.op, ws_bytes);
+namespace {
+
+// One or two networks per pass.  Two ("paired" passes): structurally identical programs over the SAME rulebooks - the
+// ScoreNet and NPCS-Net U-Nets of network/model.py:116-118, which read the same proposal grid - whose layers are launched
+// TOGETHER: every conv / BatchNorm-apply / concat launch computes layer i of both networks (blockIdx.y picks the network's
+// pointer set: gpn::ConvTwin, gpn::BnFwdPtrs), so a pass over two small networks costs the launches of one.  The arithmetic
+// of each network is that of its own single pass (same kernels, same summation orders).
+struct NetSet {
+  gpn_net_slot_t* slots;
+  const gpn_net_conv_t* convs;
+  const gpn_net_bn_t* bns;
+};
+
+int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const NetSet* nets, int n_nets, int n_slots,
+                     const gpn_net_rulebook_t* rbs, int n_rbs, int n_convs, int n_bns, int training, void* ws, size_t ws_bytes,
+                     hipStream_t stream) {
+  int rc = GPN_OK;
+  for (int t = 0; t < n_nets; ++t) {
+    rc = check_program(who, ops, n_ops, nets[t].slots, n_slots, rbs, n_rbs, nets[t].convs, n_convs, nets[t].bns, n_bns);
+    if (rc) return rc;
+  }
+  const Need need = workspace_need(ops, n_ops, nets[0].slots, rbs, nets[0].convs);
+  const size_t per_net = need.packed + need.stats;
+  if (!ws || ws_bytes < n_nets * per_net + need.op) {
+    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", who, n_nets * per_net + need.op, ws_bytes);
     return GPN_ERR_WS;
   }
-  std::vector<const float*> packed_of;
-  rc = pack_program(ops, n_ops, rbs, convs, false, static_cast<char*>(ws), packed_of, stream);
-  if (rc) return rc;
-  void* op_ws = static_cast<char*>(ws) + need.packed + need.stats;
-  const size_t op_ws_bytes = ws_bytes - need.packed - need.stats;
+  std::vector<const float*> packed_of[2];
+  for (int t = 0; t < n_nets; ++t) {
+    rc = pack_program(ops, n_ops, rbs, nets[t].convs, false, static_cast<char*>(ws) + t * per_net, packed_of[t], stream);
+    if (rc) return rc;
+  }
+  void* op_ws = static_cast<char*>(ws) + n_nets * per_net;
+  const size_t op_ws_bytes = ws_bytes - n_nets * per_net;
   // training: a BatchNorm that directly follows a conv whose kernel has the sum epilogue gets its statistics from that
   // launch (bn_stats.h) and keeps only its apply pass
-  std::vector<unsigned long long*> slab_of(n_ops, nullptr);  // by BN op: where its sums are accumulated; by CONV op: same slab
+  std::vector<unsigned long long*> slab_of[2];  // by BN op: where its sums are accumulated; by CONV op: same slab
+  for (int t = 0; t < n_nets; ++t) slab_of[t].assign(n_ops, nullptr);
   if (training && g_bn_fusion.load(std::memory_order_relaxed)) {
     std::vector<int> readers(n_slots, 0);
     for (int i = 0; i < n_ops; ++i) {
       readers[ops[i].src0]++;
       if (ops[i].src1 >= 0) readers[ops[i].src1]++;
     }
-    char* area = static_cast<char*>(ws) + need.packed;
-    size_t off = 0;
-    for (int i = 0; i + 1 < n_ops; ++i) {
-      const gpn_net_op_t &cv_op = ops[i], &bn_op = ops[i + 1];
-      if (cv_op.kind != GPN_NET_CONV || bn_op.kind != GPN_NET_BN || bn_op.src0 != cv_op.dst || readers[cv_op.dst] != 1) continue;
-      const gpn_net_rulebook_t& rb = rbs[cv_op.rulebook];
-      const gpn_net_conv_t& cv = convs[cv_op.param];
-      if (!gpn::bn_two_pass(rb.n_dst, cv.cout) || !gpn::spconv_fwd_accumulates_stats(rb.K, rb.n_dst, cv.cin, cv.cout)) continue;
-      slab_of[i] = slab_of[i + 1] = reinterpret_cast<unsigned long long*>(area + off);
-      off += gpn::stat_slab_bytes(cv.cout);
+    for (int t = 0; t < n_nets; ++t) {
+      char* area = static_cast<char*>(ws) + t * per_net + need.packed;
+      size_t off = 0;
+      for (int i = 0; i + 1 < n_ops; ++i) {
+        const gpn_net_op_t &cv_op = ops[i], &bn_op = ops[i + 1];
+        if (cv_op.kind != GPN_NET_CONV || bn_op.kind != GPN_NET_BN || bn_op.src0 != cv_op.dst || readers[cv_op.dst] != 1) continue;
+        const gpn_net_rulebook_t& rb = rbs[cv_op.rulebook];
+        const gpn_net_conv_t& cv = nets[t].convs[cv_op.param];
+        if (!gpn::bn_two_pass(rb.n_dst, cv.cout) || !gpn::spconv_fwd_accumulates_stats(rb.K, rb.n_dst, cv.cin, cv.cout)) continue;
+        slab_of[t][i] = slab_of[t][i + 1] = reinterpret_cast<unsigned long long*>(area + off);
+        off += gpn::stat_slab_bytes(cv.cout);
+      }
+      if (off) GPN_CHECK_HIP(hipMemsetAsync(area, 0, off, stream));
     }
-    if (off) GPN_CHECK_HIP(hipMemsetAsync(area, 0, off, stream));
   }
+  const bool pair = n_nets == 2;
   for (int i = 0; i < n_ops; ++i) {
     const gpn_net_op_t& op = ops[i];
-    const gpn_net_slot_t &s0 = slots[op.src0], &d = slots[op.dst];
-    if (!s0.data || !d.data) {
-      gpn::set_error("%s: op %d: null activation pointer", __func__, i);
-      return GPN_ERR_ARG;
-    }
+    for (int t = 0; t < n_nets; ++t)
+      if (!nets[t].slots[op.src0].data || !nets[t].slots[op.dst].data) {
+        gpn::set_error("%s: op %d: null activation pointer", who, i);
+        return GPN_ERR_ARG;
+      }
+    const gpn_net_slot_t &s0 = nets[0].slots[op.src0], &d = nets[0].slots[op.dst];
     if (op.kind == GPN_NET_CONV) {
       const gpn_net_rulebook_t& rb = rbs[op.rulebook];
-      const gpn_net_conv_t& cv = convs[op.param];
+      const gpn_net_conv_t& cv = nets[0].convs[op.param];
       gpn::ConvStats st;
-      st.slab = slab_of[i];
+      st.slab = slab_of[0][i];
       st.slot_mask = gpn::stat_slot_count(rb.n_dst) - 1;
-      rc = gpn::spconv_fwd_into(s0.data, packed_of[i], rb.nbr, rb.nbr_p, rb.perm, rb.K, rb.n_dst, cv.cin, cv.cout, d.data, 0, st,
+      if (pair) {
+        st.twin.in = nets[1].slots[op.src0].data;
+        st.twin.packed = packed_of[1][i];
+        st.twin.out = nets[1].slots[op.dst].data;
+        st.twin.slab = slab_of[1][i];
+      }
+      rc = gpn::spconv_fwd_into(s0.data, packed_of[0][i], rb.nbr, rb.nbr_p, rb.perm, rb.K, rb.n_dst, cv.cin, cv.cout, d.data, 0, st,
                                 op_ws, op_ws_bytes, stream);
     } else if (op.kind == GPN_NET_BN) {
-      const gpn_net_bn_t& bn = bns[op.param];
-      const float* res = op.src1 >= 0 ? slots[op.src1].data : nullptr;
       const int relu = (op.flags & GPN_NET_RELU) ? 1 : 0;
-      if (training && slab_of[i]) {
-        rc = gpn::bn_fwd_train_fused(s0.data, res, bn.weight, bn.bias, s0.rows, bn.C, bn.eps, bn.momentum, relu, d.data,
-                                     bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, slab_of[i], stream);
-      } else if (training) {
-        rc = gpn_bn_fwd_train(s0.data, res, bn.weight, bn.bias, s0.rows, bn.C, bn.eps, bn.momentum, relu, d.data,
-                              bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, op_ws, op_ws_bytes, stream_);
+      gpn::BnFwdPtrs pp[2];
+      for (int t = 0; t < n_nets; ++t) {
+        const gpn_net_bn_t& bn = nets[t].bns[op.param];
+        pp[t].x = nets[t].slots[op.src0].data;
+        pp[t].res = op.src1 >= 0 ? nets[t].slots[op.src1].data : nullptr;
+        pp[t].partial = slab_of[t][i];
+        pp[t].weight = bn.weight, pp[t].bias = bn.bias, pp[t].y = nets[t].slots[op.dst].data;
+        pp[t].mean = bn.save_mean, pp[t].invstd = bn.save_invstd;
+        pp[t].running_mean = bn.running_mean, pp[t].running_var = bn.running_var;
+      }
+      const gpn_net_bn_t& bn0 = nets[0].bns[op.param];
+      const bool together = pair && nets[1].bns[op.param].eps == bn0.eps && nets[1].bns[op.param].momentum == bn0.momentum;
+      if (training && slab_of[0][i] && together) {
+        rc = gpn::bn_fwd_train_fused(pp[0], &pp[1], s0.rows, bn0.C, bn0.eps, bn0.momentum, relu, stream);
       } else {
-        if (!bn.running_mean || !bn.running_var || !bn.save_invstd) {
-          gpn::set_error("%s: op %d: eval-mode BatchNorm needs running statistics", __func__, i);
-          return GPN_ERR_ARG;
+        for (int t = 0; t < n_nets && rc == GPN_OK; ++t) {
+          const gpn_net_bn_t& bn = nets[t].bns[op.param];
+          if (training && slab_of[t][i]) {
+            rc = gpn::bn_fwd_train_fused(pp[t], nullptr, s0.rows, bn.C, bn.eps, bn.momentum, relu, stream);
+          } else if (training) {
+            rc = gpn_bn_fwd_train(pp[t].x, pp[t].res, bn.weight, bn.bias, s0.rows, bn.C, bn.eps, bn.momentum, relu, pp[t].y,
+                                  bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, op_ws, op_ws_bytes, (gpn_stream_t)stream);
+          } else {
+            if (!bn.running_mean || !bn.running_var || !bn.save_invstd) {
+              gpn::set_error("%s: op %d: eval-mode BatchNorm needs running statistics", who, i);
+              return GPN_ERR_ARG;
+            }
+            hipLaunchKernelGGL(invstd_kernel, dim3((bn.C + 63) / 64), dim3(64), 0, stream, bn.running_var, bn.eps, bn.C,
+                               bn.save_invstd);
+            GPN_CHECK_LAUNCH();
+            rc = gpn_bn_fwd_eval(pp[t].x, pp[t].res, bn.weight, bn.bias, bn.running_mean, bn.save_invstd, s0.rows, bn.C, relu,
+                                 pp[t].y, (gpn_stream_t)stream);
+          }
         }
-        hipLaunchKernelGGL(invstd_kernel, dim3((bn.C + 63) / 64), dim3(64), 0, stream, bn.running_var, bn.eps, bn.C,
-                           bn.save_invstd);
-        GPN_CHECK_LAUNCH();
-        rc = gpn_bn_fwd_eval(s0.data, res, bn.weight, bn.bias, bn.running_mean, bn.save_invstd, s0.rows, bn.C, relu,
-                             d.data, stream_);
       }
     } else {
-      const gpn_net_slot_t& s1 = slots[op.src1];
-      hipLaunchKernelGGL(concat_kernel, dim3(grid_for(d.rows * (d.channels / 4))), dim3(kThreads), 0, stream,
-                         (const float4*)s0.data, (const float4*)s1.data, d.rows, s0.channels / 4, s1.channels / 4,
-                         (float4*)d.data);
+      const gpn_net_slot_t& s1 = nets[0].slots[op.src1];
+      ConcatPtrs ca{(const float4*)s0.data, (const float4*)s1.data, (float4*)d.data}, cb = ca;
+      if (pair)
+        cb = ConcatPtrs{(const float4*)nets[1].slots[op.src0].data, (const float4*)nets[1].slots[op.src1].data,
+                        (float4*)nets[1].slots[op.dst].data};
+      hipLaunchKernelGGL(concat_kernel, dim3(grid_for(d.rows * (d.channels / 4)), n_nets), dim3(kThreads), 0, stream, ca, cb,
+                         d.rows, s0.channels / 4, s1.channels / 4);
       GPN_CHECK_LAUNCH();
       rc = GPN_OK;
     }
     if (rc) return rc;
   }
   return GPN_OK;
+}
+
+}  // namespace
+
+extern "C" int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
+                               const gpn_net_rulebook_t* rbs, int n_rbs, const gpn_net_conv_t* convs, int n_convs,
+                               const gpn_net_bn_t* bns, int n_bns, int training, void* ws, size_t ws_bytes,
+                               gpn_stream_t stream_) {
+  const NetSet one{slots, convs, bns};
+  return net_forward_impl(__func__, ops, n_ops, &one, 1, n_slots, rbs, n_rbs, n_convs, n_bns, training, ws, ws_bytes,
+                          (hipStream_t)stream_);
+}
+
+// two structurally identical networks over the same rulebooks in one pass (see NetSet); workspace: 2 x gpn_net_ws_bytes
+extern "C" int gpn_net_forward_pair(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots_a, gpn_net_slot_t* slots_b,
+                                    int n_slots, const gpn_net_rulebook_t* rbs, int n_rbs, const gpn_net_conv_t* convs_a,
+                                    const gpn_net_conv_t* convs_b, int n_convs, const gpn_net_bn_t* bns_a,
+                                    const gpn_net_bn_t* bns_b, int n_bns, int training, void* ws, size_t ws_bytes,
+                                    gpn_stream_t stream_) {
+  const NetSet two[2] = {{slots_a, convs_a, bns_a}, {slots_b, convs_b, bns_b}};
+  return net_forward_impl(__func__, ops, n_ops, two, 2, n_slots, rbs, n_rbs, n_convs, n_bns, training, ws, ws_bytes,
+                          (hipStream_t)stream_);
 }
 
 namespace {
@@ -499,33 +585,39 @@ int commit(gpn_net_slot_t& s, const GradTarget& t, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
-                                const gpn_net_rulebook_t* rbs, int n_rbs, const gpn_net_conv_t* convs, int n_convs,
-                                const gpn_net_bn_t* bns, int n_bns, int training, int need_input_grad, void* ws,
-                                size_t ws_bytes, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_program(__func__, ops, n_ops, slots, n_slots, rbs, n_rbs, convs, n_convs, bns, n_bns);
-  if (rc) return rc;
-  const Need need = workspace_need(ops, n_ops, slots, rbs, convs);
-  const size_t total_need = need.tmp + need.packed + need.stats + need.op + need.wgrad;
+namespace {
+
+int net_backward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const NetSet* nets, int n_nets, int n_slots,
+                      const gpn_net_rulebook_t* rbs, int n_rbs, int n_convs, int n_bns, int training, int need_input_grad,
+                      void* ws, size_t ws_bytes, hipStream_t stream) {
+  int rc = GPN_OK;
+  for (int t = 0; t < n_nets; ++t) {
+    rc = check_program(who, ops, n_ops, nets[t].slots, n_slots, rbs, n_rbs, nets[t].convs, n_convs, nets[t].bns, n_bns);
+    if (rc) return rc;
+  }
+  const Need need = workspace_need(ops, n_ops, nets[0].slots, rbs, nets[0].convs);
+  const size_t per_net = need.tmp + need.packed + need.stats;
+  const size_t total_need = n_nets * per_net + need.op + need.wgrad;
   if (!ws || ws_bytes < total_need) {
-    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", __func__, total_need, ws_bytes);
+    gpn::set_error("%s: workspace too small (%zu needed, %zu given)", who, total_need, ws_bytes);
     return GPN_ERR_WS;
   }
   char* base = static_cast<char*>(ws);
-  float* tmp = reinterpret_cast<float*>(base);
-  char* stats_area = base + need.tmp + need.packed;
-  void* op_ws = base + need.tmp + need.packed + need.stats;
+  float* tmp[2] = {reinterpret_cast<float*>(base), reinterpret_cast<float*>(base + per_net)};
+  void* op_ws = base + n_nets * per_net;
   const size_t op_ws_bytes = need.op;
-  void* wgrad_ws = base + need.tmp + need.packed + need.stats + need.op;
-  const size_t wgrad_ws_bytes = ws_bytes - (need.tmp + need.packed + need.stats + need.op);
-  std::vector<const float*> packed_of;
-  rc = pack_program(ops, n_ops, rbs, convs, true, base + need.tmp, packed_of, stream);
-  if (rc) return rc;
+  void* wgrad_ws = base + n_nets * per_net + need.op;
+  const size_t wgrad_ws_bytes = ws_bytes - (n_nets * per_net + need.op);
+  std::vector<const float*> packed_of[2];
+  for (int t = 0; t < n_nets; ++t) {
+    rc = pack_program(ops, n_ops, rbs, nets[t].convs, true, base + t * per_net + need.tmp, packed_of[t], stream);
+    if (rc) return rc;
+  }
   // A dgrad conv that writes the FINAL gradient of a BatchNorm's output (it is the slot's first reader in program order, so
   // the last one of this reverse walk) adds that BatchNorm's backward sums in its epilogue (bn_stats.h); the BatchNorm then
-  // runs only its apply pass.  bn_slab[j]: the slab of BN op j; fused_by[i]: the BN op a CONV op i accumulates for.
-  std::vector<unsigned long long*> bn_slab(n_ops, nullptr);
+  // runs only its apply pass.  bn_slab[t][j]: the slab of BN op j of network t; fused_by[i]: the BN op CONV op i accumulates for.
+  std::vector<unsigned long long*> bn_slab[2];
+  for (int t = 0; t < n_nets; ++t) bn_slab[t].assign(n_ops, nullptr);
   std::vector<int> fused_by(n_ops, -1);
   std::vector<char> sums_done(n_ops, 0);
   if (g_bn_fusion.load(std::memory_order_relaxed)) {
@@ -542,17 +634,19 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
       if (j < 0 || ops[j].kind != GPN_NET_BN || first_reader[ops[i].src0] != i) continue;
       if (ops[i].src0 == 0 && !need_input_grad) continue;
       const gpn_net_rulebook_t& rb = rbs[ops[i].rulebook];
-      const gpn_net_conv_t& cv = convs[ops[i].param];
+      const gpn_net_conv_t& cv = nets[0].convs[ops[i].param];
       if (!gpn::bn_two_pass(rb.n_src, cv.cin) || !gpn::spconv_fwd_accumulates_stats(rb.K, rb.n_src, cv.cout, cv.cin)) continue;
-      bn_slab[j] = reinterpret_cast<unsigned long long*>(stats_area + off);
+      for (int t = 0; t < n_nets; ++t)
+        bn_slab[t][j] = reinterpret_cast<unsigned long long*>(base + t * per_net + need.tmp + need.packed + off);
       off += gpn::stat_slab_bytes(cv.cin);
       fused_by[i] = j;
     }
-    if (off) GPN_CHECK_HIP(hipMemsetAsync(stats_area, 0, off, stream));
+    if (off)
+      for (int t = 0; t < n_nets; ++t) GPN_CHECK_HIP(hipMemsetAsync(base + t * per_net + need.tmp + need.packed, 0, off, stream));
   }
   SideStream* side = side_stream();
   if (!side) {
-    gpn::set_error("%s: could not create the weight-gradient stream", __func__);
+    gpn::set_error("%s: could not create the weight-gradient stream", who);
     return GPN_ERR_HIP;
   }
   // the side stream may still be reading the workspace of the previous call on this device
@@ -565,7 +659,7 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
   DeviceWorker& dw = device_worker(device);
   std::lock_guard<std::mutex> pass_lock(dw.pass_mu);
   WgradWorker& worker = dw.worker;
-  worker.begin(device, side->stream, wgrad_ws, wgrad_ws_bytes, (size_t)n_ops);
+  worker.begin(device, side->stream, wgrad_ws, wgrad_ws_bytes, (size_t)n_ops * n_nets);
   // every exit below must close the pass, or the worker would spin forever
   struct PassGuard {
     WgradWorker& w;
@@ -577,102 +671,140 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
       }
     }
   } guard{worker};
+  const bool pair = n_nets == 2;
   for (int i = n_ops - 1; i >= 0; --i) {
     const gpn_net_op_t& op = ops[i];
-    gpn_net_slot_t &s0 = slots[op.src0], &d = slots[op.dst];
+    gpn_net_slot_t &s0 = nets[0].slots[op.src0], &d = nets[0].slots[op.dst];
     if (!d.grad_state) continue;  // nothing flows back through this op (its output does not reach the loss)
-    if (!d.grad || !s0.data || !d.data) {
-      gpn::set_error("%s: op %d: null pointer", __func__, i);
-      return GPN_ERR_ARG;
+    for (int t = 0; t < n_nets; ++t) {
+      const gpn_net_slot_t &ts0 = nets[t].slots[op.src0], &td = nets[t].slots[op.dst];
+      if (!td.grad || !ts0.data || !td.data || td.grad_state != d.grad_state) {
+        gpn::set_error("%s: op %d: null pointer (or the two networks' gradient states differ)", who, i);
+        return GPN_ERR_ARG;
+      }
     }
     if (op.kind == GPN_NET_CONV) {
       const gpn_net_rulebook_t& rb = rbs[op.rulebook];
-      const gpn_net_conv_t& cv = convs[op.param];
-      if (cv.dW) {
+      const gpn_net_conv_t& cv = nets[0].convs[op.param];
+      bool any_dw = false;
+      for (int t = 0; t < n_nets; ++t) any_dw = any_dw || nets[t].convs[op.param].dW;
+      if (any_dw) {
         if (!rb.pair_src || !rb.pair_dst || !rb.tile_off) {
-          gpn::set_error("%s: op %d: rulebook has no pair lists for wgrad", __func__, i);
+          gpn::set_error("%s: op %d: rulebook has no pair lists for wgrad", who, i);
           return GPN_ERR_ARG;
         }
         // d.grad is final here (every consumer of slot d ran earlier in this reverse walk): fork the contraction
         hipEvent_t ev = side->fork[side->next];
         side->next = (side->next + 1) % kForkEvents;
         GPN_CHECK_HIP(hipEventRecord(ev, stream));
-        worker.push(WgradJob{s0.data, d.grad, rb.pair_src, rb.pair_dst, rb.tile_off, rb.K, rb.n_dst, cv.cin, cv.cout,
-                             cv.dW, ev});
+        for (int t = 0; t < n_nets; ++t)
+          if (nets[t].convs[op.param].dW)
+            worker.push(WgradJob{nets[t].slots[op.src0].data, nets[t].slots[op.dst].grad, rb.pair_src, rb.pair_dst, rb.tile_off,
+                                 rb.K, rb.n_dst, cv.cin, cv.cout, nets[t].convs[op.param].dW, ev});
         forked = true;
       }
       if (op.src0 != 0 || need_input_grad) {
-        if (!s0.grad || !rb.nbr_t) {
-          gpn::set_error("%s: op %d: null gradient buffer / transposed table", __func__, i);
-          return GPN_ERR_ARG;
-        }
+        for (int t = 0; t < n_nets; ++t)
+          if (!nets[t].slots[op.src0].grad || !rb.nbr_t) {
+            gpn::set_error("%s: op %d: null gradient buffer / transposed table", who, i);
+            return GPN_ERR_ARG;
+          }
         // a slot that already holds a gradient takes this one added in place (no staging buffer, no accumulate launch)
         gpn::ConvStats st;
+        if (pair) {
+          st.twin.in = nets[1].slots[op.dst].grad;
+          st.twin.packed = packed_of[1][i];
+          st.twin.out = nets[1].slots[op.src0].grad;
+        }
         if (fused_by[i] >= 0) {
           const gpn_net_op_t& bo = ops[fused_by[i]];
-          const gpn_net_bn_t& bn = bns[bo.param];
-          st.slab = bn_slab[fused_by[i]];
+          const gpn_net_bn_t& bn = nets[0].bns[bo.param];
+          st.slab = bn_slab[0][fused_by[i]];
           st.slot_mask = gpn::stat_slot_count(rb.n_src) - 1;
-          st.x = slots[bo.src0].data;
+          st.x = nets[0].slots[bo.src0].data;
           st.y = s0.data;
           st.mean = training ? bn.save_mean : bn.running_mean;
           st.invstd = bn.save_invstd;
           st.relu = (bo.flags & GPN_NET_RELU) ? 1 : 0;
+          if (pair) {
+            const gpn_net_bn_t& bn1 = nets[1].bns[bo.param];
+            st.twin.slab = bn_slab[1][fused_by[i]];
+            st.twin.x = nets[1].slots[bo.src0].data;
+            st.twin.y = nets[1].slots[op.src0].data;
+            st.twin.mean = training ? bn1.save_mean : bn1.running_mean;
+            st.twin.invstd = bn1.save_invstd;
+          }
           sums_done[fused_by[i]] = 1;
         }
-        rc = gpn::spconv_fwd_into(d.grad, packed_of[i], rb.nbr_t, rb.nbr_t_p, rb.perm_t, rb.K, rb.n_src, cv.cout, cv.cin, s0.grad,
+        rc = gpn::spconv_fwd_into(d.grad, packed_of[0][i], rb.nbr_t, rb.nbr_t_p, rb.perm_t, rb.K, rb.n_src, cv.cout, cv.cin, s0.grad,
                                   s0.grad_state ? 1 : 0, st, op_ws, op_ws_bytes, stream);
         if (rc) return rc;
-        s0.grad_state = 1;
+        for (int t = 0; t < n_nets; ++t) nets[t].slots[op.src0].grad_state = 1;
       }
     } else if (op.kind == GPN_NET_BN) {
-      const gpn_net_bn_t& bn = bns[op.param];
-      if (!s0.grad || !bn.dweight || !bn.dbias) {
-        gpn::set_error("%s: op %d: null gradient buffer", __func__, i);
-        return GPN_ERR_ARG;
-      }
-      const float* mean = training ? bn.save_mean : bn.running_mean;
-      GradTarget tx = grad_target(s0, tmp);
-      if (tx.staged) {
-        gpn::set_error("%s: op %d: BatchNorm input consumed twice is not supported", __func__, i);
-        return GPN_ERR_ARG;
-      }
-      float* dres = nullptr;
-      GradTarget tr{nullptr, false};
-      if (op.src1 >= 0 && (op.src1 != 0 || need_input_grad)) {
-        if (!slots[op.src1].grad) {
-          gpn::set_error("%s: op %d: null residual gradient buffer", __func__, i);
+      const int relu = (op.flags & GPN_NET_RELU) ? 1 : 0;
+      gpn::BnBwdPtrs pp[2];
+      GradTarget tr[2] = {{nullptr, false}, {nullptr, false}};
+      for (int t = 0; t < n_nets; ++t) {
+        const gpn_net_bn_t& bn = nets[t].bns[op.param];
+        gpn_net_slot_t& ts0 = nets[t].slots[op.src0];
+        if (!ts0.grad || !bn.dweight || !bn.dbias) {
+          gpn::set_error("%s: op %d: null gradient buffer", who, i);
           return GPN_ERR_ARG;
         }
-        tr = grad_target(slots[op.src1], tmp);
-        dres = tr.ptr;
+        GradTarget tx = grad_target(ts0, tmp[t]);
+        if (tx.staged) {
+          gpn::set_error("%s: op %d: BatchNorm input consumed twice is not supported", who, i);
+          return GPN_ERR_ARG;
+        }
+        if (op.src1 >= 0 && (op.src1 != 0 || need_input_grad)) {
+          if (!nets[t].slots[op.src1].grad) {
+            gpn::set_error("%s: op %d: null residual gradient buffer", who, i);
+            return GPN_ERR_ARG;
+          }
+          tr[t] = grad_target(nets[t].slots[op.src1], tmp[t]);
+        }
+        pp[t].x = ts0.data, pp[t].y = nets[t].slots[op.dst].data, pp[t].dy = nets[t].slots[op.dst].grad;
+        pp[t].partial = bn_slab[t][i];
+        pp[t].mean = training ? bn.save_mean : bn.running_mean;
+        pp[t].invstd = bn.save_invstd, pp[t].weight = bn.weight;
+        pp[t].dx = tx.ptr, pp[t].dres = tr[t].ptr, pp[t].dweight = bn.dweight, pp[t].dbias = bn.dbias;
       }
-      if (sums_done[i])
-        rc = gpn::bn_bwd_fused(s0.data, d.data, d.grad, bn.weight, mean, bn.save_invstd, s0.rows, bn.C,
-                               (op.flags & GPN_NET_RELU) ? 1 : 0, training ? 1 : 0, tx.ptr, dres, bn.dweight, bn.dbias, bn_slab[i],
-                               stream);
-      else
-        rc = gpn_bn_bwd(s0.data, d.data, d.grad, bn.weight, mean, bn.save_invstd, s0.rows, bn.C,
-                        (op.flags & GPN_NET_RELU) ? 1 : 0, training ? 1 : 0, tx.ptr, dres, bn.dweight, bn.dbias, op_ws,
-                        op_ws_bytes, stream_);
+      const gpn_net_bn_t& bn0 = nets[0].bns[op.param];
+      if (sums_done[i] && pair) {
+        rc = gpn::bn_bwd_fused(pp[0], &pp[1], s0.rows, bn0.C, relu, training ? 1 : 0, stream);
+      } else {
+        for (int t = 0; t < n_nets && rc == GPN_OK; ++t) {
+          if (sums_done[i])
+            rc = gpn::bn_bwd_fused(pp[t], nullptr, s0.rows, bn0.C, relu, training ? 1 : 0, stream);
+          else
+            rc = gpn_bn_bwd(pp[t].x, pp[t].y, pp[t].dy, pp[t].weight, pp[t].mean, pp[t].invstd, s0.rows, bn0.C, relu,
+                            training ? 1 : 0, pp[t].dx, pp[t].dres, pp[t].dweight, pp[t].dbias, op_ws, op_ws_bytes, (gpn_stream_t)stream);
+        }
+      }
       if (rc) return rc;
-      s0.grad_state = 1;
-      if (dres) {
-        rc = commit(slots[op.src1], tr, stream);
-        if (rc) return rc;
+      for (int t = 0; t < n_nets; ++t) {
+        nets[t].slots[op.src0].grad_state = 1;
+        if (pp[t].dres) {
+          rc = commit(nets[t].slots[op.src1], tr[t], stream);
+          if (rc) return rc;
+        }
       }
     } else {
-      gpn_net_slot_t& s1 = slots[op.src1];
-      if (!s0.grad || !s1.grad) {
-        gpn::set_error("%s: op %d: null gradient buffer", __func__, i);
-        return GPN_ERR_ARG;
-      }
-      hipLaunchKernelGGL(split_kernel, dim3(grid_for(d.rows * (d.channels / 4))), dim3(kThreads), 0, stream,
-                         (const float4*)d.grad, d.rows, s0.channels / 4, s1.channels / 4, (float4*)s0.grad,
-                         s0.grad_state, (float4*)s1.grad, s1.grad_state);
+      gpn_net_slot_t& s1 = nets[0].slots[op.src1];
+      for (int t = 0; t < n_nets; ++t)
+        if (!nets[t].slots[op.src0].grad || !nets[t].slots[op.src1].grad) {
+          gpn::set_error("%s: op %d: null gradient buffer", who, i);
+          return GPN_ERR_ARG;
+        }
+      SplitPtrs sa{(const float4*)d.grad, (float4*)s0.grad, (float4*)s1.grad}, sb = sa;
+      if (pair)
+        sb = SplitPtrs{(const float4*)nets[1].slots[op.dst].grad, (float4*)nets[1].slots[op.src0].grad,
+                       (float4*)nets[1].slots[op.src1].grad};
+      hipLaunchKernelGGL(split_kernel, dim3(grid_for(d.rows * (d.channels / 4)), n_nets), dim3(kThreads), 0, stream, sa, sb, d.rows,
+                         s0.channels / 4, s1.channels / 4, s0.grad_state, s1.grad_state);
       GPN_CHECK_LAUNCH();
-      s0.grad_state = 1;
-      s1.grad_state = 1;
+      for (int t = 0; t < n_nets; ++t) nets[t].slots[op.src0].grad_state = nets[t].slots[op.src1].grad_state = 1;
     }
   }
   std::string worker_err;
@@ -687,4 +819,25 @@ extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot
     GPN_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
   }
   return GPN_OK;
+}
+
+}  // namespace
+
+extern "C" int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,
+                                const gpn_net_rulebook_t* rbs, int n_rbs, const gpn_net_conv_t* convs, int n_convs,
+                                const gpn_net_bn_t* bns, int n_bns, int training, int need_input_grad, void* ws,
+                                size_t ws_bytes, gpn_stream_t stream_) {
+  const NetSet one{slots, convs, bns};
+  return net_backward_impl(__func__, ops, n_ops, &one, 1, n_slots, rbs, n_rbs, n_convs, n_bns, training, need_input_grad, ws,
+                           ws_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int gpn_net_backward_pair(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots_a, gpn_net_slot_t* slots_b,
+                                     int n_slots, const gpn_net_rulebook_t* rbs, int n_rbs, const gpn_net_conv_t* convs_a,
+                                     const gpn_net_conv_t* convs_b, int n_convs, const gpn_net_bn_t* bns_a,
+                                     const gpn_net_bn_t* bns_b, int n_bns, int training, int need_input_grad, void* ws,
+                                     size_t ws_bytes, gpn_stream_t stream_) {
+  const NetSet two[2] = {{slots_a, convs_a, bns_a}, {slots_b, convs_b, bns_b}};
+  return net_backward_impl(__func__, ops, n_ops, two, 2, n_slots, rbs, n_rbs, n_convs, n_bns, training, need_input_grad, ws,
+                           ws_bytes, (hipStream_t)stream_);
 }

@@ -293,6 +293,11 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
                                                                 int64_t units, size_t packed_bytes,
                                                                 const int32_t* __restrict__ perm, int accumulate,
                                                                 gpn::ConvStats stats, float* __restrict__ out) {
+  if (blockIdx.y) {  // the launch's second problem (gpn::ConvTwin)
+    in = stats.twin.in, packed = stats.twin.packed, out = stats.twin.out;
+    stats.slab = stats.twin.slab, stats.x = stats.twin.x, stats.y = stats.twin.y, stats.mean = stats.twin.mean,
+    stats.invstd = stats.twin.invstd;
+  }
   constexpr int S = KT * CB;
   constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;  // prefetch depth in stages
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -442,6 +447,11 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;
   constexpr int UPW = 4 / SP;             // units per workgroup
   __shared__ f32x4 red[4][64];
+  if (blockIdx.y) {  // the launch's second problem (gpn::ConvTwin)
+    in = stats.twin.in, packed = stats.twin.packed, out = stats.twin.out;
+    stats.slab = stats.twin.slab, stats.x = stats.twin.x, stats.y = stats.twin.y, stats.mean = stats.twin.mean,
+    stats.invstd = stats.twin.invstd;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   const int64_t wg = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -577,7 +587,7 @@ int launch_split(const float* in, const float* packed, const int32_t* nbr, const
                  int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
-  hipLaunchKernelGGL((spconv_fwd_split_kernel<KT, CB, SP>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4 / SP), 8) * 8)), dim3(256), 0,
+  hipLaunchKernelGGL((spconv_fwd_split_kernel<KT, CB, SP>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4 / SP), 8) * 8), stats.twin.in ? 2 : 1), dim3(256), 0,
                      stream, in, packed, nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
@@ -594,7 +604,7 @@ int launch_direct(const float* in, const float* packed, const int32_t* nbr, cons
       return launch_split<KT, CB, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
   }
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
-  hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4), 8) * 8)), dim3(256), 0, stream, in, packed,
+  hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4), 8) * 8), stats.twin.in ? 2 : 1), dim3(256), 0, stream, in, packed,
                      nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
@@ -675,6 +685,7 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
   GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
   if (n_dst == 0) return GPN_OK;
   GPN_CHECK_ARG(in && packed_w && nbr && out);
+  GPN_CHECK_ARG(!stats.twin.in || (stats.twin.packed && stats.twin.out && (stats.slab == nullptr) == (stats.twin.slab == nullptr)));
   const int nt = cout / 16;
   if (gpn::spconv_tiles_supported(K, n_dst, cin, cout)) {  // the masked-tile kernel (spconv_tiles.hip): every layer of >= 16 tiles
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
@@ -687,9 +698,15 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
            : K == 8 ? dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream)
                     : dispatch_direct<1>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream);
   }
-  if (stats.slab) {
+  if (stats.slab || stats.twin.slab) {
     gpn::set_error("gpn_spconv_fwd: this shape runs on a kernel without a BatchNorm-sum epilogue (see spconv_fwd_accumulates_stats)");
     return GPN_ERR_ARG;
+  }
+  if (stats.twin.in) {  // the lock-step kernel takes one problem per launch
+    const gpn::ConvTwin tw = stats.twin;
+    int rc2 = gpn::spconv_fwd_into(in, packed_w, nbr, nbr_p, perm, K, n_dst, cin, cout, out, accumulate, gpn::ConvStats(), ws, ws_bytes, stream);
+    if (rc2) return rc2;
+    return gpn::spconv_fwd_into(tw.in, tw.packed, nbr, nbr_p, perm, K, n_dst, cin, cout, tw.out, accumulate, gpn::ConvStats(), ws, ws_bytes, stream);
   }
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   float* target = out;

@@ -55,6 +55,11 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
                                                            int K, int64_t n_dst, int n_tiles, int n_units, int nt_total,
                                                            int col_groups, size_t packed_bytes, int accumulate,
                                                            gpn::ConvStats stats, float* __restrict__ out) {
+  if (blockIdx.y) {  // the launch's second problem (gpn::ConvTwin)
+    in = stats.twin.in, packed = stats.twin.packed, out = stats.twin.out;
+    stats.slab = stats.twin.slab, stats.x = stats.twin.x, stats.y = stats.twin.y, stats.mean = stats.twin.mean,
+    stats.invstd = stats.twin.invstd;
+  }
   constexpr int U = cfg_group(CB, R, NT);
   constexpr int RW = R * 16;        // rows of a wave
   constexpr int TPI = 64 / RW;      // taps covered by one table load of the prologue
@@ -261,7 +266,7 @@ int launch_tiles(const float* in, const float* packed, const int32_t* nbr, const
   const int col_groups = nt_total / NT;
   const int n_units = (int)gpn::cdiv(n_tiles, R) * col_groups;
   const size_t packed_bytes = (size_t)K * CB * nt_total * 1024;
-  const dim3 grid((unsigned)(gpn::cdiv(gpn::cdiv(n_units, 4), 8) * 8));
+  const dim3 grid((unsigned)(gpn::cdiv(gpn::cdiv(n_units, 4), 8) * 8), stats.twin.in ? 2 : 1);
   hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
                      n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out);
   GPN_CHECK_LAUNCH();

@@ -14,6 +14,7 @@ Pipeline of one step (model.py:466-659):
   -> [epoch >= schedule[1]] NPCS U-Net -> per-point NPCS, symmetry-aware loss
 """
 import functools
+import os
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -296,10 +297,26 @@ class GAPartNet(LightningModule):
                               instance_labels=built["instance_labels"])
         return voxel_tensor, built["pc_voxel_id"], proposals
 
+    # ScoreNet and NPCS-Net read the same proposal grid and have the same structure: with both switched on, their U-Nets run
+    # as PAIRED passes of the native executor (network/net_exec.run_pair: layer i of both networks in one launch per kernel,
+    # forward and backward) - same values as one after the other, half the launches of a part of the step where the GPU
+    # waits for the host to issue them.  GPN_NET_PAIR=0 runs them one after the other.
+    pair_proposal_unets = os.environ.get("GPN_NET_PAIR", "1") != "0"
+
+    def forward_proposal_unets(self, voxel_tensor: spconv.SparseConvTensor):
+        """(score_unet(x), npcs_unet(x)) in paired passes, or None where that form does not apply"""
+        if not self.pair_proposal_unets or backend.raw().name != "hip":
+            return None
+        if not (getattr(self.score_unet, "use_native_executor", False) and getattr(self.npcs_unet, "use_native_executor", False)):
+            return None
+        from . import net_exec
+        return net_exec.run_pair(self.score_unet, self.npcs_unet, voxel_tensor)
+
     def forward_proposal_score(self, voxel_tensor: spconv.SparseConvTensor, pc_voxel_id: torch.Tensor,
-                               proposals: Instances) -> torch.Tensor:
+                               proposals: Instances, feats: Optional[spconv.SparseConvTensor] = None) -> torch.Tensor:
         offsets = proposals.proposal_offsets
-        feats = self.score_unet(voxel_tensor)
+        if feats is None:
+            feats = self.score_unet(voxel_tensor)
         feats = GF.gather_rows(feats.features, pc_voxel_id, getattr(voxel_tensor, "point_csr", None))
         pooled, _ = segmented_maxpool(feats, offsets[:-1], offsets[1:])
         return GF.linear(pooled, self.score_head.weight, self.score_head.bias)
@@ -313,8 +330,10 @@ class GAPartNet(LightningModule):
         gt_scores = get_gt_scores(ious.max(-1)[0], 0.75, 0.25)
         return F.binary_cross_entropy_with_logits(score_logits, gt_scores)
 
-    def forward_proposal_npcs(self, voxel_tensor: spconv.SparseConvTensor, pc_voxel_id: torch.Tensor) -> torch.Tensor:
-        feats = self.npcs_unet(voxel_tensor)
+    def forward_proposal_npcs(self, voxel_tensor: spconv.SparseConvTensor, pc_voxel_id: torch.Tensor,
+                              feats: Optional[spconv.SparseConvTensor] = None) -> torch.Tensor:
+        if feats is None:
+            feats = self.npcs_unet(voxel_tensor)
         logits = GF.linear(feats.features, self.npcs_head.weight, self.npcs_head.bias)
         return GF.gather_rows(logits, pc_voxel_id, getattr(voxel_tensor, "point_csr", None))
 
@@ -452,9 +471,15 @@ class GAPartNet(LightningModule):
                     proposals.sem_labels = sem_labels[self._proposal_rows(proposals)]
                 proposals.instance_sem_labels = data_batch.instance_sem_labels
 
+        pair = None
+        if (self.current_epoch >= self.start_scorenet and self.current_epoch >= self.start_npcs and voxel_tensor is not None
+                and proposals is not None):
+            pair = self.forward_proposal_unets(voxel_tensor)
+        score_feats, npcs_feats = pair if pair is not None else (None, None)
+
         loss_prop_score = 0.0
         if self.current_epoch >= self.start_scorenet and voxel_tensor is not None and proposals is not None:
-            score_logits = self.forward_proposal_score(voxel_tensor, pc_voxel_id, proposals)
+            score_logits = self.forward_proposal_score(voxel_tensor, pc_voxel_id, proposals, score_feats)
             first_point = proposals.proposal_offsets[:-1].long()
             cls_source = proposals.sem_labels if proposals.sem_labels is not None else proposals.sem_preds
             proposal_cls = cls_source[first_point].long()
@@ -466,7 +491,7 @@ class GAPartNet(LightningModule):
 
         loss_prop_npcs = 0.0
         if self.current_epoch >= self.start_npcs and voxel_tensor is not None:
-            npcs_logits = self.forward_proposal_npcs(voxel_tensor, pc_voxel_id)
+            npcs_logits = self.forward_proposal_npcs(voxel_tensor, pc_voxel_id, npcs_feats)
             if gt_npcs is not None:
                 gt_npcs = gt_npcs[self._proposal_rows(proposals)]
                 loss_prop_npcs = self.loss_proposal_npcs(npcs_logits, gt_npcs, proposals)

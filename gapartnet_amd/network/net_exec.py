@@ -344,10 +344,25 @@ def _has_hooks(p) -> bool:
     return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
 
 
-def _forward_impl(ctx, features, prog: NetProgram, rt, training):
+def _call_pair(fn_name, prog, slots_a, slots_b, rb_table, conv_a, conv_b, bn_a, bn_b, extra, device):
+    from ..hip_ops import _fast_ws
+    L = _C.lib()
+    fn = getattr(L, fn_name)
+    ws_ptr, ws_size, stream = _fast_ws(device)
+    args = (_vp(prog.ops_np), len(prog.ops_np), _vp(slots_a), _vp(slots_b), len(slots_a), _vp(rb_table), len(rb_table),
+            _vp(conv_a), _vp(conv_b), len(conv_a), _vp(bn_a), _vp(bn_b), len(bn_a)) + extra
+    rc = fn(*args, ctypes.c_void_p(ws_ptr), ctypes.c_size_t(ws_size), ctypes.c_void_p(stream))
+    if rc == 2:  # workspace too small: twice the library's estimate for one network
+        need = 2 * L.gpn_net_ws_bytes(_vp(prog.ops_np), len(prog.ops_np), _vp(slots_a), len(slots_a), _vp(rb_table), _vp(conv_a))
+        ws_ptr, ws_size, stream = _fast_ws(device, int(need))
+        rc = fn(*args, ctypes.c_void_p(ws_ptr), ctypes.c_size_t(ws_size), ctypes.c_void_p(stream))
+    if rc:
+        raise _C.GpnError(f"{fn_name} failed: {L.gpn_last_error().decode('utf-8', 'replace')}")
+
+
+def _forward_tables(features, prog: NetProgram, rows):
+    """activation arena, slot / weight / BatchNorm tables of one forward pass of ``prog`` over ``features``"""
     params = prog.params()
-    rows, rb_table, rb_objs = rt
-    features = features.contiguous()
     dev = features.device
     n_slots = len(prog.slot_level)
     slot_rows = rows[prog.slot_level_np]
@@ -378,25 +393,33 @@ def _forward_impl(ctx, features, prog: NetProgram, rt, training):
     bn_table["eps"] = prog.bn_eps
     bn_table["momentum"] = prog.bn_momentum
     bn_table["C"] = prog.bn_C
-    _call("gpn_net_forward", prog, slots, rb_table, conv_table, bn_table, (1 if training else 0,), dev)
+    o = prog.out_slot
+    out = arena[int(offs[o]):int(offs[o + 1])].view(int(slot_rows[o]), int(prog.slot_channels_np[o]))
+    return out, (features, arena, stats, slots, conv_table, bn_table, sizes, params)
+
+
+def _log_forward(prog, rb_objs):
     if GF.CONV_LOG is not None:
         for _, op in prog.conv_ops:
             conv, (rb, _rb_t) = prog.convs[op[5]], rb_objs[op[4]]
             GF._log(rb, conv.in_channels, conv.out_channels, "fwd")
-    o = prog.out_slot
-    out = arena[int(offs[o]):int(offs[o + 1])].view(int(slot_rows[o]), int(prog.slot_channels_np[o]))
+
+
+def _forward_impl(ctx, features, prog: NetProgram, rt, training):
+    rows, rb_table, rb_objs = rt
+    features = features.contiguous()
+    out, state = _forward_tables(features, prog, rows)
+    _call("gpn_net_forward", prog, state[3], rb_table, state[4], state[5], (1 if training else 0,), features.device)
+    _log_forward(prog, rb_objs)
     ctx.prog, ctx.rt, ctx.training = prog, rt, training
-    ctx.state = (features, arena, stats, slots, conv_table, bn_table, sizes, params)
+    ctx.state = state
     return out
 
 
-def _backward_impl(ctx, dout, fresh: bool, need_in: bool):
-    """runs gpn_net_backward; -> (din or None, flat parameter-gradient buffer, its per-parameter views, params)"""
-    prog = ctx.prog
-    rows, rb_table, rb_objs = ctx.rt
-    features, arena, stats, slots, conv_table, bn_table, sizes, params = ctx.state
+def _backward_tables(prog: NetProgram, state, dout, fresh: bool):
+    """gradient arena and the tables of one backward pass; -> (garena, slots, conv_table, bn_table, pgrad, views)"""
+    features, arena, stats, slots, conv_table, bn_table, sizes, params = state
     dev = features.device
-    dout = dout.contiguous()
     gsizes = sizes.copy()
     gsizes[0] = features.numel()
     gsizes[prog.out_slot] = 0  # the incoming gradient is used in place
@@ -419,8 +442,10 @@ def _backward_impl(ctx, dout, fresh: bool, need_in: bool):
     bn_table = bn_table.copy()
     bn_table["dweight"] = pbase + (total_w + prog.bn_off[:-1]) * 4
     bn_table["dbias"] = pbase + (total_w + total_c + prog.bn_off[:-1]) * 4
-    _call("gpn_net_backward", prog, slots, rb_table, conv_table, bn_table,
-          (1 if ctx.training else 0, 1 if need_in else 0), dev)
+    return garena, slots, conv_table, bn_table, pgrad, views
+
+
+def _log_backward(prog, rb_objs, need_in):
     if GF.CONV_LOG is not None:
         for _, op in prog.conv_ops:
             conv, (rb, rb_t) = prog.convs[op[5]], rb_objs[op[4]]
@@ -428,9 +453,39 @@ def _backward_impl(ctx, dout, fresh: bool, need_in: bool):
                 GF._log(rb_t, conv.out_channels, conv.in_channels, "dgrad")
             if conv.weight.requires_grad:
                 GF._log(rb, conv.in_channels, conv.out_channels, "wgrad")
+
+
+def _backward_impl(ctx, dout, fresh: bool, need_in: bool):
+    """runs gpn_net_backward; -> (din or None, flat parameter-gradient buffer, its per-parameter views, params)"""
+    prog = ctx.prog
+    rows, rb_table, rb_objs = ctx.rt
+    features, params = ctx.state[0], ctx.state[-1]
+    dout = dout.contiguous()
+    garena, slots, conv_table, bn_table, pgrad, views = _backward_tables(prog, ctx.state, dout, fresh)
+    _call("gpn_net_backward", prog, slots, rb_table, conv_table, bn_table,
+          (1 if ctx.training else 0, 1 if need_in else 0), features.device)
+    _log_backward(prog, rb_objs, need_in)
     din = garena[:features.numel()].view_as(features) if need_in else None
     ctx.state = None
     return din, pgrad, views, params
+
+
+def _hand_over(prog, params, views, pgrad, fresh):
+    """assign / add the parameter gradients of one network (see the contract above)"""
+    if fresh:
+        for p, g in zip(params, views):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        prog.last_pgrad = None
+    else:
+        for p, g in zip(params, views):
+            if p.requires_grad:
+                p.grad = g
+        prog.last_pgrad = pgrad  # grad_sync all-reduces this buffer in place (its slices are the parameters' .grad)
 
 
 class _NetFn(torch.autograd.Function):
@@ -455,21 +510,65 @@ class _NetFn(torch.autograd.Function):
         params = ctx.state[-1]
         fresh = any(p.grad is not None for p in params)  # accumulation into existing gradients: temporary buffer, then add
         din, pgrad, views, params = _backward_impl(ctx, dout, fresh, bool(ctx.needs_input_grad[0]))
-        if fresh:
-            for p, g in zip(params, views):
-                if not p.requires_grad:
-                    continue
-                if p.grad is None:
-                    p.grad = g
-                else:
-                    p.grad.add_(g)
-            prog.last_pgrad = None
-        else:
-            for p, g in zip(params, views):
-                if p.requires_grad:
-                    p.grad = g
-            prog.last_pgrad = pgrad  # grad_sync all-reduces this buffer in place (its slices are the parameters' .grad)
+        _hand_over(prog, params, views, pgrad, fresh)
         return din, None, None, None, None
+
+
+class _NetPairFn(torch.autograd.Function):
+    """two structurally identical programs over the same input and rulebooks as ONE differentiable op with two outputs
+    (gpn_net_forward_pair / gpn_net_backward_pair: layer i of both networks per launch).  Gradient hand-over as in _NetFn.
+    If only one output received a gradient (a loss term was absent), that network alone runs its single backward pass."""
+
+    @staticmethod
+    def forward(ctx, features, anchor, prog_a: NetProgram, prog_b: NetProgram, rt, training):
+        rows, rb_table, rb_objs = rt
+        features = features.contiguous()
+        out_a, state_a = _forward_tables(features, prog_a, rows)
+        out_b, state_b = _forward_tables(features, prog_b, rows)
+        _call_pair("gpn_net_forward_pair", prog_a, state_a[3], state_b[3], rb_table, state_a[4], state_b[4], state_a[5],
+                   state_b[5], (1 if training else 0,), features.device)
+        _log_forward(prog_a, rb_objs)
+        _log_forward(prog_b, rb_objs)
+        ctx.progs, ctx.rt, ctx.training = (prog_a, prog_b), rt, training
+        ctx.states = (state_a, state_b)
+        ctx.set_materialize_grads(False)  # an output that does not reach the loss arrives as None in backward, not as zeros
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, dout_a, dout_b):
+        rows, rb_table, rb_objs = ctx.rt
+        need_in = bool(ctx.needs_input_grad[0])
+        features = ctx.states[0][0]
+        dev = features.device
+        douts = (dout_a, dout_b)
+        live = [t for t in (0, 1) if douts[t] is not None]
+        if not live:
+            ctx.states = None
+            return None, None, None, None, None, None
+        tabs = {}
+        for t in live:
+            prog, params = ctx.progs[t], ctx.states[t][-1]
+            fresh = any(p.grad is not None for p in params)
+            tabs[t] = (fresh,) + _backward_tables(prog, ctx.states[t], douts[t].contiguous(), fresh)
+        extra = (1 if ctx.training else 0, 1 if need_in else 0)
+        if len(live) == 2:
+            (_, _, slots_a, conv_a, bn_a, _, _), (_, _, slots_b, conv_b, bn_b, _, _) = tabs[0], tabs[1]
+            _call_pair("gpn_net_backward_pair", ctx.progs[0], slots_a, slots_b, rb_table, conv_a, conv_b, bn_a, bn_b, extra, dev)
+        else:
+            for t in live:
+                _, _, slots, conv_t, bn_t, _, _ = tabs[t]
+                _call("gpn_net_backward", ctx.progs[t], slots, rb_table, conv_t, bn_t, extra, dev)
+        din = None
+        for t in live:
+            fresh, garena, _slots, _c, _b, pgrad, views = tabs[t]
+            _log_backward(ctx.progs[t], rb_objs, need_in)
+            _hand_over(ctx.progs[t], ctx.states[t][-1], views, pgrad, fresh)
+            if need_in:
+                d = garena[:features.numel()].view_as(features)
+                din = d if din is None else din.add_(d)
+        ctx.states = None
+        return din, None, None, None, None, None
+
 
 
 class _NetFnAutograd(torch.autograd.Function):
@@ -539,3 +638,36 @@ def run(unet, x):
     lvl = prog.slot_level[prog.out_slot]
     idx, shape = levels[lvl]
     return spconv.SparseConvTensor(out, idx, shape, x.batch_size, x.indice_dict)
+
+
+def run_pair(unet_a, unet_b, x):
+    """``(unet_a(x), unet_b(x))`` for two SparseUNets of the same structure in paired passes (one launch per layer for both
+    networks); None when the pair cannot run that way (different structures, a network the executor does not express, hooks
+    on parameters, the autograd-parameter form) - the caller then runs the two networks one after the other."""
+    prog_a, prog_b = program_for(unet_a), program_for(unet_b)
+    if prog_a is None or prog_b is None or prog_a is prog_b or _AUTOGRAD_PARAMS:
+        return None
+    if x.features.shape[0] == 0 or not x.features.is_cuda or x.features.dtype != torch.float32:
+        return None
+    if (prog_a.ops != prog_b.ops or prog_a.slot_channels != prog_b.slot_channels or prog_a.rb_keys != prog_b.rb_keys
+            or prog_a.level_keys != prog_b.level_keys or prog_a.python_stem_conv is not None
+            or prog_b.python_stem_conv is not None or prog_a.conv_cin != prog_b.conv_cin or prog_a.conv_cout != prog_b.conv_cout):
+        return None
+    training = prog_a.bns[0].training
+    for bn in prog_a.bns + prog_b.bns:
+        if bn.training != training:
+            return None
+    params = prog_a.params() + prog_b.params()
+    if any(_has_hooks(p) for p in params):
+        return None
+    rows, rb_table, rb_objs, levels = prog_a.rulebooks(x)
+    if int(rows.min()) < 1 or x.features.shape[1] != prog_a.slot_channels[0]:
+        return None
+    if training:
+        with torch.no_grad():
+            torch._foreach_add_(prog_a.buffers("num_batches_tracked") + prog_b.buffers("num_batches_tracked"), 1)
+    out_a, out_b = _NetPairFn.apply(x.features, prog_a._anchor, prog_a, prog_b, (rows, rb_table, rb_objs), training)
+    lvl = prog_a.slot_level[prog_a.out_slot]
+    idx, shape = levels[lvl]
+    return (spconv.SparseConvTensor(out_a, idx, shape, x.batch_size, x.indice_dict),
+            spconv.SparseConvTensor(out_b, idx, shape, x.batch_size, x.indice_dict))

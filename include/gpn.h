@@ -313,6 +313,18 @@ int gpn_net_backward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, 
                      const gpn_net_rulebook_t* rulebooks, int n_rulebooks, const gpn_net_conv_t* convs, int n_convs,
                      const gpn_net_bn_t* bns, int n_bns, int training, int need_input_grad, void* ws, size_t ws_bytes,
                      gpn_stream_t stream);
+/* Paired passes: TWO networks with the same program over the same rulebooks (the ScoreNet and NPCS-Net U-Nets of
+ * network/model.py:116-118 read the same proposal grid), layer i of both computed by ONE launch per kernel (blockIdx.y picks
+ * the network).  Each network's values are those of its own single pass.  Tables a / b: the two networks' slots, weights and
+ * BatchNorms; ops and rulebooks are shared.  Workspace: 2 x gpn_net_ws_bytes. */
+int gpn_net_forward_pair(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots_a, gpn_net_slot_t* slots_b, int n_slots,
+                         const gpn_net_rulebook_t* rulebooks, int n_rulebooks, const gpn_net_conv_t* convs_a,
+                         const gpn_net_conv_t* convs_b, int n_convs, const gpn_net_bn_t* bns_a, const gpn_net_bn_t* bns_b,
+                         int n_bns, int training, void* ws, size_t ws_bytes, gpn_stream_t stream);
+int gpn_net_backward_pair(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots_a, gpn_net_slot_t* slots_b, int n_slots,
+                          const gpn_net_rulebook_t* rulebooks, int n_rulebooks, const gpn_net_conv_t* convs_a,
+                          const gpn_net_conv_t* convs_b, int n_convs, const gpn_net_bn_t* bns_a, const gpn_net_bn_t* bns_b,
+                          int n_bns, int training, int need_input_grad, void* ws, size_t ws_bytes, gpn_stream_t stream);
 
 /* ================================================================================================
  * B — ball query.  replaces epic_ops.ball_query.ball_query (network/grouping_utils.py:119-128).

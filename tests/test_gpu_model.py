@@ -296,6 +296,62 @@ def test_native_executor_matches_per_layer_path(cuda, without_stem, training, bn
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("bn_fusion", [False, True], indirect=True)
+@pytest.mark.parametrize("one_sided", [False, True])
+def test_paired_passes_equal_one_network_after_the_other(cuda, training, bn_fusion, one_sided):
+    """net_exec.run_pair (gpn_net_forward_pair / gpn_net_backward_pair: layer i of two structurally identical U-Nets in ONE
+    launch per kernel, as ScoreNet + NPCS-Net run in the model): outputs, input gradient, every parameter gradient and every
+    buffer are BIT-equal to running the two networks one after the other (same kernels, same summation orders; the
+    BatchNorm sums are order-independent integers).  ``one_sided``: only one output reaches the loss - that network
+    alone runs backward, the other's parameters keep ``grad is None``."""
+    from gapartnet_amd.network import net_exec
+    net_a, idx, feats, spconv = _unet_case(cuda, True)
+    torch.manual_seed(11)
+    net_b = copy.deepcopy(net_a)
+    with torch.no_grad():
+        for p in net_b.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    ref_a, ref_b = copy.deepcopy(net_a), copy.deepcopy(net_b)
+    for m in (net_a, net_b, ref_a, ref_b):
+        m.train(training)
+    results = []
+    for paired in (True, False):
+        a, b = (net_a, net_b) if paired else (ref_a, ref_b)
+        f = feats.clone().requires_grad_(True)
+        x = spconv.SparseConvTensor(f, idx, [64, 64, 64], 3)
+        if paired:
+            out = net_exec.run_pair(a, b, x)
+            assert out is not None, "two copies of one architecture must pair"
+            ya, yb = out
+        else:
+            ya, yb = a(x), b(x)
+        wa = torch.linspace(-1, 1, ya.features.numel(), device=cuda).view_as(ya.features)
+        wb = torch.linspace(2, -1, yb.features.numel(), device=cuda).view_as(yb.features)
+        loss = (ya.features * wa).sum() if one_sided else (ya.features * wa).sum() + (yb.features * wb).sum()
+        loss.backward()
+        results.append((ya.features.detach(), yb.features.detach(), f.grad,
+                        {k: p.grad for k, p in a.named_parameters()}, {k: p.grad for k, p in b.named_parameters()},
+                        a.state_dict(), b.state_dict()))
+    (ya, yb, din, ga, gb, sa, sb), (ra, rb, rdin, rga, rgb, rsa, rsb) = results
+    assert torch.equal(ya, ra) and torch.equal(yb, rb)
+    assert torch.equal(din, rdin)
+    for k in rga:
+        assert ga[k] is not None and torch.equal(ga[k], rga[k]), k
+    for k in rgb:
+        if one_sided:
+            assert gb[k] is None and rgb[k] is None, k
+        else:
+            assert gb[k] is not None and torch.equal(gb[k], rgb[k]), k
+    for got, want in ((sa, rsa), (sb, rsb)):
+        for k in want:
+            assert torch.equal(got[k], want[k]), f"buffer / parameter {k} diverged"
+    # different architectures do not pair
+    other, _, _, _ = _unet_case(cuda, False)
+    assert net_exec.run_pair(net_a, other, spconv.SparseConvTensor(feats, idx, [64, 64, 64], 3)) is None
+
+
+@pytest.mark.gpu
 def test_conv_epilogue_batchnorm_sums_are_deterministic_and_used(cuda):
     """the fused form (BatchNorm sums accumulated by the producing conv launch as fixed-point integers): two runs are
     bit-identical although thousands of waves add to one channel in arbitrary order, and the profile shows no separate
