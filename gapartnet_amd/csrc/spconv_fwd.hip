@@ -366,6 +366,23 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
       orow[r] = (int32_t)(row < n_dst ? row : n_dst - 1);
     }
   }
+  // a dgrad launch carrying a BatchNorm's backward sums (bn_stats.h): that BatchNorm's x, y at this wave's output elements and
+  // the channel statistics are requested now and arrive during the contraction (read in the epilogue they were a round trip
+  // of pure latency at the end of every wave)
+  const bool st_bwd = stats.slab != nullptr && stats.x != nullptr;
+  const uint32_t col = (uint32_t)(nt * 16 + i16);
+  float bx[4] = {0.f, 0.f, 0.f, 0.f}, by[4] = {1.f, 1.f, 1.f, 1.f}, mu = 0.f, is = 1.f;
+  if (st_bwd) {
+    mu = stats.mean[col], is = stats.invstd[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (row0 + 4 * g + r < n_dst) {
+        const uint32_t e = (uint32_t)orow[r] * (uint32_t)cout + col;
+        bx[r] = stats.x[e];
+        if (stats.relu) by[r] = stats.y[e];
+      }
+    }
+  }
   // two-level summation: a tap's CB * 16 products accumulate in `part` (one MFMA chain), the taps' partial sums are
   // added to `acc` - rounding error grows with sqrt(16 CB) + sqrt(KT) terms instead of sqrt(16 CB KT) (measured against a
   // float64 evaluation: 2e-7 relative instead of 6e-7; BatchNorm on the tiny deep levels amplifies it ~1000x in backward)
@@ -403,10 +420,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
     asm volatile("" ::: "memory");
   }
   // store; BatchNorm column sums of the tile when the launch carries a slab (bn_stats.h)
-  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr, st_bwd = stats.slab != nullptr && stats.x != nullptr;
-  const uint32_t col = (uint32_t)(nt * 16 + i16);
-  float s0 = 0.f, s1 = 0.f, mu = 0.f, is = 1.f;
-  if (st_bwd) mu = stats.mean[col], is = stats.invstd[col];
+  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr;
+  float s0 = 0.f, s1 = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + 4 * g + r;
@@ -419,9 +434,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
         s0 += v;
         s1 += v * v;
       } else if (st_bwd) {
-        const float gm = (stats.relu && !(stats.y[e] > 0.f)) ? 0.f : v;
+        const float gm = (stats.relu && !(by[r] > 0.f)) ? 0.f : v;
         s0 += gm;
-        s1 += gm * ((stats.x[e] - mu) * is);
+        s1 += gm * ((bx[r] - mu) * is);
       }
     }
   }
@@ -496,6 +511,34 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
 #pragma unroll
   for (int s = 0; s < D; ++s) issue(s, s);
 
+  int32_t orow[4];
+  if (perm) {
+    const int4 pv = *reinterpret_cast<const int4*>(perm + row0 + 4 * g);
+    orow[0] = pv.x, orow[1] = pv.y, orow[2] = pv.z, orow[3] = pv.w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + 4 * g + r;
+      orow[r] = (int32_t)(row < n_dst ? row : n_dst - 1);
+    }
+  }
+  // a dgrad launch carrying a BatchNorm's backward sums (bn_stats.h): that BatchNorm's x, y at this wave's output elements and
+  // the channel statistics are requested now and arrive during the contraction (read in the epilogue they were a round trip
+  // of pure latency at the end of every wave)
+  const bool st_bwd = stats.slab != nullptr && stats.x != nullptr;
+  const uint32_t col = (uint32_t)(nt * 16 + i16);
+  float bx[4] = {0.f, 0.f, 0.f, 0.f}, by[4] = {1.f, 1.f, 1.f, 1.f}, mu = 0.f, is = 1.f;
+  if (st_bwd && part == 0 && active) {
+    mu = stats.mean[col], is = stats.invstd[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (row0 + 4 * g + r < n_dst) {
+        const uint32_t e = (uint32_t)orow[r] * (uint32_t)cout + col;
+        bx[r] = stats.x[e];
+        if (stats.relu) by[r] = stats.y[e];
+      }
+    }
+  }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -530,21 +573,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
 #pragma unroll
   for (int q = 1; q < SP; ++q) acc += red[wave + q][lane];
 
-  int32_t orow[4];
-  if (perm) {
-    const int4 pv = *reinterpret_cast<const int4*>(perm + row0 + 4 * g);
-    orow[0] = pv.x, orow[1] = pv.y, orow[2] = pv.z, orow[3] = pv.w;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = row0 + 4 * g + r;
-      orow[r] = (int32_t)(row < n_dst ? row : n_dst - 1);
-    }
-  }
-  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr, st_bwd = stats.slab != nullptr && stats.x != nullptr;
-  const uint32_t col = (uint32_t)(nt * 16 + i16);
-  float s0 = 0.f, s1 = 0.f, mu = 0.f, is = 1.f;
-  if (st_bwd) mu = stats.mean[col], is = stats.invstd[col];
+  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr;
+  float s0 = 0.f, s1 = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + 4 * g + r;
@@ -557,9 +587,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
         s0 += v;
         s1 += v * v;
       } else if (st_bwd) {
-        const float gm = (stats.relu && !(stats.y[e] > 0.f)) ? 0.f : v;
+        const float gm = (stats.relu && !(by[r] > 0.f)) ? 0.f : v;
         s0 += gm;
-        s1 += gm * ((stats.x[e] - mu) * is);
+        s1 += gm * ((bx[r] - mu) * is);
       }
     }
   }

@@ -85,6 +85,42 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed), 0, (int)packed_bytes, 0x00020000);
   const uint32_t col_bytes = (uint32_t)n_dst * 4u;
 
+  // ---- a dgrad launch that carries a BatchNorm's backward sums (bn_stats.h) needs that BatchNorm's x and y at the elements
+  // this wave will write, and the channel statistics: requested NOW, so that they arrive during the contraction - read in
+  // the epilogue they were one (perm ->) x, y round trip of pure latency at the end of every wave (4 us per launch) ----------
+  const bool st_bwd = stats.slab != nullptr && stats.x != nullptr;
+  int32_t orow[R][4];
+  float bx[R][NT][4], by[R][NT][4], bmu[NT], bis[NT];
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    const int tile = tile0 + t;
+    if (perm && tile < n_tiles) {
+      const int4 pv = *reinterpret_cast<const int4*>(perm + (int64_t)tile * 16 + 4 * g);
+      orow[t][0] = pv.x, orow[t][1] = pv.y, orow[t][2] = pv.z, orow[t][3] = pv.w;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) orow[t][r] = tile * 16 + 4 * g + r;
+    }
+  }
+  if (st_bwd) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const uint32_t col = (uint32_t)((nt0 + nt) * 16 + i16);
+      bmu[nt] = stats.mean[col], bis[nt] = stats.invstd[col];
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bx[t][nt][r] = 0.f, by[t][nt][r] = 1.f;
+          if ((int64_t)(tile0 + t) * 16 + 4 * g + r < n_dst) {
+            const uint32_t e = (uint32_t)orow[t][r] * (uint32_t)cout + col;
+            bx[t][nt][r] = stats.x[e];
+            if (stats.relu) by[t][nt][r] = stats.y[e];
+          }
+        }
+    }
+  }
+
   // ---- prologue: table column of the wave's rows, all taps; live taps; compacted offsets into the slab --------------------
   const int lr = lane % RW, lt = lane / RW;
   const int64_t pos = (int64_t)tile0 * 16 + lr;
@@ -196,28 +232,19 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
   }
 
   // ---- D[row = 4g + r][col = i16] of every (row tile, column tile) -> out; BatchNorm column sums of the tile (bn_stats.h) ----
-  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr, st_bwd = stats.slab != nullptr && stats.x != nullptr;
+  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr;
 #pragma unroll
   for (int t = 0; t < R; ++t) {
     const int tile = tile0 + t;
     if (tile < n_tiles) {
-      int32_t orow[4];
-      if (perm) {
-        const int4 pv = *reinterpret_cast<const int4*>(perm + (int64_t)tile * 16 + 4 * g);
-        orow[0] = pv.x, orow[1] = pv.y, orow[2] = pv.z, orow[3] = pv.w;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) orow[r] = tile * 16 + 4 * g + r;
-      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const uint32_t col = (uint32_t)((nt0 + nt) * 16 + i16);
-        float s0 = 0.f, s1 = 0.f, mu = 0.f, is = 1.f;
-        if (st_bwd) mu = stats.mean[col], is = stats.invstd[col];
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if ((int64_t)tile * 16 + 4 * g + r < n_dst) {
-            const uint32_t e = (uint32_t)orow[r] * (uint32_t)cout + col;
+            const uint32_t e = (uint32_t)orow[t][r] * (uint32_t)cout + col;
             float v = acc[t][nt][r];
             if (accumulate) v += out[e];  // (a second gradient of the same rows, added in place)
             out[e] = v;
@@ -225,9 +252,9 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
               s0 += v;
               s1 += v * v;
             } else if (st_bwd) {
-              const float gm = (stats.relu && !(stats.y[e] > 0.f)) ? 0.f : v;
+              const float gm = (stats.relu && !(by[t][nt][r] > 0.f)) ? 0.f : v;
               s0 += gm;
-              s1 += gm * ((stats.x[e] - mu) * is);
+              s1 += gm * ((bx[t][nt][r] - bmu[nt]) * bis[nt]);
             }
           }
         }

@@ -45,22 +45,34 @@ def wrap(owner, attr, label):
 
 
 for name in ["forward_backbone", "forward_sem_seg", "forward_offset", "proposal_clustering_and_revoxelize",
-             "forward_proposal_score", "loss_proposal_score", "forward_proposal_npcs", "loss_proposal_npcs"]:
+             "forward_proposal_unets", "forward_proposal_score", "loss_proposal_score", "forward_proposal_npcs",
+             "loss_proposal_npcs", "log"]:
     wrap(model, name, name)
 _orig_call = net_exec._call
+_orig_call_pair = net_exec._call_pair
 counter = defaultdict(int)
+CALLS_PER_STEP = {"gpn_net_forward": 1, "gpn_net_backward": 1}  # (the proposal networks run as a pair)
 
 
 def _call(fn_name, *a, **k):
     counter[fn_name] += 1
-    label = f"{fn_name[8:]} #{(counter[fn_name] - 1) % 3}"
+    label = f"  {fn_name[8:]} call {(counter[fn_name] - 1) % CALLS_PER_STEP.get(fn_name, 1)}"
     mark(label, 0)
     out = _orig_call(fn_name, *a, **k)
     mark(label, 1)
     return out
 
 
+def _call_pair(fn_name, *a, **k):
+    label = f"  {fn_name[8:]}"
+    mark(label, 0)
+    out = _orig_call_pair(fn_name, *a, **k)
+    mark(label, 1)
+    return out
+
+
 net_exec._call = _call
+net_exec._call_pair = _call_pair
 
 
 def step(i):
