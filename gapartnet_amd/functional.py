@@ -96,14 +96,22 @@ def _identity_rulebook(n: int, device):
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = x @ W^T + b as the K = 1 case of the fused conv kernels, output channels zero-padded to a multiple of 16;
-    one autograd node with three library calls (forward, dgrad, wgrad) and no autograd-visible pad / slice ops"""
+    """y = x @ W^T + b of the dense heads.  On the HIP library: its own streaming kernels (csrc/linear.hip: one launch
+    forward, three backward).  Over other raw-op backends (the oracle in the CPU tests), and for widths those kernels do not
+    take: the K = 1 case of the conv operator family, output channels zero-padded to a multiple of 16 - one autograd node
+    with three operator calls (forward, dgrad, wgrad) and no autograd-visible pad / slice ops."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ops = backend.raw()
         x = x.contiguous()
         cout, cin = weight.shape
+        ctx.native = hasattr(ops, "linear_fwd") and ops.linear_supported(cin, cout)
+        if ctx.native:
+            w = weight.detach().contiguous()
+            ctx.save_for_backward(x, w)
+            ctx.has_bias = bias is not None
+            return ops.linear_fwd(x, w, bias.detach() if bias is not None else None)
         cout_p = _pad16(cout)
         w = weight.detach()
         if cout_p != cout:
@@ -120,6 +128,9 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         ops = backend.raw()
         x, w = ctx.saved_tensors
+        if ctx.native:
+            return ops.linear_bwd(x, w, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                  ctx.has_bias and ctx.needs_input_grad[2])
         cout, cout_p = ctx.cout, w.shape[0]
         dy_p = dy.contiguous() if cout_p == cout else F.pad(dy, (0, cout_p - cout))
         dx = ops.conv_dgrad(dy_p, w, ctx.rb, ctx.rb, False, "oki") if ctx.needs_input_grad[0] else None
@@ -135,8 +146,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     K = 1 cases of the fused conv kernel family (forward, dgrad, wgrad): at [160k, 16] x [16, 3..27] the library GEMMs
     the framework dispatches to run at 0.2-0.4 TFLOP/s (fwd+bwd 260-380 us per layer vs 200-250 here).
     Falls back to F.linear for shapes the kernels do not cover."""
-    if (backend.raw().name != "hip" or not x.is_cuda or x.dim() != 2 or x.shape[1] % 16 != 0 or x.shape[0] < 16
-            or x.dtype != torch.float32):  # (small row counts too: the library GEMM costs 165 us of host time per call)
+    ops = backend.raw()
+    if ops.name != "hip" or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32 or x.shape[0] == 0:
+        return F.linear(x, weight, bias)
+    if hasattr(ops, "linear_supported") and ops.linear_supported(x.shape[1], weight.shape[0]):
+        # (any row count: the first torch GEMM of a process initialises the BLAS library - a 250 ms stall in the step where
+        # a batch first has fewer than 16 proposals, when the score head used to fall back to F.linear)
+        return _LinearFn.apply(x, weight, bias)
+    if x.shape[1] % 16 != 0 or x.shape[0] < 16:
         return F.linear(x, weight, bias)
     return _LinearFn.apply(x, weight, bias)
 

@@ -814,3 +814,36 @@ def npcs_loss_bwd(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, P, s
                                      ptr(sym["mats"]), first, count, group, n, ptr(scratch),
                                      ptr(_c(grad_loss.reshape(1), torch.float32)), ptr(d_logits), _stream()), "gpn_npcs_loss_bwd")
     return d_logits
+
+
+# ---------------------------------------------------------------------------------------------------- H (dense heads)
+def linear_supported(cin: int, cout: int) -> bool:
+    return bool(_C.lib().gpn_linear_supported(i32(cin), i32(cout)))
+
+
+def linear_fwd(x, weight, bias):
+    """y = x @ weight.T + bias in one launch (csrc/linear.hip); weight [cout, cin] as torch.nn.Linear holds it"""
+    dev = _dev(x, weight)
+    x, weight = _c(x, torch.float32), _c(weight, torch.float32)
+    N, cin = x.shape
+    cout = weight.shape[0]
+    y = torch.empty((N, cout), dtype=torch.float32, device=dev)
+    check(_C.lib().gpn_linear_fwd(ptr(x), ptr(weight), ptr(_c(bias, torch.float32) if bias is not None else None), i64(N),
+                                  i32(cin), i32(cout), ptr(y), _stream()), "gpn_linear_fwd")
+    return y
+
+
+def linear_bwd(x, weight, dy, need_dx: bool, need_dw: bool, need_db: bool):
+    """-> (dx or None, dW or None, db or None): three launches at most (dx; partial dW / db per 512 rows; their ordered sum)"""
+    dev = _dev(x, dy)
+    x, weight, dy = _c(x, torch.float32), _c(weight, torch.float32), _c(dy, torch.float32)
+    N, cin = x.shape
+    cout = weight.shape[0]
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty_like(weight) if need_dw else None
+    db = torch.empty((cout,), dtype=torch.float32, device=dev) if need_db else None
+    L = _C.lib()
+    ws = _ws(L.gpn_linear_bwd_ws_bytes(i64(N), i32(cin), i32(cout)), dev) if (need_dw or need_db) else None
+    check(L.gpn_linear_bwd(ptr(x), ptr(weight), ptr(dy), i64(N), i32(cin), i32(cout), ptr(dx), ptr(dw), ptr(db), ptr(ws),
+                           szt(ws.numel() if ws is not None else 0), _stream()), "gpn_linear_bwd")
+    return dx, dw, db

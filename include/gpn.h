@@ -38,6 +38,16 @@ int gpn_version(void);
 int gpn_num_entry_points(void);
 const char* gpn_entry_point_name(int i);
 
+/* ---- H: dense heads: y = x W^T + b on [N, cin] rows, cin % 4 == 0, cin, cout <= 64 (csrc/linear.hip) ----------------------
+ * Replaces torch.nn.functional.linear of network/model.py:140, 159-160, 322, 337 (sem_seg_head, offset_head, score_head,
+ * npcs_head) and its autograd: W [cout, cin] in torch.nn.Linear's layout, b [cout] or NULL.  One launch forward; backward
+ * writes dx [N, cin], dW [cout, cin], db [cout] (each may be NULL = skipped), deterministic (fixed-order sums). */
+int gpn_linear_supported(int cin, int cout);
+int gpn_linear_fwd(const float* x, const float* W, const float* b, int64_t N, int cin, int cout, float* y, gpn_stream_t stream);
+size_t gpn_linear_bwd_ws_bytes(int64_t N, int cin, int cout);
+int gpn_linear_bwd(const float* x, const float* W, const float* dy, int64_t N, int cin, int cout, float* dx, float* dW, float* db,
+                   void* ws, size_t ws_bytes, gpn_stream_t stream);
+
 /* ---- optional in-library kernel timing (hipEvent pairs around launches; used by bench.py) ------- */
 /* kernel ids for gpn_prof_get */
 enum {
@@ -48,7 +58,8 @@ enum {
   GPN_K_BALL_QUERY = 4,
   GPN_K_CCL = 5,
   GPN_K_BN = 6, /* BatchNorm passes (statistics where not taken by a conv epilogue, apply forward / backward) */
-  GPN_K_COUNT = 7
+  GPN_K_LINEAR = 7, /* the dense heads (section H) */
+  GPN_K_COUNT = 8
 };
 /* fixed cost of a (start event, launch, stop event) bracket, measured around an empty kernel on `stream` (median, us):
  * subtract it from hipEvent-measured launch durations before comparing them with a profiler's kernel durations. */

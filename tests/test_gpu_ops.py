@@ -521,11 +521,44 @@ def test_conv_parameter_layout_matches_canonical(H, cuda):
     assert torch.equal(H.conv_wgrad(f, g, rb).permute(2, 0, 1), H.conv_wgrad(f, g, rb, "oki"))
 
 
-@pytest.mark.parametrize("n,cin,cout", [(20000, 16, 10), (5000, 32, 27), (4096, 16, 16)])
-def test_linear_through_the_conv_kernels_matches_torch(H, cuda, n, cin, cout):
-    """GF.linear (K = 1 case of the fused conv family, output channels zero-padded to 16) vs F.linear, 1e-4"""
+@pytest.mark.parametrize("n,cin,cout", [(20000, 16, 10), (5000, 32, 27), (4096, 16, 16), (513, 16, 3), (1, 64, 64), (37, 16, 27)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_dense_heads_match_torch(H, cuda, n, cin, cout, bias):
+    """GF.linear on the library's own head kernels (csrc/linear.hip: gpn_linear_fwd / gpn_linear_bwd) vs a float64
+    F.linear: values and the three gradients at 1e-5 relative to the tensor's largest entry; two runs bit-equal (fixed-order
+    sums); outputs that are not needed are not computed"""
     import torch.nn.functional as F
     from gapartnet_amd import functional as GF
+    assert H.linear_supported(cin, cout)
+    g = torch.Generator().manual_seed(n + cout)
+    x = torch.randn(n, cin, generator=g).to(cuda).requires_grad_(True)
+    w = (torch.randn(cout, cin, generator=g) * 0.2).to(cuda).requires_grad_(True)
+    b = torch.randn(cout, generator=g).to(cuda).requires_grad_(True) if bias else None
+    dy = torch.randn(n, cout, generator=g).to(cuda)
+    leaves = [x, w] + ([b] if bias else [])
+    ref = F.linear(x.double(), w.double(), b.double() if bias else None)
+    gref = torch.autograd.grad(ref, leaves, dy.double())
+    got = GF.linear(x, w, b)
+    ggot = torch.autograd.grad(got, leaves, dy)
+
+    def close(a, r):
+        return torch.allclose(a.double(), r.double(), rtol=0, atol=1e-5 * max(1.0, float(r.abs().max())))
+    assert close(got, ref)
+    for a, r in zip(ggot, gref):
+        assert close(a, r)
+    again = torch.autograd.grad(GF.linear(x, w, b), leaves, dy)
+    assert all(torch.equal(a, c) for a, c in zip(ggot, again)), "fixed summation order"
+    dx, dw, db = H.linear_bwd(x.detach(), w.detach(), dy, False, True, False)
+    assert dx is None and db is None and torch.equal(dw, ggot[1])
+
+
+def test_linear_through_the_conv_kernels_matches_torch(H, cuda):
+    """widths the head kernels do not take (> 64) keep the K = 1 case of the fused conv family (output channels zero-padded to
+    16) vs F.linear, 1e-4"""
+    import torch.nn.functional as F
+    from gapartnet_amd import functional as GF
+    n, cin, cout = 4096, 80, 10
+    assert not H.linear_supported(cin, cout)
     g = torch.Generator().manual_seed(n + cout)
     x = torch.randn(n, cin, generator=g).to(cuda).requires_grad_(True)
     w = (torch.randn(cout, cin, generator=g) * 0.2).to(cuda).requires_grad_(True)
