@@ -275,7 +275,10 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(gpn::B
   float* __restrict__ invstd = pp.invstd;
   float* __restrict__ running_mean = pp.running_mean;
   float* __restrict__ running_var = pp.running_var;
-  __shared__ double red[2][kApplyThreads][4];
+  // (the fused form needs 8 KB for its integer fold, not the 32 KB of the partial-sum fold: 17 instead of 44 KB of LDS per
+  // workgroup - a workgroup then still finds room on a CU whose LDS the weight-gradient stream's workgroups have filled)
+  __shared__ double red[2][FIXED ? 1 : kApplyThreads][4];
+  __shared__ unsigned long long words[FIXED ? 4 : 1][FIXED ? kFoldMaxC : 1];
   __shared__ double sums[2][kFoldMaxC];
   __shared__ __attribute__((aligned(16))) float stat[4][kFoldMaxC];  // mean, 1/std, weight, bias
   constexpr int U = kApplyBatch;
@@ -297,9 +300,9 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(gpn::B
     }
   }
   if constexpr (FIXED)
-    fold_fixed<false>(static_cast<const unsigned long long*>(partial), C, blocks, reinterpret_cast<unsigned long long (*)[kFoldMaxC]>(&red[0][0][0]), sums);
+    fold_fixed<false>(static_cast<const unsigned long long*>(partial), C, blocks, reinterpret_cast<unsigned long long (*)[kFoldMaxC]>(&words[0][0]), sums);
   else
-    fold_partials(static_cast<const double*>(partial), blocks, C4, red, sums);
+    fold_partials(static_cast<const double*>(partial), blocks, C4, reinterpret_cast<double (*)[kApplyThreads][4]>(&red[0][0][0]), sums);
   for (int c = threadIdx.x; c < C; c += kApplyThreads) {
     const double m = sums[0][c] / (double)N;
     double var = sums[1][c] / (double)N - m * m;
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_bwd_fold_kernel(gpn::B
   float* __restrict__ dres = pp.dres;
   float* __restrict__ dweight = pp.dweight;
   float* __restrict__ dbias = pp.dbias;
-  __shared__ double red[2][kApplyThreads][4];
+  __shared__ double red[2][FIXED ? 1 : kApplyThreads][4];
+  __shared__ unsigned long long words[FIXED ? 4 : 1][FIXED ? kFoldMaxC : 1];
   __shared__ double sums[2][kFoldMaxC];
   __shared__ __attribute__((aligned(16))) float stat[5][kFoldMaxC];  // dbias, dweight, mean, 1/std, weight
   constexpr int U = kApplyBatch;
@@ -387,9 +391,9 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_bwd_fold_kernel(gpn::B
     }
   }
   if constexpr (FIXED)
-    fold_fixed<true>(static_cast<const unsigned long long*>(partial), C, blocks, reinterpret_cast<unsigned long long (*)[kFoldMaxC]>(&red[0][0][0]), sums);
+    fold_fixed<true>(static_cast<const unsigned long long*>(partial), C, blocks, reinterpret_cast<unsigned long long (*)[kFoldMaxC]>(&words[0][0]), sums);
   else
-    fold_partials(static_cast<const double*>(partial), blocks, C4, red, sums);
+    fold_partials(static_cast<const double*>(partial), blocks, C4, reinterpret_cast<double (*)[kApplyThreads][4]>(&red[0][0][0]), sums);
   for (int c = threadIdx.x; c < C; c += kApplyThreads) {
     const float db = (float)sums[0][c], dw = (float)sums[1][c];
     stat[0][c] = db;
