@@ -449,3 +449,67 @@ extern "C" int gpn_npcs_loss_bwd(const float* logits, int n_cls3, const float* g
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
+
+
+// ================================================================================================ score loss
+// Proposal score loss (network/model.py:348-396 of the reference: loss_proposal_score over get_gt_scores,
+// grouping_utils.py:144-156, and the class selection of model.py:560-566) in one launch:
+//   cls_p   = class of the proposal's first point (sem_labels if given, else sem_preds)
+//   l_p     = logits[p, cls_p - 1]
+//   t_p     = soft target of max_k ious[p, k]: 0 below bg, 1 above fg, iou * k + b in between (mul, then add: the reference's
+//             two roundings)
+//   loss    = mean_p ( max(l, 0) - l t + log1p(exp(-|l|)) )        (binary_cross_entropy_with_logits, mean)
+// and what the rest of the step wants from the same values: score_preds[p] = sigmoid(l_p) and d loss / d logits (zero except
+// column cls_p - 1: (sigmoid(l_p) - t_p) / P), so that backward is one multiplication by the upstream gradient.
+// As torch ops this was ~18 launches forward and ~6 backward on a few hundred elements, issued while the GPU waits for the host.
+// One workgroup; sums per thread in double, fixed-order tree: deterministic.
+namespace {
+
+__global__ __launch_bounds__(kThreads) void score_loss_kernel(const float* __restrict__ logits, int C1,
+                                                              const int64_t* __restrict__ cls64, const int32_t* __restrict__ cls32,
+                                                              const int32_t* __restrict__ offsets, const float* __restrict__ ious,
+                                                              int I, int64_t P, float fg, float bg, float k, float b,
+                                                              float* __restrict__ loss, float* __restrict__ score_preds,
+                                                              float* __restrict__ d_logits) {
+  __shared__ double scratch[4];
+  double acc = 0.0;
+  const float inv_p = 1.0f / (float)P;
+  for (int64_t p = threadIdx.x; p < P; p += kThreads) {
+    const int32_t first = offsets[p];
+    const int64_t cls = cls64 ? cls64[first] : (int64_t)cls32[first];
+    const int col = (int)(cls - 1);
+    float iou = ious[p * I];
+    for (int q = 1; q < I; ++q) iou = fmaxf(iou, ious[p * I + q]);
+    const bool is_fg = iou > fg;
+    const bool mid = !(is_fg || iou < bg);
+    const float t = mid ? __fadd_rn(__fmul_rn(iou, k), b) : (is_fg ? 1.f : 0.f);
+    for (int c = 0; c < C1; ++c) d_logits[p * C1 + c] = 0.f;
+    float l = 0.f;
+    if (col >= 0 && col < C1) l = logits[p * C1 + col];
+    const float sig = 1.0f / (1.0f + expf(-l));
+    score_preds[p] = sig;
+    acc += (double)(fmaxf(l, 0.f) - l * t + log1pf(expf(-fabsf(l))));
+    if (col >= 0 && col < C1) d_logits[p * C1 + col] = (sig - t) * inv_p;
+  }
+  const double total = block_sum(acc, scratch);
+  if (threadIdx.x == 0) loss[0] = (float)(total / (double)P);
+}
+
+}  // namespace
+
+// logits [P, C1] f32; cls_i64 / cls_i32: per proposal-point class (exactly one non-NULL); offsets [P+1] i32 (CSR of the
+// proposals); ious [P, I] f32 (gpn_instance_iou).  Outputs: loss [1], score_preds [P], d_logits [P, C1] (fully written).
+extern "C" int gpn_score_loss(const float* logits, int C1, const int64_t* cls_i64, const int32_t* cls_i32, const int32_t* offsets,
+                              const float* ious, int I, int64_t P, float fg_thresh, float bg_thresh, float* loss,
+                              float* score_preds, float* d_logits, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(P >= 1 && C1 >= 1 && I >= 1 && fg_thresh > bg_thresh);
+  GPN_CHECK_ARG(logits && offsets && ious && loss && score_preds && d_logits && ((cls_i64 != nullptr) != (cls_i32 != nullptr)));
+  // (the reference computes k and b in Python doubles and multiplies / adds float tensors by them: rounded to float here)
+  const float k = (float)(1.0 / ((double)fg_thresh - (double)bg_thresh));
+  const float b = (float)((double)bg_thresh / ((double)bg_thresh - (double)fg_thresh));
+  hipLaunchKernelGGL(score_loss_kernel, dim3(1), dim3(kThreads), 0, stream, logits, C1, cls_i64, cls_i32, offsets, ious, I, P,
+                     fg_thresh, bg_thresh, k, b, loss, score_preds, d_logits);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}

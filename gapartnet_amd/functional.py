@@ -239,6 +239,33 @@ def proposal_voxel_mean(feats, built) -> torch.Tensor:
                                       built["member_slot"], built["pc_voxel_id"], built["V"])
 
 
+class _ScoreLossFn(torch.autograd.Function):
+    """proposal score loss (model.py:348-396 of the reference with the class selection of :560-566) as one launch; backward is
+    one multiplication.  -> (loss 0-dim, score_preds [P] without a gradient)"""
+
+    @staticmethod
+    def forward(ctx, logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh):
+        loss, preds, d_logits = backend.raw().score_loss(logits.contiguous(), cls_source, proposal_offsets, ious, fg_thresh,
+                                                         bg_thresh)
+        ctx.save_for_backward(d_logits)
+        ctx.mark_non_differentiable(preds)
+        return loss.reshape(()), preds
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_preds):
+        (d_logits,) = ctx.saved_tensors
+        return d_logits * grad_loss, None, None, None, None, None
+
+
+def score_loss_available(logits: torch.Tensor) -> bool:
+    return (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.shape[0] > 0
+            and hasattr(backend.raw(), "score_loss"))
+
+
+def score_loss(logits, cls_source, proposal_offsets, ious, fg_thresh: float = 0.75, bg_thresh: float = 0.25):
+    return _ScoreLossFn.apply(logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh)
+
+
 class _NpcsLossFn(torch.autograd.Function):
     """symmetry-aware NPCS loss of all proposals (model.py:398-462): two launches forward, one backward"""
 

@@ -847,3 +847,21 @@ def linear_bwd(x, weight, dy, need_dx: bool, need_dw: bool, need_db: bool):
     check(L.gpn_linear_bwd(ptr(x), ptr(weight), ptr(dy), i64(N), i32(cin), i32(cout), ptr(dx), ptr(dw), ptr(db), ptr(ws),
                            szt(ws.numel() if ws is not None else 0), _stream()), "gpn_linear_bwd")
     return dx, dw, db
+
+
+def score_loss(logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh):
+    """-> (loss [1] f32, score_preds [P] f32, d_logits [P, C1] f32) in one launch (gpn_score_loss)"""
+    dev = _dev(logits, ious)
+    logits, ious = _c(logits, torch.float32), _c(ious, torch.float32)
+    po = _c(proposal_offsets, torch.int32)
+    cls_source = cls_source.contiguous()
+    assert cls_source.dtype in (torch.int64, torch.int32)
+    P, C1 = logits.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    preds = torch.empty((P,), dtype=torch.float32, device=dev)
+    d_logits = torch.empty_like(logits)
+    is64 = cls_source.dtype == torch.int64
+    check(_C.lib().gpn_score_loss(ptr(logits), i32(C1), ptr(cls_source if is64 else None), ptr(None if is64 else cls_source),
+                                  ptr(po), ptr(ious), i32(ious.shape[1]), i64(P), f32(fg_thresh), f32(bg_thresh), ptr(loss),
+                                  ptr(preds), ptr(d_logits), _stream()), "gpn_score_loss")
+    return loss, preds, d_logits

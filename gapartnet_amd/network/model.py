@@ -480,14 +480,24 @@ class GAPartNet(LightningModule):
         loss_prop_score = 0.0
         if self.current_epoch >= self.start_scorenet and voxel_tensor is not None and proposals is not None:
             score_logits = self.forward_proposal_score(voxel_tensor, pc_voxel_id, proposals, score_feats)
-            first_point = proposals.proposal_offsets[:-1].long()
             cls_source = proposals.sem_labels if proposals.sem_labels is not None else proposals.sem_preds
-            proposal_cls = cls_source[first_point].long()
-            score_logits = score_logits.gather(1, proposal_cls[:, None] - 1).squeeze(1)
-            proposals.score_preds = score_logits.detach().sigmoid()
             if num_points_per_instance is None:
                 raise RuntimeError("batch carries no num_points_per_instance (reference: pdb, model.py:567)")
-            loss_prop_score = self.loss_proposal_score(score_logits, proposals, num_points_per_instance)
+            if GF.score_loss_available(score_logits):
+                # class selection, soft IoU targets, BCE and the sigmoid scores in one launch (csrc/losses.hip); the torch
+                # formulation below is what runs over other operator backends and what the kernel is tested against
+                ious = batch_instance_seg_iou(proposals.proposal_offsets, proposals.instance_labels, proposals.batch_indices,
+                                              num_points_per_instance)
+                proposals.ious = ious
+                proposals.num_points_per_instance = num_points_per_instance
+                loss_prop_score, proposals.score_preds = GF.score_loss(score_logits, cls_source, proposals.proposal_offsets, ious,
+                                                                       0.75, 0.25)
+            else:
+                first_point = proposals.proposal_offsets[:-1].long()
+                proposal_cls = cls_source[first_point].long()
+                score_logits = score_logits.gather(1, proposal_cls[:, None] - 1).squeeze(1)
+                proposals.score_preds = score_logits.detach().sigmoid()
+                loss_prop_score = self.loss_proposal_score(score_logits, proposals, num_points_per_instance)
 
         loss_prop_npcs = 0.0
         if self.current_epoch >= self.start_npcs and voxel_tensor is not None:

@@ -451,6 +451,14 @@ int gpn_point_losses_bwd(const float* logits, const int64_t* labels, const float
                          const int32_t* instance_labels, int64_t M, int C, int64_t ignore_index, const void* stats,
                          const float* grad_losses, float* d_logits, float* d_offsets, gpn_stream_t stream);
 
+/* Proposal score loss in one launch: class selection (model.py:560-566 of the reference), get_gt_scores
+ * (grouping_utils.py:144-156) on the row maxima of ious, binary_cross_entropy_with_logits (mean), plus sigmoid scores and
+ * d loss / d logits.  logits [P, C1]; cls_i64 / cls_i32 [M]: class of every proposal point (exactly one non-NULL); offsets
+ * [P+1] i32; ious [P, I] (gpn_instance_iou).  Outputs: loss [1], score_preds [P], d_logits [P, C1]. */
+int gpn_score_loss(const float* logits, int C1, const int64_t* cls_i64, const int32_t* cls_i32, const int32_t* offsets,
+                   const float* ious, int I, int64_t P, float fg_thresh, float bg_thresh, float* loss, float* score_preds,
+                   float* d_logits, gpn_stream_t stream);
+
 /* NPCS loss of all proposals in two launches (+ one backward): network/model.py:398-462 with compute_npcs_loss
  * (network/grouping_utils.py:14-43).  logits [M, n_cls3 = 3 (classes - 1)], gt_npcs [M,3], sem_preds [M] i32 (one class per
  * proposal point), sem_labels [M] i64, proposal_offsets [P+1] i32 / proposal_indices [M] i64 (CSR of the proposals),

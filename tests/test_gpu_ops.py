@@ -552,6 +552,37 @@ def test_dense_heads_match_torch(H, cuda, n, cin, cout, bias):
     assert dx is None and db is None and torch.equal(dw, ggot[1])
 
 
+@pytest.mark.parametrize("P,I,labels64", [(300, 40, True), (7, 3, False), (1, 1, True), (2000, 64, False)])
+def test_fused_score_loss_matches_the_torch_formulation(H, cuda, P, I, labels64):
+    """gpn_score_loss (class selection, get_gt_scores on the row maxima of the IoU matrix, BCE-with-logits mean, sigmoid scores,
+    gradient) vs the reference's chain of torch ops (model.py:560-566, 373-383; grouping_utils.py:144-156): targets are the
+    same floats (mul then add), loss / scores / gradient at 1e-6"""
+    import torch.nn.functional as F
+    from gapartnet_amd import functional as GF
+    from gapartnet_amd.network.grouping_utils import get_gt_scores
+    g = torch.Generator().manual_seed(P + I)
+    C1 = 9
+    sizes = torch.randint(1, 50, (P,), generator=g)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)]).to(torch.int32).to(cuda)
+    M = int(sizes.sum())
+    cls = torch.randint(1, C1 + 1, (M,), generator=g).to(torch.int64 if labels64 else torch.int32).to(cuda)
+    ious = torch.rand(P, I, generator=g).to(cuda)
+    ious[::3] *= 0.2          # rows entirely below the background threshold
+    ious[1::3, 0] = 0.9       # rows above the foreground threshold
+    logits = (torch.randn(P, C1, generator=g) * 3).to(cuda).requires_grad_(True)
+    sel = logits.gather(1, cls[offsets[:-1].long()].long()[:, None] - 1).squeeze(1)
+    want = F.binary_cross_entropy_with_logits(sel, get_gt_scores(ious.max(-1)[0], 0.75, 0.25))
+    (gw,) = torch.autograd.grad(want * 1.7, logits)
+    assert GF.score_loss_available(logits)
+    got, preds = GF.score_loss(logits, cls, offsets, ious, 0.75, 0.25)
+    (gg,) = torch.autograd.grad(got * 1.7, logits)
+    assert got.shape == want.shape and abs(float(got) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
+    assert torch.allclose(preds, sel.detach().sigmoid(), rtol=0, atol=1e-6) and not preds.requires_grad
+    assert torch.allclose(gg, gw, rtol=0, atol=1e-6 * max(1.0, float(gw.abs().max())))
+    again, _ = GF.score_loss(logits, cls, offsets, ious, 0.75, 0.25)
+    assert torch.equal(again, got)
+
+
 def test_linear_through_the_conv_kernels_matches_torch(H, cuda):
     """widths the head kernels do not take (> 64) keep the K = 1 case of the fused conv family (output channels zero-padded to
     16) vs F.linear, 1e-4"""
