@@ -12,6 +12,9 @@ def c(n):
     if 'wgrad' in n: return 'wgrad (+reduce)'
     if 'bn_' in n: return 'batchnorm'
     if any(k in n for k in ('reduce_partials', 'accumulate_kernel', 'concat_kernel', 'split_kernel', 'pack_')): return 'executor misc'
+    if 'linear_' in n: return 'dense heads'
+    if 'adam_kernel' in n: return 'optimizer'
+    if any(k in n for k in ('prop_', 'point_losses', 'npcs_loss', 'score_loss', 'gather_rows', 'scatter_rows', 'segmented_', 'instance_iou', 'nms_')): return 'proposal stage / losses / gather'
     if 'ball_query' in n or 'bq_' in n: return 'ball query'
     if 'ccl_' in n: return 'ccl'
     if 'rocprim' in n or 'radix' in n.lower() or 'sort' in n.lower(): return 'sort/scan (rocprim, torch)'
