@@ -65,6 +65,7 @@ __global__ void subm3_lookup_kernel(const int32_t* __restrict__ indices, int64_t
                                     uint64_t mask, int32_t* __restrict__ table) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 27 * N) return;
+  if (t == 0) table[27 * N] = -1;  // sentinel entry behind the table (the compaction scan runs over 27 N + 1 entries)
   const int k = (int)(t / N);
   const int64_t o = t - (int64_t)k * N;
   const int4 c = reinterpret_cast<const int4*>(indices)[o];
@@ -111,9 +112,10 @@ __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) p[t] = v;
 }
-__global__ void fill_u64_kernel(uint64_t* p, int64_t n, uint64_t v) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) p[t] = v;
+__global__ void fill_two_i32_kernel(int32_t* a, int64_t na, int32_t* b, int64_t nb, int32_t v) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < na) a[t] = v;
+  else if (t < na + nb) b[t - na] = v;
 }
 
 size_t scan_temp_bytes(int64_t n) {
@@ -415,16 +417,15 @@ extern "C" int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32
   GPN_CHECK_WS(w);
 
   gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 16.0 * (double)N + 8.0 * 27.0 * (double)N);
-  hipLaunchKernelGGL(fill_u64_kernel, dim3((int)gpn::cdiv((int64_t)cap, kThreads)), dim3(kThreads), 0, stream,
-                     hkeys, (int64_t)cap, kEmpty);
-  GPN_CHECK_HIP(hipMemsetAsync(hvals, 0xff, sizeof(int32_t) * cap, stream));  // -1
+  // empty keys (kEmpty = all ones) and values (-1) in ONE fill: the two arrays are adjacent in the workspace
+  static_assert(kEmpty == ~0ull, "the key / value tables are initialised by one byte fill");
+  GPN_CHECK_HIP(hipMemsetAsync(hkeys, 0xff, (size_t)(reinterpret_cast<char*>(hvals + cap) - reinterpret_cast<char*>(hkeys)), stream));
   hipLaunchKernelGGL(hash_insert_kernel, dim3((int)gpn::cdiv(N, kThreads)), dim3(kThreads), 0, stream, indices,
                      N, s0, s1, s2, hkeys, hvals, cap - 1);
   GPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(subm3_lookup_kernel, dim3((int)gpn::cdiv(27 * N, kThreads)), dim3(kThreads), 0, stream,
-                     indices, N, s0, s1, s2, hkeys, hvals, cap - 1, table);
+                     indices, N, s0, s1, s2, hkeys, hvals, cap - 1, table);  // (also writes the -1 sentinel table[27 N])
   GPN_CHECK_LAUNCH();
-  GPN_CHECK_HIP(hipMemsetAsync(table + 27 * N, 0xff, sizeof(int32_t), stream));
   return lists_from_table(table, pos, 27, N, pair_src, pair_dst, tile_off, num_pairs, prim_tmp, prim_bytes,
                           stream);
 }
@@ -625,8 +626,11 @@ extern "C" int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int3
   void* prim_tmp = w.take<char>(prim_bytes);
   GPN_CHECK_WS(w);
   gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 8.0 * (double)N + 16.0 * (double)N);
-  GPN_CHECK_HIP(hipMemsetAsync(tf, 0xff, sizeof(int32_t) * (8 * (size_t)n_out + 1), stream));
-  GPN_CHECK_HIP(hipMemsetAsync(tb, 0xff, sizeof(int32_t) * (8 * (size_t)N + 1), stream));
+  {  // both tables to -1 in one launch (they are separate caller-owned outputs: two memsets otherwise)
+    const int64_t nf = 8 * n_out + 1, nb = 8 * N + 1;
+    hipLaunchKernelGGL(fill_two_i32_kernel, dim3((int)gpn::cdiv(nf + nb, kThreads)), dim3(kThreads), 0, stream, tf, nf, tb, nb, -1);
+    GPN_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(down_scatter_tables_kernel, dim3((int)gpn::cdiv(N, kThreads)), dim3(kThreads), 0, stream,
                      fine_to_coarse, tap, N, n_out, tf, tb);
   GPN_CHECK_LAUNCH();

@@ -107,11 +107,17 @@ class PointCloud:
         if first.num_instances is not None:
             num_instances = [int(pc.num_instances) for pc in point_clouds]
             width = max(num_instances)
+            # [scenes, width] tables from the per-scene vectors: one scatter through host-computed flat positions per table
+            # (a row-slice copy per scene was 2 launches per scene)
             num_points_per_instance = torch.zeros((n_scenes, width), dtype=torch.int32, device=device)
             instance_sem_labels = torch.full((n_scenes, width), -1, dtype=torch.int32, device=device)
-            for row, pc in enumerate(point_clouds):
-                num_points_per_instance[row, :pc.num_instances] = pc.num_points_per_instance
-                instance_sem_labels[row, :pc.num_instances] = pc.instance_sem_labels
+            if sum(num_instances) > 0:
+                flat = np.concatenate([row * width + np.arange(n, dtype=np.int64) for row, n in enumerate(num_instances)])
+                flat = torch.from_numpy(flat).to(device, non_blocking=True)
+                num_points_per_instance.view(-1)[flat] = torch.cat([pc.num_points_per_instance.to(torch.int32).reshape(-1)
+                                                                    for pc in point_clouds])
+                instance_sem_labels.view(-1)[flat] = torch.cat([pc.instance_sem_labels.to(torch.int32).reshape(-1)
+                                                                for pc in point_clouds])
 
         csr = None
         if first.voxel_coords is not None:

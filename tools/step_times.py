@@ -46,4 +46,7 @@ print(f"median step (after 20): {med:.2f} ms")
 for i, d in enumerate(dt):
     if i >= 5 and d > 1.8 * med:
         print(f"  step {i}: {d:.1f} ms")
+for a, b in ((5, 10), (10, 20), (20, 30), (30, 50), (50, 80), (80, 120), (120, 200), (200, 300)):
+    if b <= len(dt):
+        print(f"  steps {a:3d}-{b:3d}: mean {sum(dt[a:b]) / (b - a):6.2f} ms")
 print("memory reserved MiB:", torch.cuda.memory_reserved() >> 20, "allocated:", torch.cuda.memory_allocated() >> 20)
