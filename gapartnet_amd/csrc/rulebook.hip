@@ -447,18 +447,60 @@ __global__ void tile_order_keys_kernel(const int32_t* __restrict__ nbr, int K, i
   vals[j] = (int32_t)j;
 }
 
-__global__ void tile_order_gather_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ perm, int K,
-                                         int64_t n, int32_t* __restrict__ nbr_p) {
+__global__ void tile_order_gather_kernel(const int32_t* __restrict__ nbr, int32_t* __restrict__ perm, int K,
+                                         int64_t n, int64_t padded, int32_t* __restrict__ nbr_p) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < padded - n) perm[n + t] = (int32_t)(n - 1);  // positions past the last row (a partial tile + one spare tile)
+  if (t == 0) nbr_p[(int64_t)K * n] = -1;              // sentinel entry behind the table
   if (t >= (int64_t)K * n) return;
   const int64_t k = t / n, j = t - k * n;
   nbr_p[t] = nbr[k * n + perm[j]];
 }
 
-__global__ void tile_order_pad_kernel(int32_t* __restrict__ perm, int64_t n, int64_t padded) {
-  const int64_t j = n + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < padded) perm[j] = (int32_t)(n - 1);
+// The order is per block of block_rows rows, so a workgroup can sort a block entirely in LDS: mask of its rows (K strided
+// table reads per row), rocPRIM's block radix sort over the K mask bits with the row index as value (LSD radix: stable, so
+// equal masks keep ascending row order - the same permutation the device-wide sort of (block, mask) keys gives), perm out.
+// One launch instead of the key kernel + ~14 launches of a device-wide sort (4 rulebooks per batch take a tile order).
+template <int BS, int IPT>
+__global__ __launch_bounds__(BS) void tile_order_block_sort_kernel(const int32_t* __restrict__ nbr, int K, int64_t n,
+                                                                   int32_t* __restrict__ perm) {
+  using sort_t = rocprim::block_radix_sort<uint32_t, BS, IPT, uint32_t>;
+  extern __shared__ __attribute__((aligned(16))) char tile_order_smem[];
+  typename sort_t::storage_type& storage = *reinterpret_cast<typename sort_t::storage_type*>(tile_order_smem);
+  const int64_t base = (int64_t)blockIdx.x * (BS * IPT) + (int64_t)threadIdx.x * IPT;
+  uint32_t keys[IPT], vals[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) keys[i] = 0u;
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int64_t j = base + i;
+      if (j < n) keys[i] |= (nbr[(int64_t)k * n + j] >= 0 ? 1u : 0u) << k;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int64_t j = base + i;
+    vals[i] = (uint32_t)(j < n ? j : n - 1);
+    if (j >= n) keys[i] = 0xffffffffu;  // past the end: behind every real row of the (last) block
+  }
+  sort_t().sort(keys, vals, storage, 0, K < 32 ? K : 32);
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int64_t j = base + i;
+    if (j < n) perm[j] = (int32_t)vals[i];
+  }
 }
+
+template <int BS, int IPT>
+int launch_tile_order_block_sort(const int32_t* nbr, int K, int64_t n, int32_t* perm, hipStream_t stream) {
+  using sort_t = rocprim::block_radix_sort<uint32_t, BS, IPT, uint32_t>;
+  hipLaunchKernelGGL((tile_order_block_sort_kernel<BS, IPT>), dim3((unsigned)gpn::cdiv(n, (int64_t)BS * IPT)), dim3(BS),
+                     sizeof(typename sort_t::storage_type), stream, nbr, K, n, perm);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
 
 extern "C" size_t gpn_rulebook_tile_order_ws_bytes(int64_t n) {
   gpn::WsCarver w(nullptr, 0);
@@ -484,22 +526,25 @@ extern "C" int gpn_rulebook_tile_order(const int32_t* nbr, int K, int64_t n, int
   size_t prim_bytes = sort_temp_bytes(n);
   void* prim_tmp = w.take<char>(prim_bytes);
   GPN_CHECK_WS(w);
-  const int grid = (int)gpn::cdiv(n, kThreads);
-  hipLaunchKernelGGL(tile_order_keys_kernel, dim3(grid), dim3(kThreads), 0, stream, nbr, K, n, block_shift, keys, vals);
-  GPN_CHECK_LAUNCH();
-  // key = (block << 32) | mask: only K mask bits and the block bits carry information (5 radix passes instead of 8)
-  int block_bits = 1;
-  while (((int64_t)1 << block_bits) <= ((n - 1) >> block_shift)) ++block_bits;
-  GPN_CHECK_HIP(rocprim::radix_sort_pairs(prim_tmp, prim_bytes, keys, keys_sorted, vals, perm, (size_t)n, 0,
-                                          (unsigned)(32 + block_bits), stream));
+  if (block_rows == 16384 || block_rows == 8192 || block_rows == 4096) {  // a block fits one workgroup's LDS: one launch
+    const int rc = block_rows == 16384 ? launch_tile_order_block_sort<1024, 16>(nbr, K, n, perm, stream)
+                   : block_rows == 8192 ? launch_tile_order_block_sort<512, 16>(nbr, K, n, perm, stream)
+                                        : launch_tile_order_block_sort<256, 16>(nbr, K, n, perm, stream);
+    if (rc != GPN_OK) return rc;
+  } else {
+    const int grid = (int)gpn::cdiv(n, kThreads);
+    hipLaunchKernelGGL(tile_order_keys_kernel, dim3(grid), dim3(kThreads), 0, stream, nbr, K, n, block_shift, keys, vals);
+    GPN_CHECK_LAUNCH();
+    // key = (block << 32) | mask: only K mask bits and the block bits carry information (5 radix passes instead of 8)
+    int block_bits = 1;
+    while (((int64_t)1 << block_bits) <= ((n - 1) >> block_shift)) ++block_bits;
+    GPN_CHECK_HIP(rocprim::radix_sort_pairs(prim_tmp, prim_bytes, keys, keys_sorted, vals, perm, (size_t)n, 0,
+                                            (unsigned)(32 + block_bits), stream));
+  }
   const int64_t padded = gpn::cdiv(n, 16) * 16 + 16;
-  hipLaunchKernelGGL(tile_order_pad_kernel, dim3((int)gpn::cdiv(padded - n, kThreads)), dim3(kThreads), 0, stream, perm, n,
-                     padded);
-  GPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(tile_order_gather_kernel, dim3((int)gpn::cdiv((int64_t)K * n, kThreads)), dim3(kThreads), 0, stream,
-                     nbr, perm, K, n, nbr_p);
+                     nbr, perm, K, n, padded, nbr_p);  // (also pads perm and writes the table's -1 sentinel)
   GPN_CHECK_LAUNCH();
-  GPN_CHECK_HIP(hipMemsetAsync(nbr_p + (int64_t)K * n, 0xff, sizeof(int32_t), stream));
   return GPN_OK;
 }
 

@@ -637,6 +637,37 @@ def test_grid_ball_query_is_bit_exact(H, cuda, case):
         assert (ref_cnt == K).mean() > 0.5, "the dense case must exercise truncation"
 
 
+@pytest.mark.parametrize("block", [16384, 8192, 4096, 1024])
+def test_tile_order_is_the_stable_sort_by_neighbour_mask(H, cuda, block):
+    """gpn_rulebook_tile_order: inside every block of `block` rows the rows are ordered by their K-bit neighbour mask, equal
+    masks in ascending row order (blocks of 4096 / 8192 / 16384 rows are sorted in one workgroup's LDS, other sizes by the
+    device-wide sort: same permutation); perm is padded with the last row, the permuted table ends in the -1 sentinel"""
+    import ctypes
+    from gapartnet_amd import _C
+    rng = np.random.default_rng(block)
+    shape = [96, 96, 96]
+    idx = dev(synth.surface_indices(rng, 3, shape, 7000), cuda)
+    n = idx.shape[0]
+    assert n % 16 != 0 or True
+    rb = H.rulebook_subm3(idx, shape)
+    K = 27
+    perm = torch.empty(((n + 15) // 16 * 16 + 16,), dtype=torch.int32, device=cuda)
+    nbr_p = torch.empty((K * n + 1,), dtype=torch.int32, device=cuda)
+    L = _C.lib()
+    ws = torch.empty((int(L.gpn_rulebook_tile_order_ws_bytes(H.i64(n))),), dtype=torch.uint8, device=cuda)
+    rc = L.gpn_rulebook_tile_order(H.ptr(rb.nbr), H.i32(K), H.i64(n), H.i32(block), H.ptr(perm), H.ptr(nbr_p), H.ptr(ws),
+                                   H.szt(ws.numel()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.gpn_last_error()
+    table = host(rb.nbr[:K * n].view(K, n))
+    mask = np.zeros(n, np.int64)
+    for k in range(K):
+        mask |= (table[k] >= 0).astype(np.int64) << k
+    want = np.lexsort((np.arange(n), mask, np.arange(n) // block))  # by block, then mask, then row (stable)
+    assert np.array_equal(host(perm[:n]), want)
+    assert np.all(host(perm[n:]) == n - 1)
+    assert np.array_equal(host(nbr_p[:K * n].view(K, n)), table[:, want]) and int(nbr_p[K * n]) == -1
+
+
 def test_tile_ordered_conv_is_bit_equal(H, cuda):
     """the rulebook's tile order (rows sorted by neighbour mask inside 16384-row blocks) changes which taps a tile skips,
     not a single output bit: forward and dgrad through (nbr_p, perm) == through the plain table"""
