@@ -460,29 +460,25 @@ __global__ void tile_order_gather_kernel(const int32_t* __restrict__ nbr, int32_
 // The order is per block of block_rows rows, so a workgroup can sort a block entirely in LDS: mask of its rows (K strided
 // table reads per row), rocPRIM's block radix sort over the K mask bits with the row index as value (LSD radix: stable, so
 // equal masks keep ascending row order - the same permutation the device-wide sort of (block, mask) keys gives), perm out.
-// One launch instead of the key kernel + ~14 launches of a device-wide sort (4 rulebooks per batch take a tile order).
+// Two launches (masks by the whole chip, sort by one workgroup per block) instead of the key kernel + ~14 launches of a
+// device-wide sort (4 rulebooks per batch take a tile order).  The masks are NOT computed inside the sort kernel: nine
+// workgroups reading the 16 MB table of level 0 took 250 us.
+#ifndef GPN_TILE_ORDER_RADIX_BITS
+#define GPN_TILE_ORDER_RADIX_BITS 8  // digit width of the block sort: 27 mask bits = 4 passes (rocPRIM's default of 4 bits: 7)
+#endif
 template <int BS, int IPT>
-__global__ __launch_bounds__(BS) void tile_order_block_sort_kernel(const int32_t* __restrict__ nbr, int K, int64_t n,
+__global__ __launch_bounds__(BS) void tile_order_block_sort_kernel(const uint32_t* __restrict__ mask, int K, int64_t n,
                                                                    int32_t* __restrict__ perm) {
-  using sort_t = rocprim::block_radix_sort<uint32_t, BS, IPT, uint32_t>;
+  using sort_t = rocprim::block_radix_sort<uint32_t, BS, IPT, uint32_t, 1, 1, GPN_TILE_ORDER_RADIX_BITS>;
   extern __shared__ __attribute__((aligned(16))) char tile_order_smem[];
   typename sort_t::storage_type& storage = *reinterpret_cast<typename sort_t::storage_type*>(tile_order_smem);
   const int64_t base = (int64_t)blockIdx.x * (BS * IPT) + (int64_t)threadIdx.x * IPT;
   uint32_t keys[IPT], vals[IPT];
 #pragma unroll
-  for (int i = 0; i < IPT; ++i) keys[i] = 0u;
-  for (int k = 0; k < K; ++k) {
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      const int64_t j = base + i;
-      if (j < n) keys[i] |= (nbr[(int64_t)k * n + j] >= 0 ? 1u : 0u) << k;
-    }
-  }
-#pragma unroll
   for (int i = 0; i < IPT; ++i) {
     const int64_t j = base + i;
+    keys[i] = j < n ? mask[j] : 0xffffffffu;  // past the end: behind every real row of the (last) block
     vals[i] = (uint32_t)(j < n ? j : n - 1);
-    if (j >= n) keys[i] = 0xffffffffu;  // past the end: behind every real row of the (last) block
   }
   sort_t().sort(keys, vals, storage, 0, K < 32 ? K : 32);
 #pragma unroll
@@ -492,15 +488,23 @@ __global__ __launch_bounds__(BS) void tile_order_block_sort_kernel(const int32_t
   }
 }
 
+// the K-bit neighbour mask of every row (whole-chip launch: the table is 4 K n bytes, read coalesced per tap)
+__global__ void tile_order_mask_kernel(const int32_t* __restrict__ nbr, int K, int64_t n, uint32_t* __restrict__ mask) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint32_t m = 0;
+  for (int k = 0; k < K; ++k) m |= (nbr[(int64_t)k * n + j] >= 0 ? 1u : 0u) << k;
+  mask[j] = m;
+}
+
 template <int BS, int IPT>
-int launch_tile_order_block_sort(const int32_t* nbr, int K, int64_t n, int32_t* perm, hipStream_t stream) {
-  using sort_t = rocprim::block_radix_sort<uint32_t, BS, IPT, uint32_t>;
+int launch_tile_order_block_sort(const uint32_t* mask, int K, int64_t n, int32_t* perm, hipStream_t stream) {
+  using sort_t = rocprim::block_radix_sort<uint32_t, BS, IPT, uint32_t, 1, 1, GPN_TILE_ORDER_RADIX_BITS>;
   hipLaunchKernelGGL((tile_order_block_sort_kernel<BS, IPT>), dim3((unsigned)gpn::cdiv(n, (int64_t)BS * IPT)), dim3(BS),
-                     sizeof(typename sort_t::storage_type), stream, nbr, K, n, perm);
+                     sizeof(typename sort_t::storage_type), stream, mask, K, n, perm);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
-
 
 extern "C" size_t gpn_rulebook_tile_order_ws_bytes(int64_t n) {
   gpn::WsCarver w(nullptr, 0);
@@ -527,9 +531,12 @@ extern "C" int gpn_rulebook_tile_order(const int32_t* nbr, int K, int64_t n, int
   void* prim_tmp = w.take<char>(prim_bytes);
   GPN_CHECK_WS(w);
   if (block_rows == 16384 || block_rows == 8192 || block_rows == 4096) {  // a block fits one workgroup's LDS: one launch
-    const int rc = block_rows == 16384 ? launch_tile_order_block_sort<1024, 16>(nbr, K, n, perm, stream)
-                   : block_rows == 8192 ? launch_tile_order_block_sort<512, 16>(nbr, K, n, perm, stream)
-                                        : launch_tile_order_block_sort<256, 16>(nbr, K, n, perm, stream);
+    uint32_t* mask = reinterpret_cast<uint32_t*>(vals);
+    hipLaunchKernelGGL(tile_order_mask_kernel, dim3((int)gpn::cdiv(n, kThreads)), dim3(kThreads), 0, stream, nbr, K, n, mask);
+    GPN_CHECK_LAUNCH();
+    const int rc = block_rows == 16384 ? launch_tile_order_block_sort<1024, 16>(mask, K, n, perm, stream)
+                   : block_rows == 8192 ? launch_tile_order_block_sort<512, 16>(mask, K, n, perm, stream)
+                                        : launch_tile_order_block_sort<256, 16>(mask, K, n, perm, stream);
     if (rc != GPN_OK) return rc;
   } else {
     const int grid = (int)gpn::cdiv(n, kThreads);
