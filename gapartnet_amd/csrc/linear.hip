@@ -14,7 +14,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxC = 64;        // cin, cout <= 64
 constexpr int kRowsPerWg = 512;  // rows a workgroup of the dW pass reduces
-constexpr int kTileRows = 32;
+constexpr int kTileRows = 128;
 
 // thread = (row, j): outputs 4j .. 4j + 3 of that row.  W^T is staged in LDS ([ci][cout padded to 4]: the four outputs of a
 // thread are one 16-byte LDS read per ci); the threads of a row read the same x row (one L1 line, broadcast)
@@ -88,49 +88,92 @@ __global__ __launch_bounds__(kThreads) void linear_dx_kernel(const float* __rest
 }
 
 // partial[wg][o][ci] = sum over the workgroup's rows of dy[row, o] x[row, ci];  partial[wg][cout * cin + o] = sum of dy[row, o].
-// Rows go through LDS in tiles of kTileRows (coalesced loads); thread (o, c) owns four adjacent ci of one o.
+// Rows go through LDS in tiles of 128 rows (64 for the widest layers: 64 KB of dynamic LDS at most) (coalesced loads; dynamic LDS sized to the layer: a 32-row tile made the kernel a
+// chain of 16 load round trips per workgroup, 36 us per layer); thread (o, c) owns four adjacent ci of one o.
 __global__ __launch_bounds__(kThreads) void linear_dw_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                     int64_t N, int cin, int cout, float* __restrict__ partial) {
-  __shared__ __attribute__((aligned(16))) float xs[kTileRows][kMaxC];
-  __shared__ float gs[kTileRows][kMaxC + 1];
+                                                                     int64_t N, int cin, int cout, int tile_rows,
+                                                                     float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float lin_smem[];
+  float* xs = lin_smem;                       // [tile_rows][cin]
+  const int gp = cout + 1;                    // (odd pitch: the o-th column of consecutive rows in different banks)
+  float* gs = lin_smem + tile_rows * cin;     // [tile_rows][cout + 1]
   const int C4 = cin >> 2;
   const int owners = cout * C4;  // (o, c) pairs; a thread takes pairs t, t + 256, ... (<= 4 of them at 64 x 64)
+  // the heads have 12-108 pairs: G = 256 / owners row groups share a tile's rows (group g takes rows g, g + G, ...) and are
+  // summed in group order at the end - with one group 40 threads of 256 did all the arithmetic of a 16 -> 10 layer
+  const int G = owners <= kThreads / 2 ? kThreads / owners : 1;
+  const int g = G > 1 ? (int)threadIdx.x / owners : 0;
+  const int pg = G > 1 ? (int)threadIdx.x - g * owners : (int)threadIdx.x;  // pair of this thread in the grouped form
   float4 acc[4];
   float bacc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc[k] = float4{0.f, 0.f, 0.f, 0.f}, bacc[k] = 0.f;
   const int64_t r0 = (int64_t)blockIdx.x * kRowsPerWg;
   const int64_t r1 = r0 + kRowsPerWg < N ? r0 + kRowsPerWg : N;
-  for (int64_t base = r0; base < r1; base += kTileRows) {
-    const int rows = (int)(r1 - base < kTileRows ? r1 - base : kTileRows);
+  for (int64_t base = r0; base < r1; base += tile_rows) {
+    const int rows = (int)(r1 - base < tile_rows ? r1 - base : tile_rows);
     __syncthreads();
-    for (int e = threadIdx.x; e < rows * C4; e += kThreads) {
-      const int r = e / C4, c = e - r * C4;
-      *reinterpret_cast<float4*>(&xs[r][4 * c]) = reinterpret_cast<const float4*>(x + (base + r) * cin)[c];
-    }
+    // the tile's rows are contiguous in both arrays: straight float4 / float copies
+    const float4* __restrict__ xsrc = reinterpret_cast<const float4*>(x + base * cin);
+    for (int e = threadIdx.x; e < rows * C4; e += kThreads) reinterpret_cast<float4*>(xs)[e] = xsrc[e];
+    const float* __restrict__ gsrc = dy + base * cout;
     for (int e = threadIdx.x; e < rows * cout; e += kThreads) {
       const int r = e / cout, o = e - r * cout;
-      gs[r][o] = dy[(base + r) * cout + o];
+      gs[r * gp + o] = gsrc[e];
     }
     __syncthreads();
+    if (G > 1) {
+      if (g < G) {
+        const int o = pg / C4, c = pg - o * C4;
+        for (int r = g; r < rows; r += G) {
+          const float gv = gs[r * gp + o];
+          const float4 xv = *reinterpret_cast<const float4*>(&xs[r * cin + 4 * c]);
+          acc[0].x = fmaf(gv, xv.x, acc[0].x);
+          acc[0].y = fmaf(gv, xv.y, acc[0].y);
+          acc[0].z = fmaf(gv, xv.z, acc[0].z);
+          acc[0].w = fmaf(gv, xv.w, acc[0].w);
+          if (c == 0) bacc[0] += gv;
+        }
+      }
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = threadIdx.x + k * kThreads;
-      if (p < owners) {
-        const int o = p / C4, c = p - o * C4;
-        for (int r = 0; r < rows; ++r) {
-          const float gv = gs[r][o];
-          const float4 xv = *reinterpret_cast<const float4*>(&xs[r][4 * c]);
-          acc[k].x = fmaf(gv, xv.x, acc[k].x);
-          acc[k].y = fmaf(gv, xv.y, acc[k].y);
-          acc[k].z = fmaf(gv, xv.z, acc[k].z);
-          acc[k].w = fmaf(gv, xv.w, acc[k].w);
-          if (c == 0) bacc[k] += gv;
+      for (int k = 0; k < 4; ++k) {
+        const int p = threadIdx.x + k * kThreads;
+        if (p < owners) {
+          const int o = p / C4, c = p - o * C4;
+          for (int r = 0; r < rows; ++r) {
+            const float gv = gs[r * gp + o];
+            const float4 xv = *reinterpret_cast<const float4*>(&xs[r * cin + 4 * c]);
+            acc[k].x = fmaf(gv, xv.x, acc[k].x);
+            acc[k].y = fmaf(gv, xv.y, acc[k].y);
+            acc[k].z = fmaf(gv, xv.z, acc[k].z);
+            acc[k].w = fmaf(gv, xv.w, acc[k].w);
+            if (c == 0) bacc[k] += gv;
+          }
         }
       }
     }
   }
   float* __restrict__ out = partial + (int64_t)blockIdx.x * (cout * cin + cout);
+  if (G > 1) {  // the groups' sums through LDS (the tiles are done with), added in group order by group 0
+    __syncthreads();
+    float* red = lin_smem;  // [G][owners][5]
+    if (g < G) {
+      float* q = red + ((size_t)g * owners + pg) * 5;
+      q[0] = acc[0].x, q[1] = acc[0].y, q[2] = acc[0].z, q[3] = acc[0].w, q[4] = bacc[0];
+    }
+    __syncthreads();
+    if (g == 0) {
+      float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+        for (int u = 0; u < 5; ++u) v[u] += red[((size_t)gg * owners + pg) * 5 + u];
+      const int o = pg / C4, c = pg - o * C4;
+      *reinterpret_cast<float4*>(out + o * cin + 4 * c) = float4{v[0], v[1], v[2], v[3]};
+      if (c == 0) out[cout * cin + o] = v[4];
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int p = threadIdx.x + k * kThreads;
@@ -142,22 +185,29 @@ __global__ __launch_bounds__(kThreads) void linear_dw_partial_kernel(const float
   }
 }
 
-// dW / db = the partials summed in workgroup order (8 in flight per thread)
+// dW / db = the partials summed over the workgroups: 16 lanes per element stride over them (8 loads in flight each), then a
+// fixed-order shuffle tree - deterministic; one thread per element walking all 313 partials of a 160k-row layer was a
+// chain of 40 round trips (10 us)
 __global__ __launch_bounds__(kThreads) void linear_dw_sum_kernel(const float* __restrict__ partial, int blocks, int cin, int cout,
                                                                  float* __restrict__ dW, float* __restrict__ db) {
   const int per = cout * cin + cout;
-  const int e = blockIdx.x * kThreads + threadIdx.x;
-  if (e >= per) return;
+  const int part = threadIdx.x & 15;
+  const int e = blockIdx.x * (kThreads / 16) + (threadIdx.x >> 4);
   float acc = 0.f;
-  int b = 0;
-  for (; b + 8 <= blocks; b += 8) {
-    float v[8];
+  if (e < per) {
+    int b = part;
+    for (; b + 7 * 16 < blocks; b += 8 * 16) {
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u) * per + e];
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + 16 * u) * per + e];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < blocks; b += 16) acc += partial[(int64_t)b * per + e];
   }
-  for (; b < blocks; ++b) acc += partial[(int64_t)b * per + e];
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 16);
+  if (part != 0 || e >= per) return;
   if (e < cout * cin) {
     if (dW) dW[e] = acc;
   } else if (db) {
@@ -219,9 +269,11 @@ extern "C" int gpn_linear_bwd(const float* x, const float* W, const float* dy, i
     }
     GPN_CHECK_ARG(x);
     float* partial = static_cast<float*>(ws);
-    hipLaunchKernelGGL(linear_dw_partial_kernel, dim3(blocks), dim3(kThreads), 0, stream, x, dy, N, cin, cout, partial);
+    const int tile_rows = (size_t)kTileRows * (cin + cout + 1) * sizeof(float) <= 65536 ? kTileRows : kTileRows / 2;
+    const size_t lds = (size_t)tile_rows * (cin + cout + 1) * sizeof(float);  // 22 KB for a 16 -> 27 head
+    hipLaunchKernelGGL(linear_dw_partial_kernel, dim3(blocks), dim3(kThreads), lds, stream, x, dy, N, cin, cout, tile_rows, partial);
     GPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(linear_dw_sum_kernel, dim3((cout * cin + cout + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
+    hipLaunchKernelGGL(linear_dw_sum_kernel, dim3((cout * cin + cout + kThreads / 16 - 1) / (kThreads / 16)), dim3(kThreads), 0, stream,
                        (const float*)partial, blocks, cin, cout, dW, db);
     GPN_CHECK_LAUNCH();
   }

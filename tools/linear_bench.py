@@ -1,19 +1,15 @@
-import os, sys, time
+"""micro-benchmark of the dense-head kernels (csrc/linear.hip) through the Python wrappers: forward, full backward, dW / db only"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, torch.nn.functional as F
-from gapartnet_amd import functional as GF
+import torch
+from gapartnet_amd import hip_ops as H
 dev = torch.device("cuda:0")
-for n, cin, cout in ((160000, 16, 10), (160000, 16, 16), (160000, 16, 3), (60000, 16, 27)):
-    x = torch.randn(n, cin, device=dev, requires_grad=True)
-    w = torch.randn(cout, cin, device=dev, requires_grad=True)
-    b = torch.randn(cout, device=dev, requires_grad=True)
-    dy = torch.randn(n, cout, device=dev)
-    for name, fn in (("F.linear", F.linear), ("GF.linear", GF.linear)):
-        def run():
-            y = fn(x, w, b)
-            torch.autograd.grad(y, [x, w, b], dy)
-        for _ in range(5): run()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(50): run()
-        t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-        print(f"{n:7d} {cin}->{cout:2d} {name:10s} host {1e6 * (t1 - t0) / 50:7.1f} us  total {1e6 * (t2 - t0) / 50:7.1f} us")
+def t(fn, it=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(it): fn()
+    b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / it * 1e3
+for n, cin, cout in ((160000, 16, 10), (160000, 16, 16), (160000, 16, 3), (10000, 16, 27), (300, 16, 9), (4096, 64, 64)):
+    x = torch.randn(n, cin, device=dev); w = torch.randn(cout, cin, device=dev); b = torch.randn(cout, device=dev); dy = torch.randn(n, cout, device=dev)
+    print(n, cin, cout, "fwd %.1f us" % t(lambda: H.linear_fwd(x, w, b)), "bwd (dx+dW+db) %.1f us" % t(lambda: H.linear_bwd(x, w, dy, True, True, True)), "bwd dW only %.1f" % t(lambda: H.linear_bwd(x, w, dy, False, True, True)))
