@@ -1,5 +1,6 @@
 // gpn_common.h — shared host/device helpers for libgpn_hip.so (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <cstring>  // must precede rocprim (texture_cache_iterator.hpp calls memset on the host)
 #include <hip/hip_runtime.h>
 

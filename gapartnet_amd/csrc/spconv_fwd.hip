@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   }
   // store; BatchNorm column sums of the tile when the launch carries a slab (bn_stats.h)
   const bool st_fwd = stats.slab != nullptr && stats.x == nullptr;
-  float s0 = 0.f, s1 = 0.f;
+  double s0 = 0.0, s1 = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + 4 * g + r;
@@ -431,12 +431,12 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
       if (accumulate) v += out[e];  // (a second gradient of the same rows, added in place)
       out[e] = v;
       if (st_fwd) {
-        s0 += v;
-        s1 += v * v;
+        s0 += (double)v;
+        s1 += (double)v * (double)v;
       } else if (st_bwd) {
         const float gm = (stats.relu && !(by[r] > 0.f)) ? 0.f : v;
-        s0 += gm;
-        s1 += gm * ((bx[r] - mu) * is);
+        s0 += (double)gm;
+        s1 += (double)gm * (double)((bx[r] - mu) * is);
       }
     }
   }
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   for (int q = 1; q < SP; ++q) acc += red[wave + q][lane];
 
   const bool st_fwd = stats.slab != nullptr && stats.x == nullptr;
-  float s0 = 0.f, s1 = 0.f;
+  double s0 = 0.0, s1 = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + 4 * g + r;
@@ -584,12 +584,12 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
       if (accumulate) v += out[e];
       out[e] = v;
       if (st_fwd) {
-        s0 += v;
-        s1 += v * v;
+        s0 += (double)v;
+        s1 += (double)v * (double)v;
       } else if (st_bwd) {
         const float gm = (stats.relu && !(by[r] > 0.f)) ? 0.f : v;
-        s0 += gm;
-        s1 += gm * ((bx[r] - mu) * is);
+        s0 += (double)gm;
+        s1 += (double)gm * (double)((bx[r] - mu) * is);
       }
     }
   }

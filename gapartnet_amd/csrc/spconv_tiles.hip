@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const uint32_t col = (uint32_t)((nt0 + nt) * 16 + i16);
-        float s0 = 0.f, s1 = 0.f;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if ((int64_t)tile * 16 + 4 * g + r < n_dst) {
@@ -249,12 +249,12 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
             if (accumulate) v += out[e];  // (a second gradient of the same rows, added in place)
             out[e] = v;
             if (st_fwd) {
-              s0 += v;
-              s1 += v * v;
+              s0 += (double)v;
+              s1 += (double)v * (double)v;
             } else if (st_bwd) {
               const float gm = (stats.relu && !(by[t][nt][r] > 0.f)) ? 0.f : v;
-              s0 += gm;
-              s1 += gm * ((bx[t][nt][r] - bmu[nt]) * bis[nt]);
+              s0 += (double)gm;
+              s1 += (double)gm * (double)((bx[t][nt][r] - bmu[nt]) * bis[nt]);
             }
           }
         }
