@@ -17,6 +17,8 @@
 //  * dgrad is the same kernel on the transposed rulebook with transposed (and for SubM, tap-reversed)
 //    packed weights.  wgrad contracts over pairs: A = in[src]^T, B = dout[dst], 4 pairs per MFMA,
 //    split over (tap, pair-range, cin-group) workgroups with a fixed-order partial reduction.
+#include <cstdlib>
+
 #include "gpn_common.h"
 #include "spconv_pack.h"
 
@@ -246,13 +248,28 @@ int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
   const int ct_tiles = cin / 16;
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int cig = (ct_tiles + CT - 1) / CT;
-  // enough pair slices for ~4096 workgroups (each slice is a latency-bound gather loop), at least ~128 dst rows
-  // per slice, and at most 8 MB of partials (they are written and re-read by the reduce: 37 MB at 48 channels cost more
-  // than the extra slices saved)
-  int64_t S = 4096 / ((int64_t)K * cig);
-  const int64_t cap = n_dst / 128;
+  // enough pair slices for ~4096 workgroups (each slice is a latency-bound gather loop), at least ~128 dst rows per slice,
+  // and at most 8 MB of partials (they are written and re-read by the reduce).  Swept in the training step, round 3
+  // (profiles/r03_findings.md): rows per slice 32 / 64 / 128 / 384 / 768 / 1536 -> 9.43 / 9.5 / 8.9 / 9.0 / 9.4 / 9.95 ms per
+  // step; partial cap 2 / 3 / 4 / 6 / 8 / 16 MB -> 10.3 / 9.8 / 9.1 / 9.7 / 9.3 / 9.5 ms in single runs (box noise +-0.3), and
+  // 4 MB (with the thread-per-element reduce up to 64 slices) 9.32 vs 9.16 ms for 8 MB in an interleaved same-box A/B.
+  // env: GPN_WGRAD_TARGET_WGS, GPN_WGRAD_ROWS_PER_SLICE, GPN_WGRAD_PARTIAL_MB
+  static const int64_t target_wgs = [] {
+    const char* e = getenv("GPN_WGRAD_TARGET_WGS");
+    return (int64_t)(e ? atoll(e) : 4096);
+  }();
+  static const int64_t partial_mb = [] {
+    const char* e = getenv("GPN_WGRAD_PARTIAL_MB");
+    return (int64_t)(e ? atoll(e) : 8);
+  }();
+  int64_t S = target_wgs / ((int64_t)K * cig);
+  static const int64_t rows_per_slice = [] {
+    const char* e = getenv("GPN_WGRAD_ROWS_PER_SLICE");
+    return (int64_t)(e ? atoll(e) : 128);
+  }();
+  const int64_t cap = n_dst / rows_per_slice;
   if (S > cap) S = cap;
-  const int64_t mem_cap = ((int64_t)8 << 20) / ((int64_t)K * cin * cout * 4);
+  const int64_t mem_cap = (partial_mb << 20) / ((int64_t)K * cin * cout * 4);
   if (S > mem_cap) S = mem_cap;
   if (S < 1) S = 1;
   if (S > 512) S = 512;
