@@ -83,28 +83,110 @@ struct ValidFlag {
   __device__ __host__ int32_t operator()(int32_t v) const { return v >= 0 ? 1 : 0; }
 };
 
-// pos = exclusive scan of (table >= 0) over K*n_dst+1 entries (last entry is a -1 sentinel)
-__global__ void compact_kernel(const int32_t* __restrict__ table, const int32_t* __restrict__ pos, int K,
-                               int64_t n_dst, int64_t n_tiles, int32_t* __restrict__ pair_src,
-                               int32_t* __restrict__ pair_dst, int32_t* __restrict__ tile_off,
-                               int64_t* __restrict__ num_pairs) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)K * n_dst;
-  if (t > total) return;
-  if (t == total) {
-    if (num_pairs) num_pairs[0] = pos[total];
-    tile_off[(int64_t)(K - 1) * (n_tiles + 1) + n_tiles] = pos[total];
-    return;
+// ---- pair lists from the tap-major table: wave ballots, no device-wide scan over the table (round 3) ------------------------
+// pair_src / pair_dst = the valid entries of table [K, n_dst] in (tap, row) order; tile_off[k][t] = position of the first pair
+// of tap k at or behind row 32 t; tile_off[k][n_tiles] = end of tap k.  Until round 3: a rocPRIM exclusive scan over all
+// K n_dst + 1 entries (4 M at level 0: a 16 MB position array written and read back) + a compaction launch.  Now:
+//   A  lists_count_kernel    a half-wave per (tap, 32-row tile): ballot + popcount = the tile's pair count; a workgroup's eight
+//                            counts and their sum go to a scratch array
+//   B  lists_block_scan_kernel   ONE workgroup: exclusive scan of the workgroup sums (15 k of them at level 0), total
+//   C  lists_compact_kernel  same ballots again: position = workgroup offset + prefix of the tile counts before it + rank of
+//                            the lane among the tile's valid lanes (ballot mask below the lane) -> pairs in (tap, row) order
+// The table is read twice (coalesced); nothing else of its size is written.  Flat tile index f = k * n_tiles + t.
+constexpr int kListTilesPerWg = 8;  // 256 threads = 4 waves x 2 half-waves
+
+__device__ __forceinline__ bool lists_entry(const int32_t* __restrict__ table, int K, int64_t n_dst, int64_t n_tiles, int64_t f,
+                                            int lane32, int& k, int64_t& row, int32_t& value) {
+  k = 0, row = 0, value = -1;
+  if (f >= (int64_t)K * n_tiles) return false;
+  k = (int)(f / n_tiles);
+  const int64_t t = f - (int64_t)k * n_tiles;
+  row = t * GPN_TILE_ROWS + lane32;
+  if (row >= n_dst) return false;
+  value = table[(int64_t)k * n_dst + row];
+  return value >= 0;
+}
+
+__global__ __launch_bounds__(256) void lists_count_kernel(const int32_t* __restrict__ table, int K, int64_t n_dst, int64_t n_tiles,
+                                                          int32_t* __restrict__ counts, int32_t* __restrict__ wg_sum) {
+  __shared__ int32_t c[kListTilesPerWg];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const int64_t f = (int64_t)blockIdx.x * kListTilesPerWg + wave * 2 + half;
+  int k;
+  int64_t row;
+  int32_t v;
+  const bool valid = lists_entry(table, K, n_dst, n_tiles, f, lane & 31, k, row, v);
+  const uint64_t m = __builtin_amdgcn_ballot_w64(valid);
+  const int cnt = __popcll(half ? (m >> 32) : (m & 0xffffffffull));
+  if ((lane & 31) == 0) {
+    c[wave * 2 + half] = cnt;
+    if (f < (int64_t)K * n_tiles) counts[f] = cnt;
   }
-  const int k = (int)(t / n_dst);
-  const int64_t o = t - (int64_t)k * n_dst;
-  const int32_t p = pos[t];
-  if ((o & (GPN_TILE_ROWS - 1)) == 0) tile_off[(int64_t)k * (n_tiles + 1) + o / GPN_TILE_ROWS] = p;
-  if (o == 0 && k > 0) tile_off[(int64_t)(k - 1) * (n_tiles + 1) + n_tiles] = p;
-  const int32_t s = table[t];
-  if (s >= 0) {
-    pair_src[p] = s;
-    pair_dst[p] = (int32_t)o;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kListTilesPerWg; ++i) sum += c[i];
+    wg_sum[blockIdx.x] = sum;
+  }
+}
+
+// in place: wg_sum[b] -> exclusive prefix; the grand total to *total (int32) and, if given, *num_pairs (int64)
+__global__ __launch_bounds__(1024) void lists_block_scan_kernel(int32_t* __restrict__ wg_sum, int64_t n, int32_t* __restrict__ total,
+                                                                int64_t* __restrict__ num_pairs) {
+  __shared__ int32_t part[1024];
+  const int tid = threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024;
+  const int64_t b = tid * chunk, e = b + chunk < n ? b + chunk : n;
+  int32_t sum = 0;
+  for (int64_t i = b; i < e; ++i) sum += wg_sum[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan of the 1024 chunk sums
+    const int32_t add = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  int32_t run = tid > 0 ? part[tid - 1] : 0;
+  for (int64_t i = b; i < e; ++i) {
+    const int32_t v = wg_sum[i];
+    wg_sum[i] = run;
+    run += v;
+  }
+  if (tid == 1023) {
+    *total = part[1023];
+    if (num_pairs) *num_pairs = part[1023];
+  }
+}
+
+__global__ __launch_bounds__(256) void lists_compact_kernel(const int32_t* __restrict__ table, int K, int64_t n_dst, int64_t n_tiles,
+                                                            const int32_t* __restrict__ counts, const int32_t* __restrict__ wg_off,
+                                                            int32_t* __restrict__ pair_src, int32_t* __restrict__ pair_dst,
+                                                            int32_t* __restrict__ tile_off) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const int slot = wave * 2 + half;
+  const int64_t f0 = (int64_t)blockIdx.x * kListTilesPerWg;
+  const int64_t f = f0 + slot, F = (int64_t)K * n_tiles;
+  int k;
+  int64_t row;
+  int32_t v;
+  const bool valid = lists_entry(table, K, n_dst, n_tiles, f, lane & 31, k, row, v);
+  const uint64_t m = __builtin_amdgcn_ballot_w64(valid);
+  const uint32_t mh = (uint32_t)(half ? (m >> 32) : (m & 0xffffffffull));
+  int32_t base = wg_off[blockIdx.x];
+  for (int i = 0; i < slot; ++i) base += (f0 + i < F) ? counts[f0 + i] : 0;  // (<= 7 L2-resident reads, the same in every lane)
+  if (f < F) {
+    if ((lane & 31) == 0) {
+      const int64_t t = f - (int64_t)k * n_tiles;
+      tile_off[(int64_t)k * (n_tiles + 1) + t] = base;
+      if (t == 0 && k > 0) tile_off[(int64_t)(k - 1) * (n_tiles + 1) + n_tiles] = base;  // end of the previous tap
+    }
+    if (valid) {
+      const int32_t p = base + __popc(mh & ((1u << (lane & 31)) - 1u));
+      pair_src[p] = v;
+      pair_dst[p] = (int32_t)row;
+    }
   }
 }
 
@@ -127,17 +209,24 @@ size_t scan_temp_bytes(int64_t n) {
 }
 
 // table: [K*n_dst + 1] with table[K*n_dst] == -1.  pos: [K*n_dst + 1].
+// scratch (`pos`): K n_tiles tile counts + one sum per workgroup of 8 tiles; callers size it K n_dst + 64 ints
 int lists_from_table(const int32_t* table, int32_t* pos, int K, int64_t n_dst, int32_t* pair_src,
                      int32_t* pair_dst, int32_t* tile_off, int64_t* num_pairs, void* prim_tmp,
                      size_t prim_bytes, hipStream_t stream) {
-  const int64_t total = (int64_t)K * n_dst + 1;
+  (void)prim_tmp;
+  (void)prim_bytes;
   const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
-  auto in = rocprim::make_transform_iterator(table, ValidFlag());
-  size_t tmp = prim_bytes;
-  GPN_CHECK_HIP(rocprim::exclusive_scan(prim_tmp, tmp, in, pos, 0, (size_t)total, rocprim::plus<int32_t>(),
-                                        stream));
-  hipLaunchKernelGGL(compact_kernel, dim3((int)gpn::cdiv(total, kThreads)), dim3(kThreads), 0, stream, table,
-                     pos, K, n_dst, n_tiles, pair_src, pair_dst, tile_off, num_pairs);
+  const int64_t F = (int64_t)K * n_tiles;
+  const int64_t n_wg = gpn::cdiv(F, kListTilesPerWg);
+  int32_t* counts = pos;
+  int32_t* wg_sum = pos + F;
+  hipLaunchKernelGGL(lists_count_kernel, dim3((unsigned)n_wg), dim3(256), 0, stream, table, K, n_dst, n_tiles, counts, wg_sum);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lists_block_scan_kernel, dim3(1), dim3(1024), 0, stream, wg_sum, n_wg,
+                     tile_off + (int64_t)(K - 1) * (n_tiles + 1) + n_tiles, num_pairs);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lists_compact_kernel, dim3((unsigned)n_wg), dim3(256), 0, stream, table, K, n_dst, n_tiles,
+                     (const int32_t*)counts, (const int32_t*)wg_sum, pair_src, pair_dst, tile_off);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -392,7 +481,7 @@ extern "C" size_t gpn_rulebook_subm3_ws_bytes(int64_t N) {
   w.take<uint64_t>(hash_capacity(N));
   w.take<int32_t>(hash_capacity(N));
   w.take<int32_t>(27 * n + 1);
-  w.take<int32_t>(27 * n + 1);
+  w.take<int32_t>(27 * n + 64);
   w.take<char>(scan_temp_bytes(27 * (int64_t)n + 1));
   return w.used;
 }
@@ -418,7 +507,7 @@ extern "C" int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32
   int32_t* hvals = w.take<int32_t>(cap);
   int32_t* table_ws = w.take<int32_t>(27 * (size_t)N + 1);
   int32_t* table = nbr ? nbr : table_ws;  // the tap-major neighbour table is an output when the caller wants it
-  int32_t* pos = w.take<int32_t>(27 * (size_t)N + 1);
+  int32_t* pos = w.take<int32_t>(27 * (size_t)N + 64);
   size_t prim_bytes = scan_temp_bytes(27 * N + 1);
   void* prim_tmp = w.take<char>(prim_bytes);
   GPN_CHECK_WS(w);
@@ -655,7 +744,7 @@ extern "C" size_t gpn_rulebook_down_lists_ws_bytes(int64_t N, int64_t n_out) {
   size_t n = (size_t)(N > 0 ? N : 1), no = (size_t)(n_out > 0 ? n_out : 1);
   w.take<int32_t>(8 * no + 1);
   w.take<int32_t>(8 * n + 1);
-  w.take<int32_t>(8 * n + 1);  // pos (shared, sized for the larger table)
+  w.take<int32_t>(8 * n + 64);  // scratch of the list builder (shared, sized for the larger table)
   w.take<char>(scan_temp_bytes(8 * (int64_t)n + 1));
   return w.used;
 }
@@ -680,7 +769,7 @@ extern "C" int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int3
   int32_t* tb_ws = w.take<int32_t>(8 * (size_t)N + 1);
   int32_t* tf = fwd_nbr ? fwd_nbr : tf_ws;
   int32_t* tb = bwd_nbr ? bwd_nbr : tb_ws;
-  int32_t* pos = w.take<int32_t>(8 * (size_t)N + 1);
+  int32_t* pos = w.take<int32_t>(8 * (size_t)N + 64);
   size_t prim_bytes = scan_temp_bytes(8 * N + 1);
   void* prim_tmp = w.take<char>(prim_bytes);
   GPN_CHECK_WS(w);
