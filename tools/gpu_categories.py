@@ -19,7 +19,7 @@ def c(n):
     if 'ccl_' in n: return 'ccl'
     if 'rocprim' in n or 'radix' in n.lower() or 'sort' in n.lower(): return 'sort/scan (rocprim, torch)'
     if 'Cijk' in n: return 'GEMM (hipBLASLt)'
-    if any(k in n for k in ('vox_', 'hash', 'subm', 'down_', 'compact')): return 'voxelize/rulebook'
+    if any(k in n for k in ('vox_', 'hash', 'subm', 'down_', 'compact', 'lists_', 'bitmap_', 'level_counts', 'identity_rulebook', 'fill_two')): return 'voxelize/rulebook'
     if 'multi_tensor' in n or 'fused_adam' in n.lower(): return 'optimizer'
     if 'copyBuffer' in n or 'fillBuffer' in n: return 'memcpy/memset'
     if 'index' in n: return 'torch indexing'
