@@ -15,6 +15,7 @@ f=$(find /tmp/p1 -name "*kernel_trace.csv" 2>/dev/null | head -1)
 if [ -n "$f" ]; then python "$R/tools/step_sequence.py" "$f" > "$O/step_sequence.txt" 2>&1 < /dev/null; python "$R/tools/fwd_bwd_split.py" "$f" > "$O/fwd_bwd_split.txt" 2>&1 < /dev/null; python "$R/tools/summarize_trace.py" "$f" "$O/conv_kernels_by_grid.csv" "spconv,wgrad,bn_,ccl_,linear" > /dev/null 2>&1 < /dev/null; python "$R/tools/timeline.py" "$f" "$O/timeline.txt" 0.12 > /dev/null 2>&1 < /dev/null; python "$R/tools/queue_breakdown.py" "$f" 21 > "$O/queue_breakdown.txt" 2>&1 < /dev/null; python "$R/tools/backward_tail.py" "$f" > "$O/backward_tail.txt" 2>&1 < /dev/null; fi
 cp "$O/profile_summary.json" "$R/profiles/profile_summary.json" 2>/dev/null
 timeout 240 python "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err" < /dev/null; cut -c1-260 "$O/bench_default.json"
+for i in 1 2 3; do timeout 240 python "$R/bench.py" --no-cpu-baseline > "$O/bench_default_run$i.json" 2> /dev/null < /dev/null; done  # run-to-run spread on this box
 GPN_BENCH_FORCE_GRAD_SYNC=1 timeout 240 python "$R/bench.py" --no-cpu-baseline > "$O/bench_forced_grad_sync.json" 2> /dev/null < /dev/null
 for cfg in "--schedule 5,10" "--points 50000 --batch 4" "--batch 32"; do
   tag=$(echo "$cfg" | tr -d ' -' | tr ',' '_')
