@@ -10,6 +10,13 @@
 // passes cost 4.5 us of GPU time and one host launch per layer and pass (176 per training step of the default model).  Compared with separate BatchNorm / add / ReLU kernels this removes three full read+write passes per
 // layer in forward and two in backward.  All reductions are fixed-order (deterministic).
 //
+// Inside the network executor (net.hip) most BatchNorms do not run their statistics / reduction pass at all: the conv (or
+// dgrad) launch that produces their input (or output gradient) accumulates the column sums in its epilogue as
+// order-independent fixed-point integers (bn_stats.h), and only the apply pass of this file runs
+// (gpn::bn_fwd_train_fused / bn_bwd_fused: every workgroup folds the <= 32 slot sets, the first batch of elements is
+// requested before the fold, predicated batches of 4 loads; a launch can carry a second BatchNorm of the same shape for the
+// executor's paired passes).
+//
 // Small matrices (N <= kSmallRows: the deep levels of the U-Net, where a layer's kernels run at the
 // launch-latency floor) take a single-launch form instead: one workgroup per float4 column computes the statistics of
 // its four channels and applies them in a second sweep over the (L2-resident) column - one launch instead of three.

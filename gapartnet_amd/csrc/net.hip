@@ -9,7 +9,8 @@
 // weight packer (every weight of the program packed by a few launches at the start of a pass instead of one launch
 // per layer).  In backward the weight-gradient contractions run on a second (lower-priority) stream: they are off
 // the critical path (nothing in the backward pass consumes dW), so they fill the CUs the dependent dgrad / BN chain
-// of the small, deep levels leaves idle.
+// of the small, deep levels leaves idle.  Round 3: BatchNorm sums ride in the conv / dgrad epilogues (bn_stats.h), and two
+// structurally identical networks over the same rulebooks run as PAIRED passes - one launch per layer for both (NetSet below).
 #include <unistd.h>
 
 #include <cstdlib>

@@ -4,9 +4,12 @@
 //
 // Design (MI355X): coordinates -> row lookups go through an open-addressing hash table in HBM/L2
 // (64-bit linear keys, linear probing, one atomicCAS per insert); every other step is a coalesced
-// streaming pass over a tap-major [K][n_dst] table: lookup -> exclusive scan (rocPRIM) -> compaction
-// into pair lists ordered by (tap, dst).  The scan doubles as the per-tile offset table the fused
-// conv kernel walks, so no sort is ever needed for SubM rulebooks.
+// streaming pass over a tap-major [K][n_dst] table: lookup -> per-tile ballot counts -> a small scan of
+// the workgroup sums -> ballot-rank compaction into pair lists ordered by (tap, dst) (round 3; a
+// rocPRIM exclusive scan over the whole table before).  The counts double as the per-tile offset table
+// the weight-gradient kernel walks, so no sort is ever needed for SubM rulebooks.  Stride-2 levels:
+// occupancy bitmap + popcount prefix (no sort either); the tile order of the large levels: masks by a
+// whole-chip launch, each 16384-row block sorted in one workgroup's LDS (rocPRIM block radix sort).
 #include "gpn_common.h"  // first: pulls <cstring> ahead of the HIP/rocPRIM headers
 
 #include <rocprim/rocprim.hpp>

@@ -1,22 +1,19 @@
 // spconv.hip — kernel C: sparse convolution forward / dgrad / wgrad for gfx950.
 // Replaces the gather-GEMM-scatter conv inside spconv (network/backbone.py:19-36,74-90,149-152).
 //
+// This file: weight packing, the weight-gradient contraction (+ its slice reductions) and the row gather / ordered scatter.
+// The forward / dgrad kernels live in spconv_tiles.hip (masked-tile kernel, layers of >= 4096 row tiles) and spconv_fwd.hip
+// (direct kernel, its tap-split form, the lock-step kernel for the tiniest layers).
+//
 // Design (MI355X / CDNA4, wave64):
-//  * ONE fused kernel per conv (spconv_fwd.hip), output-stationary: a wave owns a tile of 32 destination
-//    rows and keeps that tile's fp32 accumulators in its private slice of LDS.  For each tap k it walks
-//    the tile's 16-pair blocks: the 16 gathered source rows are the MFMA A operand, the tap's weight
-//    slab (shared by the workgroup through LDS) the B operand, v_mfma_f32_16x16x4_f32 does the
-//    per-rule dense contraction (exact fp32, == an fmaf chain), and the 16x(16*NTW) result is added
-//    to the owning rows of the LDS tile.  Each output row is written to HBM exactly once — no global
-//    atomics, no separate gather/scatter kernels, deterministic summation order (tap-major).
-//  * A operand straight from global memory with one 16-byte load per lane: lane (i = l&15, g = l>>4)
-//    loads channels [16cb+4g, 16cb+4g+4) of pair i's source row, i.e. every gathered row is read as
-//    whole contiguous 64-byte pieces.  The 4 loaded channels feed 4 consecutive MFMA steps; the
-//    matching K-permutation is baked into the packed weights (gpn_spconv_pack_weights), whose
-//    per-(tap, channel-block, column-tile) fragment is one coalesced 1 KiB load per wave.
-//  * dgrad is the same kernel on the transposed rulebook with transposed (and for SubM, tap-reversed)
-//    packed weights.  wgrad contracts over pairs: A = in[src]^T, B = dout[dst], 4 pairs per MFMA,
-//    split over (tap, pair-range, cin-group) workgroups with a fixed-order partial reduction.
+//  * packed weights: [K][Cin/16][Cout/16][64 lanes][4] = the MFMA B fragment of one 16x16 tile per 1 KiB, with transpose /
+//    tap-reverse flags for dgrad (gpn_spconv_pack_weights; the executor packs a whole network per pass, net.hip).
+//  * wgrad contracts over pair lists: A = in[src]^T, B = dout[dst], 4 pairs per v_mfma_f32_16x16x4_f32 k-step, grid
+//    (tap, pair slice, Cin group); a workgroup stages 64 pairs at a time through LDS (16-byte gathers, conflict-free pitch)
+//    while the next tile's gathers and the one after's indices are in flight; fixed-order reductions over the 4 waves (LDS)
+//    and over the slices (a second launch: 16 lanes per element for many slices, a thread per element - coalesced - for
+//    <= 32) => deterministic.  The kernel is bound by gather bandwidth out of L2 (each row is re-read once per pair).
+//  * gather_rows / scatter_rows_csr: features[pc_voxel_id] and its transpose as an ordered CSR sum (deterministic).
 #include <cstdlib>
 
 #include "gpn_common.h"

@@ -9,12 +9,13 @@
 // consecutive MFMA steps and the matching K-permutation is baked into the packed weights.  The fp32 MFMA is exact and
 // the summation order is fixed, so results are deterministic.
 //
-// Two kernels:
-//  * spconv_fwd_direct_kernel (below, second half of the file) - every k = 27 / k = 8 layer with >= 16 row tiles, i.e.
-//    ~95 % of the flops: one wave per (16-row tile, 16-column tile), weight fragments straight from L2, no LDS, no
+// Three kernels here (layers of >= 4096 row tiles take the masked-tile kernel of spconv_tiles.hip instead, round 3):
+//  * spconv_fwd_direct_kernel (below, second half of the file) - k = 27 / 8 / 1 layers with 16 .. 4095 row tiles; with fewer
+//    than 12000 (tile, column tile) units in its tap-split form spconv_fwd_split_kernel (4 waves per unit, partial sums added
+//    through LDS in wave order).  The direct kernel: one wave per (16-row tile, 16-column tile), weight fragments straight from L2, no LDS, no
 //    barrier, no partial outputs.  It replaced round 1's persistent LDS-slab streaming kernel (L0 / L1 / L2 launches
 //    32 / 72 / 74 us -> 27 / 56 / 42 us; that kernel, its tile-order rulebook option and its input-block partial sums are gone).
-//  * spconv_fwd_kernel - the k = 1 layers and the deepest levels (< 16 tiles): WPB waves (4..16) walk stages (tap k, chunk of
+//  * spconv_fwd_kernel - the deepest levels (< 16 tiles) and widths the direct kernel is not instantiated for: WPB waves (4..16) walk stages (tap k, chunk of
 //    CW 16-channel blocks) in lock-step, a stage's weight slab (CW x NTW 1 KiB MFMA-B fragments) goes through a
 //    double-buffered LDS slab, one barrier per stage; loads are software-pipelined with compile-time ring slots and are
 //    unconditional / branch-free so that the compiler emits counted s_waitcnt vmcnt(N); tiny layers split their taps over

@@ -172,7 +172,7 @@ import os as _os
 # Rows re-ordered by neighbour mask (gpn_rulebook_tile_order) for the masked-tile conv kernel (csrc/spconv_tiles.hip): a
 # tile executes a tap as soon as ANY of its rows has that neighbour.  In voxel order a level-0 tile of the bench scenes runs
 # 4.3x the MFMA row-slots of its useful pairs, sorted by mask inside 16384-row blocks 2.1x (levels 1 / 2: 2.2x / 2.0x ->
-# 1.4x; stride-2 convs 4.4x -> 1.3x, inverse convs 4.3x -> 1.0x; tools/conv_tiles_bench.py).  The order costs a radix sort
+# 1.4x; stride-2 convs 4.4x -> 1.3x, inverse convs 4.3x -> 1.0x; tools/conv_tiles_bench.py).  The order costs a block-local sort (one workgroup per 16384 rows)
 # and a permuted table per rulebook; levels below 4096 tiles run on the direct kernel and keep voxel order.
 TILE_ORDER_MIN_ROWS = int(_os.environ.get("GPN_TILE_ORDER_MIN_ROWS", 65536))  # = the levels the masked-tile kernel takes
 TILE_ORDER_BLOCK = int(_os.environ.get("GPN_TILE_ORDER_BLOCK", 16384))
