@@ -63,6 +63,8 @@ def init_distributed(device_type: str = "cuda"):
     device = torch.device(f"cuda:{0 if share else local_rank}") if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
+        from .affinity import pin_to_gpu_node
+        pin_to_gpu_node(device.index or 0)  # this rank's threads onto the cores of its GPU's NUMA node (GPN_NO_PIN=1: off)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

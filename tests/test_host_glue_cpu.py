@@ -304,3 +304,17 @@ def test_voxel_mean_backpropagates_to_point_features():
     (ref * w).sum().backward()
     assert torch.allclose(feats.grad, ref_feats.grad, atol=1e-6)
     assert torch.equal(feats.grad[:5], torch.zeros((5, 5)))
+
+
+def test_affinity_helpers_leave_the_process_alone_without_a_gpu(monkeypatch):
+    """affinity.pin_to_gpu_node: no GPU / unreadable topology / GPN_NO_PIN=1 -> affinity untouched, no error"""
+    import os
+    from gapartnet_amd import affinity
+    assert affinity._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert affinity._parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    assert affinity.pin_to_gpu_node(0) is None  # no GPU here: the PCI address cannot be resolved
+    monkeypatch.setenv("GPN_NO_PIN", "1")
+    monkeypatch.setattr(affinity, "gpu_numa_node", lambda i=0: 0)
+    assert affinity.pin_to_gpu_node(0) is None
+    assert os.sched_getaffinity(0) == before
