@@ -119,6 +119,24 @@ bool spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout);
 bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout);
 int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
                         int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream);
+// weight-gradient contraction and its (batched) slice sums (spconv.hip); used by gpn_spconv_wgrad and the network executor
+constexpr int kWgradReduceJobs = 24;
+struct WgradTwin {  // the same layer of a second network (paired pass): same rulebook, same shapes
+  const float* in = nullptr;
+  const float* dout = nullptr;
+  float* partial = nullptr;
+};
+struct WgradReduceJob {
+  const float* partial;
+  float* dW;
+  int64_t elems;
+  int S, K, cin, cout, oki, few;
+};
+int wgrad_slices(int K, int cin, int cout, int64_t n_dst);
+int wgrad_contract(const float* in, const float* dout, const int32_t* pair_src, const int32_t* pair_dst, const int32_t* tile_off,
+                   int K, int64_t n_dst, int cin, int cout, int S, float* partial, const WgradTwin& twin, hipStream_t stream);
+WgradReduceJob wgrad_reduce_job(const float* partial, int S, int K, int cin, int cout, int flags, float* dW);
+int wgrad_reduce_many(const WgradReduceJob* jobs, int n, hipStream_t stream);
 // gpn_rulebook_level_counts with row count and level-0 extent on the device (rulebook.hip; used by gpn_voxelize_scenes)
 int rulebook_level_counts_dev(const int32_t* indices, int64_t n_max, const int64_t* n_dev, int64_t batch_size,
                               const int64_t* max_coord_dev, int n_levels, int64_t* counts, void* ws, size_t ws_bytes,

@@ -127,10 +127,14 @@ inline int grid_for(int64_t total) {
 
 inline size_t slot_bytes(const gpn_net_slot_t& s) { return (size_t)s.rows * s.channels * sizeof(float); }
 
+// partials of the layers whose slice sums are batched into one launch: at most this much (they are written and read back
+// within a few launches - the bound keeps them inside the 256 MB memory-side cache)
+constexpr size_t kWgradBatchBytes = (size_t)96 << 20;
+
 struct Need {
   size_t tmp = 0;     // gradient staging buffer (largest slot that can receive a second gradient)
   size_t op = 0;      // largest per-op workspace of the main chain (conv tap-split partials, BN partials)
-  size_t wgrad = 0;   // largest wgrad workspace (side stream)
+  size_t wgrad = 0;   // weight-gradient partials (side stream): room for a batch of layers whose slice sums run in one launch
   size_t packed = 0;  // all packed weights of the program
   size_t stats = 0;   // BatchNorm sum slabs the conv epilogues add to (bn_stats.h), one per BN op
 };
@@ -138,6 +142,7 @@ struct Need {
 Need workspace_need(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, const gpn_net_rulebook_t* rbs,
                     const gpn_net_conv_t* convs) {
   Need n;
+  size_t wgrad_sum = 0;
   for (int i = 0; i < n_ops; ++i) {
     const gpn_net_op_t& op = ops[i];
     const gpn_net_slot_t& s0 = slots[op.src0];
@@ -147,7 +152,9 @@ Need workspace_need(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* sl
       size_t w = gpn_spconv_fwd_ws_bytes(rb.K, rb.n_dst, cv.cin, cv.cout);
       size_t wt = gpn_spconv_fwd_ws_bytes(rb.K, rb.n_src, cv.cout, cv.cin);
       n.op = std::max(n.op, std::max(w, wt));
-      n.wgrad = std::max(n.wgrad, gpn_spconv_wgrad_ws_bytes(rb.K, cv.cin, cv.cout, rb.n_dst));
+      const size_t wg = gpn_spconv_wgrad_ws_bytes(rb.K, cv.cin, cv.cout, rb.n_dst);
+      n.wgrad = std::max(n.wgrad, wg);
+      wgrad_sum += wg;
       n.packed += gpn::align_up((size_t)rb.K * cv.cin * cv.cout * sizeof(float));
       n.tmp = std::max(n.tmp, slot_bytes(s0));
     } else if (op.kind == GPN_NET_BN) {
@@ -158,7 +165,7 @@ Need workspace_need(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* sl
   }
   n.tmp = gpn::align_up(n.tmp);
   n.op = gpn::align_up(n.op);
-  n.wgrad = gpn::align_up(n.wgrad);
+  n.wgrad = gpn::align_up(std::max(n.wgrad, std::min(wgrad_sum, kWgradBatchBytes)));
   return n;
 }
 
@@ -455,6 +462,10 @@ struct WgradJob {
   int cin, cout;
   float* dW;
   hipEvent_t after;  // recorded on the caller's stream once dout is final
+  // the same layer of the second network of a paired pass (one launch contracts both), or nulls
+  const float* in2;
+  const float* dout2;
+  float* dW2;
 };
 
 class WgradWorker {
@@ -504,27 +515,70 @@ class WgradWorker {
       }
       (void)hipSetDevice(dev_);
       size_t done = 0;
+      // slice sums are deferred: every contraction gets its own piece of the workspace, and the sums of a batch of layers
+      // (up to kWgradReduceJobs of them / kWgradBatchBytes of partials) run as ONE launch (gpn::wgrad_reduce_many)
+      gpn::WgradReduceJob pending[gpn::kWgradReduceJobs];
+      int n_pending = 0;
+      size_t used = 0;
+      const size_t room = std::min(ws_bytes_, kWgradBatchBytes);
+      auto fail = [this](int rc) {
+        if (rc_ == GPN_OK) {
+          rc_ = rc;
+          err_ = gpn_last_error();
+        }
+      };
+      auto flush = [&] {
+        if (n_pending && rc_ == GPN_OK) {
+          const int rc = gpn::wgrad_reduce_many(pending, n_pending, side_);
+          if (rc != GPN_OK) fail(rc);
+        }
+        n_pending = 0;
+        used = 0;
+      };
+      auto issue = [&](const WgradJob& j) -> int {
+        if (hipStreamWaitEvent(side_, j.after, 0) != hipSuccess) {
+          gpn::set_error("gpn_net_backward: hipStreamWaitEvent failed on the weight-gradient stream");
+          return GPN_ERR_HIP;
+        }
+        const size_t elems = (size_t)j.K * j.cin * j.cout;
+        if (j.n_dst == 0) {
+          GPN_CHECK_HIP(hipMemsetAsync(j.dW, 0, sizeof(float) * elems, side_));
+          if (j.dW2) GPN_CHECK_HIP(hipMemsetAsync(j.dW2, 0, sizeof(float) * elems, side_));
+          return GPN_OK;
+        }
+        const int S = gpn::wgrad_slices(j.K, j.cin, j.cout, j.n_dst);
+        const size_t bytes = gpn::align_up((size_t)S * elems * sizeof(float));
+        const int n_nets = j.dW2 ? 2 : 1;
+        if (used + n_nets * bytes > room || n_pending + n_nets > gpn::kWgradReduceJobs) flush();
+        if (n_nets * bytes > ws_bytes_ || !ws_) {
+          gpn::set_error("gpn_net_backward: weight-gradient workspace too small");
+          return GPN_ERR_WS;
+        }
+        float* partial = reinterpret_cast<float*>(static_cast<char*>(ws_) + used);
+        gpn::WgradTwin twin;
+        if (j.dW2) twin.in = j.in2, twin.dout = j.dout2, twin.partial = reinterpret_cast<float*>(static_cast<char*>(ws_) + used + bytes);
+        const int rc = gpn::wgrad_contract(j.in, j.dout, j.pair_src, j.pair_dst, j.tile_off, j.K, j.n_dst, j.cin, j.cout, S, partial,
+                                           twin, side_);
+        if (rc != GPN_OK) return rc;
+        pending[n_pending++] = gpn::wgrad_reduce_job(partial, S, j.K, j.cin, j.cout, GPN_LAYOUT_OKI, j.dW);
+        if (j.dW2) pending[n_pending++] = gpn::wgrad_reduce_job(twin.partial, S, j.K, j.cin, j.cout, GPN_LAYOUT_OKI, j.dW2);
+        used += n_nets * bytes;
+        return GPN_OK;
+      };
       for (;;) {
         const size_t avail = published_.load(std::memory_order_acquire);
         if (done < avail) {
           const WgradJob& j = jobs_[done++];
           if (rc_ != GPN_OK) continue;  // drain after an error
-          int rc = hipStreamWaitEvent(side_, j.after, 0) == hipSuccess ? GPN_OK : GPN_ERR_HIP;
-          if (rc == GPN_OK)
-            rc = gpn_spconv_wgrad(j.in, j.dout, j.pair_src, j.pair_dst, j.tile_off, j.K, j.n_dst, j.cin, j.cout,
-                                  GPN_LAYOUT_OKI, j.dW, ws_, ws_bytes_, (gpn_stream_t)side_);
-          else
-            gpn::set_error("gpn_net_backward: hipStreamWaitEvent failed on the weight-gradient stream");
-          if (rc != GPN_OK) {
-            rc_ = rc;
-            err_ = gpn_last_error();
-          }
+          const int rc = issue(j);
+          if (rc != GPN_OK) fail(rc);
         } else if (closed_.load(std::memory_order_acquire) && done == published_.load(std::memory_order_acquire)) {
           break;
         } else {
           std::this_thread::yield();  // nothing published yet: give the core away (8 ranks share the host's cores)
         }
       }
+      flush();
       finished_.store(true, std::memory_order_release);
     }
   }
@@ -598,7 +652,7 @@ int net_backward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const
   }
   const Need need = workspace_need(ops, n_ops, nets[0].slots, rbs, nets[0].convs);
   const size_t per_net = need.tmp + need.packed + need.stats;
-  const size_t total_need = n_nets * per_net + need.op + need.wgrad;
+  const size_t total_need = n_nets * per_net + need.op + n_nets * need.wgrad;
   if (!ws || ws_bytes < total_need) {
     gpn::set_error("%s: workspace too small (%zu needed, %zu given)", who, total_need, ws_bytes);
     return GPN_ERR_WS;
@@ -698,10 +752,16 @@ int net_backward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const
         hipEvent_t ev = side->fork[side->next];
         side->next = (side->next + 1) % kForkEvents;
         GPN_CHECK_HIP(hipEventRecord(ev, stream));
-        for (int t = 0; t < n_nets; ++t)
-          if (nets[t].convs[op.param].dW)
-            worker.push(WgradJob{nets[t].slots[op.src0].data, nets[t].slots[op.dst].grad, rb.pair_src, rb.pair_dst, rb.tile_off,
-                                 rb.K, rb.n_dst, cv.cin, cv.cout, nets[t].convs[op.param].dW, ev});
+        if (pair && nets[0].convs[op.param].dW && nets[1].convs[op.param].dW) {
+          worker.push(WgradJob{nets[0].slots[op.src0].data, nets[0].slots[op.dst].grad, rb.pair_src, rb.pair_dst, rb.tile_off,
+                               rb.K, rb.n_dst, cv.cin, cv.cout, nets[0].convs[op.param].dW, ev, nets[1].slots[op.src0].data,
+                               nets[1].slots[op.dst].grad, nets[1].convs[op.param].dW});
+        } else {
+          for (int t = 0; t < n_nets; ++t)
+            if (nets[t].convs[op.param].dW)
+              worker.push(WgradJob{nets[t].slots[op.src0].data, nets[t].slots[op.dst].grad, rb.pair_src, rb.pair_dst, rb.tile_off,
+                                   rb.K, rb.n_dst, cv.cin, cv.cout, nets[t].convs[op.param].dW, ev, nullptr, nullptr, nullptr});
+        }
         forked = true;
       }
       if (op.src0 != 0 || need_input_grad) {

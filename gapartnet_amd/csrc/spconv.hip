@@ -53,7 +53,8 @@ template <int CT, int NT>
 __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
     const float* __restrict__ in, const float* __restrict__ dout, const int32_t* __restrict__ pair_src,
     const int32_t* __restrict__ pair_dst, const int32_t* __restrict__ tile_off, int64_t n_tiles, int cin,
-    int S, float* __restrict__ partial) {
+    int S, float* __restrict__ partial, int cigs, const float* __restrict__ in2, const float* __restrict__ dout2,
+    float* __restrict__ partial2) {
   constexpr int T = 64;  // pairs per tile
   constexpr int COUT = NT * 16;
   constexpr int PA = LdsPitch<CT * 16>::value, PB = LdsPitch<COUT>::value;
@@ -64,7 +65,12 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
   float* sA = smem;
   float* sB = smem + T * PA;
 
-  const int k = blockIdx.x, s = blockIdx.y, cig = blockIdx.z;
+  const int k = blockIdx.x, s = blockIdx.y;
+  int cig = blockIdx.z;
+  if (cig >= cigs) {  // second network of a paired pass (same rulebook, same shapes): gridDim.z = 2 * cigs
+    cig -= cigs;
+    in = in2, dout = dout2, partial = partial2;
+  }
   const int K = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
@@ -177,11 +183,11 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
 }
 
 // dW[e] = sum_s partial[s][e]: 16 lanes per element stride over the slices, then a fixed-order shuffle tree
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t elems,
-                                                           int K, int cin, int cout, int oki,
-                                                           float* __restrict__ dW) {
+// (block `blk` of cdiv(elems, 16) blocks of 256 threads)
+__device__ __forceinline__ void wgrad_reduce_tree(const float* __restrict__ partial, int S, int64_t elems, int K, int cin,
+                                                  int cout, int oki, float* __restrict__ dW, uint32_t blk) {
   const int part = threadIdx.x & 15;
-  const int64_t e = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t e = (int64_t)blk * 16 + (threadIdx.x >> 4);
   float acc = 0.f;
   if (e < elems) {
     // four slices in flight per lane (same order of additions): with one load per iteration the loop was a chain of
@@ -216,9 +222,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // slice order with every load in flight together - coalesced across the threads of a wave.  The 16-lane form above reads
 // 16 slices per element at once, i.e. sixteen 16-byte pieces per wave load: 22 us for the 8 MB of a 64 -> 64 layer's
 // partials (0.36 TB/s).  Sum order: slice 0, 1, 2, ... (deterministic; differs from the tree above in the last bits).
-__global__ __launch_bounds__(256) void wgrad_reduce_few_kernel(const float* __restrict__ partial, int S, int64_t elems, int K,
-                                                               int cin, int cout, int oki, float* __restrict__ dW) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// (block `blk` of cdiv(elems, 256) blocks of 256 threads)
+__device__ __forceinline__ void wgrad_reduce_few(const float* __restrict__ partial, int S, int64_t elems, int K, int cin,
+                                                 int cout, int oki, float* __restrict__ dW, uint32_t blk) {
+  const int64_t e = (int64_t)blk * 256 + threadIdx.x;
   if (e >= elems) return;
   const float* __restrict__ p = partial + e;
   float acc = 0.f;
@@ -239,6 +246,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_few_kernel(const float* __re
     o = ((int64_t)co * K + k) * cin + ci;  // gradient in the parameter's own [Cout][K][Cin] layout
   }
   dW[o] = acc;
+}
+
+// The slice sums of up to kWgradReduceJobs layers in ONE launch (the executor defers them: a contraction writes its partials
+// to its own piece of the workspace and the sums of a batch of layers run together - ~100 reduce launches of 3-8 us per
+// training step, each a dependent launch on the weight-gradient stream, become ~15).  The job table travels as a kernel
+// argument; a workgroup finds its job by a scan of the (uniform) block offsets.
+struct ReduceBatch {
+  int n;
+  uint32_t block_end[gpn::kWgradReduceJobs];  // exclusive prefix of the jobs' block counts
+  gpn::WgradReduceJob job[gpn::kWgradReduceJobs];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const ReduceBatch b) {
+  int j = 0;
+  while (j + 1 < b.n && blockIdx.x >= b.block_end[j]) ++j;
+  const uint32_t blk = blockIdx.x - (j ? b.block_end[j - 1] : 0u);
+  const gpn::WgradReduceJob& q = b.job[j];
+  if (q.few) wgrad_reduce_few(q.partial, q.S, q.elems, q.K, q.cin, q.cout, q.oki, q.dW, blk);
+  else wgrad_reduce_tree(q.partial, q.S, q.elems, q.K, q.cin, q.cout, q.oki, q.dW, blk);
 }
 
 int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
@@ -276,12 +301,12 @@ int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
 template <int CT, int NT>
 int launch_wgrad(const float* in, const float* dout, const int32_t* pair_src, const int32_t* pair_dst,
                  const int32_t* tile_off, int K, int64_t n_dst, int cin, int S, float* partial,
-                 hipStream_t stream) {
+                 const gpn::WgradTwin& twin, hipStream_t stream) {
   const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
   const int ct_tiles = cin / 16;
   const int cig = (ct_tiles + CT - 1) / CT;
-  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), dim3(K, S, cig), dim3(256), 0, stream, in, dout, pair_src,
-                     pair_dst, tile_off, n_tiles, cin, S, partial);
+  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), dim3(K, S, twin.in ? 2 * cig : cig), dim3(256), 0, stream, in, dout,
+                     pair_src, pair_dst, tile_off, n_tiles, cin, S, partial, cig, twin.in, twin.dout, twin.partial);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -289,10 +314,10 @@ int launch_wgrad(const float* in, const float* dout, const int32_t* pair_src, co
 template <int CT>
 int dispatch_wgrad_nt(int nt, const float* in, const float* dout, const int32_t* pair_src,
                       const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin, int S,
-                      float* partial, hipStream_t stream) {
+                      float* partial, const gpn::WgradTwin& twin, hipStream_t stream) {
   switch (nt) {
 #define GPN_CASE(N) \
-  case N: return launch_wgrad<CT, N>(in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream);
+  case N: return launch_wgrad<CT, N>(in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
     GPN_CASE(1) GPN_CASE(2) GPN_CASE(3) GPN_CASE(4) GPN_CASE(5) GPN_CASE(6) GPN_CASE(7) GPN_CASE(8)
 #undef GPN_CASE
     default:
@@ -396,6 +421,53 @@ extern "C" size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_
   return gpn::align_up((size_t)S * K * cin * cout * sizeof(float));
 }
 
+namespace gpn {
+
+int wgrad_slices(int K, int cin, int cout, int64_t n_dst) { return wgrad_splits(K, cin, cout, n_dst); }
+
+// the contraction of one layer (and of the same layer of a second network, `twin`) into partial[S][K][cin][cout]
+int wgrad_contract(const float* in, const float* dout, const int32_t* pair_src, const int32_t* pair_dst, const int32_t* tile_off,
+                   int K, int64_t n_dst, int cin, int cout, int S, float* partial, const WgradTwin& twin, hipStream_t stream) {
+  const int ct_tiles = cin / 16;
+  const int CT = ct_tiles < 4 ? ct_tiles : 4;
+  const int nt = cout / 16;
+  gpn::ProfScope prof(GPN_K_SPCONV_WGRAD, stream, 0.0, 0.0);
+  switch (CT) {
+    case 1: return dispatch_wgrad_nt<1>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
+    case 2: return dispatch_wgrad_nt<2>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
+    case 3: return dispatch_wgrad_nt<3>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
+    default: return dispatch_wgrad_nt<4>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
+  }
+}
+
+WgradReduceJob wgrad_reduce_job(const float* partial, int S, int K, int cin, int cout, int flags, float* dW) {
+  WgradReduceJob q;
+  q.partial = partial, q.dW = dW;
+  q.elems = (int64_t)K * cin * cout;
+  q.S = S, q.K = K, q.cin = cin, q.cout = cout;
+  q.oki = (flags & GPN_LAYOUT_OKI) ? 1 : 0;
+  q.few = (S <= 32 && q.elems >= 16384) ? 1 : 0;
+  return q;
+}
+
+int wgrad_reduce_many(const WgradReduceJob* jobs, int n, hipStream_t stream) {
+  if (n <= 0) return GPN_OK;
+  GPN_CHECK_ARG(n <= kWgradReduceJobs);
+  ReduceBatch b;
+  b.n = n;
+  uint32_t blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    b.job[j] = jobs[j];
+    blocks += (uint32_t)gpn::cdiv(jobs[j].elems, jobs[j].few ? 256 : 16);
+    b.block_end[j] = blocks;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(blocks), dim3(256), 0, stream, b);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+}  // namespace gpn
+
 extern "C" int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src,
                                 const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
                                 int cout, int flags, float* dW, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
@@ -414,28 +486,10 @@ extern "C" int gpn_spconv_wgrad(const float* in, const float* dout, const int32_
     return GPN_ERR_WS;
   }
   float* partial = static_cast<float*>(ws);
-  const int ct_tiles = cin / 16;
-  const int CT = ct_tiles < 4 ? ct_tiles : 4;
-  const int nt = cout / 16;
-  int rc;
-  {
-    gpn::ProfScope prof(GPN_K_SPCONV_WGRAD, stream, 0.0, 0.0);
-    switch (CT) {
-      case 1: rc = dispatch_wgrad_nt<1>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream); break;
-      case 2: rc = dispatch_wgrad_nt<2>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream); break;
-      case 3: rc = dispatch_wgrad_nt<3>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream); break;
-      default: rc = dispatch_wgrad_nt<4>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, stream); break;
-    }
-  }
+  int rc = gpn::wgrad_contract(in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, cout, S, partial, gpn::WgradTwin{}, stream);
   if (rc != GPN_OK) return rc;
-  if (S <= 32 && elems >= 16384)
-    hipLaunchKernelGGL(wgrad_reduce_few_kernel, dim3((unsigned)gpn::cdiv(elems, 256)), dim3(256), 0, stream, partial, S, elems, K,
-                       cin, cout, (flags & GPN_LAYOUT_OKI) ? 1 : 0, dW);
-  else
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gpn::cdiv(elems, 16)), dim3(256), 0, stream, partial, S,
-                       elems, K, cin, cout, (flags & GPN_LAYOUT_OKI) ? 1 : 0, dW);
-  GPN_CHECK_LAUNCH();
-  return GPN_OK;
+  const gpn::WgradReduceJob job = gpn::wgrad_reduce_job(partial, S, K, cin, cout, flags, dW);
+  return gpn::wgrad_reduce_many(&job, 1, stream);
 }
 
 extern "C" int gpn_gather_rows(const float* table, const int32_t* idx, int64_t n, int C, float* out,
