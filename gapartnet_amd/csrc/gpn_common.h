@@ -121,10 +121,16 @@ int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr
                         int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream);
 // weight-gradient contraction and its (batched) slice sums (spconv.hip); used by gpn_spconv_wgrad and the network executor
 constexpr int kWgradReduceJobs = 24;
-struct WgradTwin {  // the same layer of a second network (paired pass): same rulebook, same shapes
-  const float* in = nullptr;
-  const float* dout = nullptr;
-  float* partial = nullptr;
+constexpr int kWgradSets = 4;
+struct WgradSet {  // one layer's operands
+  const float* in;
+  const float* dout;
+  const int32_t *pair_src, *pair_dst, *tile_off;
+  float* partial;
+};
+struct WgradSets {  // layers of one shape contracted by one launch (kernel argument)
+  int n = 0;
+  WgradSet s[kWgradSets];
 };
 struct WgradReduceJob {
   const float* partial;
@@ -133,8 +139,7 @@ struct WgradReduceJob {
   int S, K, cin, cout, oki, few;
 };
 int wgrad_slices(int K, int cin, int cout, int64_t n_dst);
-int wgrad_contract(const float* in, const float* dout, const int32_t* pair_src, const int32_t* pair_dst, const int32_t* tile_off,
-                   int K, int64_t n_dst, int cin, int cout, int S, float* partial, const WgradTwin& twin, hipStream_t stream);
+int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream);
 WgradReduceJob wgrad_reduce_job(const float* partial, int S, int K, int cin, int cout, int flags, float* dW);
 int wgrad_reduce_many(const WgradReduceJob* jobs, int n, hipStream_t stream);
 // gpn_rulebook_level_counts with row count and level-0 extent on the device (rulebook.hip; used by gpn_voxelize_scenes)

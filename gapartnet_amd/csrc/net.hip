@@ -453,6 +453,18 @@ namespace {
 // waits) off the thread that issues the dgrad / BatchNorm chain shortens the host side of the pass by about a third.
 // Protocol: the caller publishes jobs (plain structs) through an atomic counter while the pass runs; the worker spins
 // on the counter during a pass and sleeps on a condition variable between passes.
+// layers per weight-gradient contraction launch (1 ... gpn::kWgradSets; env GPN_WGRAD_GROUP)
+std::atomic<int> g_wgrad_group{[] {
+  const char* e = getenv("GPN_WGRAD_GROUP");
+  const int v = e ? atoi(e) : gpn::kWgradSets;
+  return v < 1 ? 1 : (v > gpn::kWgradSets ? gpn::kWgradSets : v);
+}()};
+
+const int64_t g_wgrad_group_rows = [] {  // only layers with fewer rows than this share a launch (env GPN_WGRAD_GROUP_ROWS)
+  const char* e = getenv("GPN_WGRAD_GROUP_ROWS");
+  return (int64_t)(e ? atoll(e) : 16384);
+}();
+
 struct WgradJob {
   const float* in;
   const float* dout;
@@ -535,34 +547,70 @@ class WgradWorker {
         n_pending = 0;
         used = 0;
       };
-      auto issue = [&](const WgradJob& j) -> int {
-        if (hipStreamWaitEvent(side_, j.after, 0) != hipSuccess) {
+      // consecutive jobs of one shape (the convs of a level's residual blocks; the two networks of a paired pass) are
+      // contracted by ONE launch of up to kWgradSets layers: held back until a job of another shape arrives or the pass ends
+      // (on the deep levels a contraction is a 15-40 us latency chain over a few hundred workgroups: together they overlap)
+      WgradJob group[gpn::kWgradSets];
+      int n_group = 0, group_sets = 0;
+      auto same_shape = [](const WgradJob& a, const WgradJob& b) {
+        return a.K == b.K && a.n_dst == b.n_dst && a.cin == b.cin && a.cout == b.cout;
+      };
+      auto launch_group = [&]() -> int {
+        if (!n_group) return GPN_OK;
+        const WgradJob& j0 = group[0];
+        const int n = n_group, n_sets = group_sets;
+        n_group = 0, group_sets = 0;
+        // the events were recorded in job order on one stream: the last one covers the others
+        if (hipStreamWaitEvent(side_, group[n - 1].after, 0) != hipSuccess) {
           gpn::set_error("gpn_net_backward: hipStreamWaitEvent failed on the weight-gradient stream");
           return GPN_ERR_HIP;
         }
-        const size_t elems = (size_t)j.K * j.cin * j.cout;
-        if (j.n_dst == 0) {
-          GPN_CHECK_HIP(hipMemsetAsync(j.dW, 0, sizeof(float) * elems, side_));
-          if (j.dW2) GPN_CHECK_HIP(hipMemsetAsync(j.dW2, 0, sizeof(float) * elems, side_));
+        const size_t elems = (size_t)j0.K * j0.cin * j0.cout;
+        if (j0.n_dst == 0) {
+          for (int g = 0; g < n; ++g) {
+            GPN_CHECK_HIP(hipMemsetAsync(group[g].dW, 0, sizeof(float) * elems, side_));
+            if (group[g].dW2) GPN_CHECK_HIP(hipMemsetAsync(group[g].dW2, 0, sizeof(float) * elems, side_));
+          }
           return GPN_OK;
         }
-        const int S = gpn::wgrad_slices(j.K, j.cin, j.cout, j.n_dst);
+        const int S = gpn::wgrad_slices(j0.K, j0.cin, j0.cout, j0.n_dst);
         const size_t bytes = gpn::align_up((size_t)S * elems * sizeof(float));
-        const int n_nets = j.dW2 ? 2 : 1;
-        if (used + n_nets * bytes > room || n_pending + n_nets > gpn::kWgradReduceJobs) flush();
-        if (n_nets * bytes > ws_bytes_ || !ws_) {
+        if (used + n_sets * bytes > room || n_pending + n_sets > gpn::kWgradReduceJobs) flush();
+        if (n_sets * bytes > ws_bytes_ || !ws_) {
           gpn::set_error("gpn_net_backward: weight-gradient workspace too small");
           return GPN_ERR_WS;
         }
-        float* partial = reinterpret_cast<float*>(static_cast<char*>(ws_) + used);
-        gpn::WgradTwin twin;
-        if (j.dW2) twin.in = j.in2, twin.dout = j.dout2, twin.partial = reinterpret_cast<float*>(static_cast<char*>(ws_) + used + bytes);
-        const int rc = gpn::wgrad_contract(j.in, j.dout, j.pair_src, j.pair_dst, j.tile_off, j.K, j.n_dst, j.cin, j.cout, S, partial,
-                                           twin, side_);
+        gpn::WgradSets sets;
+        float* dW_of[gpn::kWgradSets];
+        for (int g = 0; g < n; ++g) {
+          const WgradJob& j = group[g];
+          float* partial = reinterpret_cast<float*>(static_cast<char*>(ws_) + used + sets.n * bytes);
+          dW_of[sets.n] = j.dW;
+          sets.s[sets.n++] = gpn::WgradSet{j.in, j.dout, j.pair_src, j.pair_dst, j.tile_off, partial};
+          if (j.dW2) {
+            partial = reinterpret_cast<float*>(static_cast<char*>(ws_) + used + sets.n * bytes);
+            dW_of[sets.n] = j.dW2;
+            sets.s[sets.n++] = gpn::WgradSet{j.in2, j.dout2, j.pair_src, j.pair_dst, j.tile_off, partial};
+          }
+        }
+        const int rc = gpn::wgrad_contract(sets, j0.K, j0.n_dst, j0.cin, j0.cout, S, side_);
         if (rc != GPN_OK) return rc;
-        pending[n_pending++] = gpn::wgrad_reduce_job(partial, S, j.K, j.cin, j.cout, GPN_LAYOUT_OKI, j.dW);
-        if (j.dW2) pending[n_pending++] = gpn::wgrad_reduce_job(twin.partial, S, j.K, j.cin, j.cout, GPN_LAYOUT_OKI, j.dW2);
-        used += n_nets * bytes;
+        for (int q = 0; q < sets.n; ++q)
+          pending[n_pending++] = gpn::wgrad_reduce_job(sets.s[q].partial, S, j0.K, j0.cin, j0.cout, GPN_LAYOUT_OKI, dW_of[q]);
+        used += sets.n * bytes;
+        return GPN_OK;
+      };
+      auto issue = [&](const WgradJob& j) -> int {
+        const int n_sets = j.dW2 ? 2 : 1;
+        // (a layer with many rows fills the chip on its own: holding it back only delays it)
+        const int limit = j.n_dst < g_wgrad_group_rows ? g_wgrad_group.load(std::memory_order_relaxed) : 1;
+        if (n_group && (!same_shape(group[0], j) || group_sets + n_sets > limit)) {
+          const int rc = launch_group();
+          if (rc != GPN_OK) return rc;
+        }
+        group[n_group++] = j;
+        group_sets += n_sets;
+        if (group_sets >= limit) return launch_group();
         return GPN_OK;
       };
       for (;;) {
@@ -577,6 +625,10 @@ class WgradWorker {
         } else {
           std::this_thread::yield();  // nothing published yet: give the core away (8 ranks share the host's cores)
         }
+      }
+      if (rc_ == GPN_OK) {
+        const int rc = launch_group();
+        if (rc != GPN_OK) fail(rc);
       }
       flush();
       finished_.store(true, std::memory_order_release);

@@ -51,10 +51,7 @@ struct LdsPitch {  // floats per LDS row for W payload floats: pitch % 64 in {16
 
 template <int CT, int NT>
 __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
-    const float* __restrict__ in, const float* __restrict__ dout, const int32_t* __restrict__ pair_src,
-    const int32_t* __restrict__ pair_dst, const int32_t* __restrict__ tile_off, int64_t n_tiles, int cin,
-    int S, float* __restrict__ partial, int cigs, const float* __restrict__ in2, const float* __restrict__ dout2,
-    float* __restrict__ partial2) {
+    const gpn::WgradSets sets, int64_t n_tiles, int cin, int S, int cigs) {
   constexpr int T = 64;  // pairs per tile
   constexpr int COUT = NT * 16;
   constexpr int PA = LdsPitch<CT * 16>::value, PB = LdsPitch<COUT>::value;
@@ -66,11 +63,15 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
   float* sB = smem + T * PA;
 
   const int k = blockIdx.x, s = blockIdx.y;
-  int cig = blockIdx.z;
-  if (cig >= cigs) {  // second network of a paired pass (same rulebook, same shapes): gridDim.z = 2 * cigs
-    cig -= cigs;
-    in = in2, dout = dout2, partial = partial2;
-  }
+  // gridDim.z = (layers in this launch) x (Cin groups): layers of one shape - the same layer of the two networks of a paired
+  // pass, consecutive layers of a level - are contracted by one launch (uniform per workgroup: scalar loads of the set)
+  const int set = blockIdx.z / cigs, cig = blockIdx.z - set * cigs;
+  const float* __restrict__ in = sets.s[set].in;
+  const float* __restrict__ dout = sets.s[set].dout;
+  const int32_t* __restrict__ pair_src = sets.s[set].pair_src;
+  const int32_t* __restrict__ pair_dst = sets.s[set].pair_dst;
+  const int32_t* __restrict__ tile_off = sets.s[set].tile_off;
+  float* __restrict__ partial = sets.s[set].partial;
   const int K = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
@@ -299,25 +300,21 @@ int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
 }
 
 template <int CT, int NT>
-int launch_wgrad(const float* in, const float* dout, const int32_t* pair_src, const int32_t* pair_dst,
-                 const int32_t* tile_off, int K, int64_t n_dst, int cin, int S, float* partial,
-                 const gpn::WgradTwin& twin, hipStream_t stream) {
+int launch_wgrad(const gpn::WgradSets& sets, int K, int64_t n_dst, int cin, int S, hipStream_t stream) {
   const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
   const int ct_tiles = cin / 16;
   const int cig = (ct_tiles + CT - 1) / CT;
-  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), dim3(K, S, twin.in ? 2 * cig : cig), dim3(256), 0, stream, in, dout,
-                     pair_src, pair_dst, tile_off, n_tiles, cin, S, partial, cig, twin.in, twin.dout, twin.partial);
+  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), dim3(K, S, sets.n * cig), dim3(256), 0, stream, sets, n_tiles, cin, S,
+                     cig);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
 template <int CT>
-int dispatch_wgrad_nt(int nt, const float* in, const float* dout, const int32_t* pair_src,
-                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin, int S,
-                      float* partial, const gpn::WgradTwin& twin, hipStream_t stream) {
+int dispatch_wgrad_nt(int nt, const gpn::WgradSets& sets, int K, int64_t n_dst, int cin, int S, hipStream_t stream) {
   switch (nt) {
 #define GPN_CASE(N) \
-  case N: return launch_wgrad<CT, N>(in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
+  case N: return launch_wgrad<CT, N>(sets, K, n_dst, cin, S, stream);
     GPN_CASE(1) GPN_CASE(2) GPN_CASE(3) GPN_CASE(4) GPN_CASE(5) GPN_CASE(6) GPN_CASE(7) GPN_CASE(8)
 #undef GPN_CASE
     default:
@@ -425,18 +422,18 @@ namespace gpn {
 
 int wgrad_slices(int K, int cin, int cout, int64_t n_dst) { return wgrad_splits(K, cin, cout, n_dst); }
 
-// the contraction of one layer (and of the same layer of a second network, `twin`) into partial[S][K][cin][cout]
-int wgrad_contract(const float* in, const float* dout, const int32_t* pair_src, const int32_t* pair_dst, const int32_t* tile_off,
-                   int K, int64_t n_dst, int cin, int cout, int S, float* partial, const WgradTwin& twin, hipStream_t stream) {
+// the contraction of sets.n layers of ONE shape (K, n_dst, cin, cout) into their partial[S][K][cin][cout] buffers
+int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream) {
+  GPN_CHECK_ARG(sets.n >= 1 && sets.n <= kWgradSets);
   const int ct_tiles = cin / 16;
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int nt = cout / 16;
   gpn::ProfScope prof(GPN_K_SPCONV_WGRAD, stream, 0.0, 0.0);
   switch (CT) {
-    case 1: return dispatch_wgrad_nt<1>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
-    case 2: return dispatch_wgrad_nt<2>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
-    case 3: return dispatch_wgrad_nt<3>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
-    default: return dispatch_wgrad_nt<4>(nt, in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, S, partial, twin, stream);
+    case 1: return dispatch_wgrad_nt<1>(nt, sets, K, n_dst, cin, S, stream);
+    case 2: return dispatch_wgrad_nt<2>(nt, sets, K, n_dst, cin, S, stream);
+    case 3: return dispatch_wgrad_nt<3>(nt, sets, K, n_dst, cin, S, stream);
+    default: return dispatch_wgrad_nt<4>(nt, sets, K, n_dst, cin, S, stream);
   }
 }
 
@@ -486,7 +483,10 @@ extern "C" int gpn_spconv_wgrad(const float* in, const float* dout, const int32_
     return GPN_ERR_WS;
   }
   float* partial = static_cast<float*>(ws);
-  int rc = gpn::wgrad_contract(in, dout, pair_src, pair_dst, tile_off, K, n_dst, cin, cout, S, partial, gpn::WgradTwin{}, stream);
+  gpn::WgradSets sets;
+  sets.n = 1;
+  sets.s[0] = gpn::WgradSet{in, dout, pair_src, pair_dst, tile_off, partial};
+  int rc = gpn::wgrad_contract(sets, K, n_dst, cin, cout, S, stream);
   if (rc != GPN_OK) return rc;
   const gpn::WgradReduceJob job = gpn::wgrad_reduce_job(partial, S, K, cin, cout, flags, dW);
   return gpn::wgrad_reduce_many(&job, 1, stream);
