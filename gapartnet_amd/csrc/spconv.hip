@@ -272,7 +272,9 @@ int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int cig = (ct_tiles + CT - 1) / CT;
   // enough pair slices for ~4096 workgroups (each slice is a latency-bound gather loop), at least ~128 dst rows per slice,
-  // and at most 8 MB of partials (they are written and re-read by the reduce).  Swept in the training step, round 3
+  // and at most 4 MB of partials (they are written and re-read by the slice sums, through the L2s the dgrad chain's gathers
+  // live in: with the sums deferred and batched, interleaved runs on one box gave 9.42 / 9.36 / 9.08 ms per step at 8 / 6 / 4 MB,
+  // 8.63 / 9.10 / 9.70 at 4 / 3 / 2 on another, 8.90 / 9.29 / 9.36 at 8 / 16 / 32 on a third).  Earlier sweeps, round 3
   // (profiles/r03_findings.md): rows per slice 32 / 64 / 128 / 384 / 768 / 1536 -> 9.43 / 9.5 / 8.9 / 9.0 / 9.4 / 9.95 ms per
   // step; partial cap 2 / 3 / 4 / 6 / 8 / 16 MB -> 10.3 / 9.8 / 9.1 / 9.7 / 9.3 / 9.5 ms in single runs (box noise +-0.3), and
   // 4 MB (with the thread-per-element reduce up to 64 slices) 9.32 vs 9.16 ms for 8 MB in an interleaved same-box A/B.
@@ -283,7 +285,7 @@ int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
   }();
   static const int64_t partial_mb = [] {
     const char* e = getenv("GPN_WGRAD_PARTIAL_MB");
-    return (int64_t)(e ? atoll(e) : 8);
+    return (int64_t)(e ? atoll(e) : 4);
   }();
   int64_t S = target_wgs / ((int64_t)K * cig);
   static const int64_t rows_per_slice = [] {
