@@ -129,7 +129,11 @@ inline size_t slot_bytes(const gpn_net_slot_t& s) { return (size_t)s.rows * s.ch
 
 // partials of the layers whose slice sums are batched into one launch: at most this much (they are written and read back
 // within a few launches - the bound keeps them inside the 256 MB memory-side cache)
-constexpr size_t kWgradBatchBytes = (size_t)96 << 20;
+const size_t kWgradBatchBytes = [] {  // env GPN_WGRAD_BATCH_MB
+  const char* e = getenv("GPN_WGRAD_BATCH_MB");
+  const long long mb = e ? atoll(e) : 96;
+  return (size_t)(mb < 1 ? 1 : mb) << 20;
+}();
 
 struct Need {
   size_t tmp = 0;     // gradient staging buffer (largest slot that can receive a second gradient)
