@@ -13,6 +13,9 @@
 //    while the next tile's gathers and the one after's indices are in flight; fixed-order reductions over the 4 waves (LDS)
 //    and over the slices (a second launch: 16 lanes per element for many slices, a thread per element - coalesced - for
 //    <= 32) => deterministic.  The kernel is bound by gather bandwidth out of L2 (each row is re-read once per pair).
+//    One launch contracts up to kWgradSets layers of one shape (gpn::wgrad_contract) and one launch sums the slices of up
+//    to kWgradReduceJobs layers (gpn::wgrad_reduce_many): the executor (net.hip) defers and batches, gpn_spconv_wgrad is
+//    the one-layer case of both.
 //  * gather_rows / scatter_rows_csr: features[pc_voxel_id] and its transpose as an ordered CSR sum (deterministic).
 #include <cstdlib>
 

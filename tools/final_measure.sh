@@ -16,6 +16,16 @@ if [ -n "$f" ]; then python "$R/tools/step_sequence.py" "$f" > "$O/step_sequence
 cp "$O/profile_summary.json" "$R/profiles/profile_summary.json" 2>/dev/null
 timeout 240 python "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err" < /dev/null; cut -c1-260 "$O/bench_default.json"
 for i in 1 2 3; do timeout 240 python "$R/bench.py" --no-cpu-baseline > "$O/bench_default_run$i.json" 2> /dev/null < /dev/null; done  # run-to-run spread on this box
+timeout 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/p_sq -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+f=$(find /tmp/p_sq -name "*counter_collection.csv" 2>/dev/null | head -1)
+if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_sq.txt" 2>&1 < /dev/null; fi
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+  f=$(find /tmp/p_$c -name "*counter_collection.csv" 2>/dev/null | head -1)
+  if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_$c.txt" 2>&1 < /dev/null; fi
+done
+f1=$O/pmc_FETCH_SIZE.txt; f2=$O/pmc_WRITE_SIZE.txt
+if [ -s "$f1" ] && [ -s "$f2" ]; then (cd "$R" && python tools/pmc_traffic.py "$f1" "$f2" "$O/traffic.json" spconv_fwd,spconv_tiles > /dev/null 2>&1); fi
 GPN_BENCH_FORCE_GRAD_SYNC=1 timeout 240 python "$R/bench.py" --no-cpu-baseline > "$O/bench_forced_grad_sync.json" 2> /dev/null < /dev/null
 for cfg in "--schedule 5,10" "--points 50000 --batch 4" "--batch 32"; do
   tag=$(echo "$cfg" | tr -d ' -' | tr ',' '_')
@@ -39,14 +49,4 @@ for v in "" "--freeze-convs" "--no-bn-fuse"; do
   if [ -n "$f" ]; then python "$R/tools/fwd_bwd_split.py" "$f" > "$O/$tag.txt" 2>&1 < /dev/null; fi
   (cd "$R" && timeout 200 python tools/step_loop.py $v 2>/dev/null | tail -1 >> "$O/$tag.txt")
 done
-timeout 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/p_sq -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
-f=$(find /tmp/p_sq -name "*counter_collection.csv" 2>/dev/null | head -1)
-if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_sq.txt" 2>&1 < /dev/null; fi
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
-  f=$(find /tmp/p_$c -name "*counter_collection.csv" 2>/dev/null | head -1)
-  if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_$c.txt" 2>&1 < /dev/null; fi
-done
-f1=$O/pmc_FETCH_SIZE.txt; f2=$O/pmc_WRITE_SIZE.txt
-if [ -s "$f1" ] && [ -s "$f2" ]; then (cd "$R" && python tools/pmc_traffic.py "$f1" "$f2" "$O/traffic.json" spconv_fwd,spconv_tiles > /dev/null 2>&1); fi
 ls -la "$O"
