@@ -32,10 +32,14 @@ constexpr int kThreads = 256;
 
 // BatchNorm sums in the conv epilogues (bn_stats.h) on / off: env GPN_BN_FUSE=0 or gpn_net_bn_fusion(0) restores the separate
 // statistics launches (A/B measurements, and the tests that compare the two forms)
-std::atomic<int> g_bn_fusion{[] {
+// (the environment readers of this file are NAMED functions: hipcc numbers the lambdas of namespace-scope initialisers per
+// anonymous-namespace block, so a lambda in a second block got the mangled name - and, at link time, the body - of the first
+// block's: a knob that silently read another knob's variable)
+int env_bn_fusion() {
   const char* e = getenv("GPN_BN_FUSE");
   return e ? atoi(e) : 1;
-}()};
+}
+std::atomic<int> g_bn_fusion{env_bn_fusion()};
 
 // dst[r, 0:ca] = a[r, :], dst[r, ca:ca+cb] = b[r, :]   (float4 granularity; channel counts are multiples of 4).  Two pointer
 // sets per launch, picked by blockIdx.y (paired passes, see NetSet below)
@@ -129,11 +133,12 @@ inline size_t slot_bytes(const gpn_net_slot_t& s) { return (size_t)s.rows * s.ch
 
 // partials of the layers whose slice sums are batched into one launch: at most this much (they are written and read back
 // within a few launches - the bound keeps them inside the 256 MB memory-side cache)
-const size_t kWgradBatchBytes = [] {  // env GPN_WGRAD_BATCH_MB
+size_t env_wgrad_batch_bytes() {  // env GPN_WGRAD_BATCH_MB
   const char* e = getenv("GPN_WGRAD_BATCH_MB");
   const long long mb = e ? atoll(e) : 96;
   return (size_t)(mb < 1 ? 1 : mb) << 20;
-}();
+}
+const size_t kWgradBatchBytes = env_wgrad_batch_bytes();
 
 struct Need {
   size_t tmp = 0;     // gradient staging buffer (largest slot that can receive a second gradient)
@@ -457,17 +462,21 @@ namespace {
 // waits) off the thread that issues the dgrad / BatchNorm chain shortens the host side of the pass by about a third.
 // Protocol: the caller publishes jobs (plain structs) through an atomic counter while the pass runs; the worker spins
 // on the counter during a pass and sleeps on a condition variable between passes.
-// layers per weight-gradient contraction launch (1 ... gpn::kWgradSets; env GPN_WGRAD_GROUP)
-std::atomic<int> g_wgrad_group{[] {
+// layers per weight-gradient contraction launch (1 ... gpn::kWgradSets; env GPN_WGRAD_GROUP).  Default 1 = only the two
+// networks of a paired pass share a launch: that is what every measurement of round 3 ran (the knob was unreadable, see the
+// note at env_bn_fusion); consecutive same-shape layers in one launch (2 ... 4) are implemented and not yet measured.
+int env_wgrad_group() {
   const char* e = getenv("GPN_WGRAD_GROUP");
-  const int v = e ? atoi(e) : gpn::kWgradSets;
+  const int v = e ? atoi(e) : 1;
   return v < 1 ? 1 : (v > gpn::kWgradSets ? gpn::kWgradSets : v);
-}()};
+}
+std::atomic<int> g_wgrad_group{env_wgrad_group()};
 
-const int64_t g_wgrad_group_rows = [] {  // only layers with fewer rows than this share a launch (env GPN_WGRAD_GROUP_ROWS)
+int64_t env_wgrad_group_rows() {  // only layers with fewer rows than this share a launch (env GPN_WGRAD_GROUP_ROWS)
   const char* e = getenv("GPN_WGRAD_GROUP_ROWS");
   return (int64_t)(e ? atoll(e) : 16384);
-}();
+}
+const int64_t g_wgrad_group_rows = env_wgrad_group_rows();
 
 struct WgradJob {
   const float* in;
