@@ -45,6 +45,23 @@ def test_entry_point_registry_matches_header(lib):
     assert lib.gpn_version() >= 1
 
 
+def test_every_environment_switch_of_the_sources_is_in_the_binary(lib):
+    """every ``getenv("GPN_...")`` of csrc/ must survive into libgpn_hip.so under its own name.  hipcc numbers the lambdas of
+    namespace-scope initialisers per anonymous-namespace block: a reader written as such a lambda in a second block took the
+    mangled name - and the body - of the first block's, so GPN_WGRAD_GROUP silently read GPN_BN_FUSE for a whole round and
+    its name was simply absent from the object (profiles/r03_findings.md).  An absent name = an unreadable switch."""
+    from gapartnet_amd import _C
+    csrc = os.path.join(ROOT, "gapartnet_amd", "csrc")
+    names = set()
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h")):
+            names.update(re.findall(r'getenv\("(GPN_[A-Z0-9_]+)"\)', open(os.path.join(csrc, fn)).read()))
+    assert len(names) >= 10
+    blob = open(_C.SO_PATH, "rb").read()
+    missing = sorted(n for n in names if (n.encode() + b"\0") not in blob)
+    assert not missing, f"environment switches compiled away (aliased initialisers?): {missing}"
+
+
 def test_argument_errors_do_not_touch_the_device(lib):
     lib.gpn_last_error.restype = ctypes.c_char_p
     rc = lib.gpn_spconv_fwd(None, None, None, ctypes.c_int(27), ctypes.c_int64(10), ctypes.c_int(15), ctypes.c_int(16), None,
