@@ -472,12 +472,16 @@ __global__ __launch_bounds__(kThreads) void score_loss_kernel(const float* __res
                                                               float* __restrict__ loss, float* __restrict__ score_preds,
                                                               float* __restrict__ d_logits) {
   __shared__ double scratch[4];
-  double acc = 0.0;
+  double acc = 0.0, bad = 0.0;
   const float inv_p = 1.0f / (float)P;
   for (int64_t p = threadIdx.x; p < P; p += kThreads) {
     const int32_t first = offsets[p];
     const int64_t cls = cls64 ? cls64[first] : (int64_t)cls32[first];
     const int col = (int)(cls - 1);
+    // a proposal whose class is outside 1 .. C1 (e.g. a ground-truth label 0 under its first point): the reference's
+    // gather(1, cls - 1) raises an index error there.  No host read here, so the failure is made loud instead: the loss
+    // comes out NaN (and the gradient of that proposal stays zero) rather than a silently different number.
+    if (col < 0 || col >= C1) bad += 1.0;
     float iou = ious[p * I];
     for (int q = 1; q < I; ++q) iou = fmaxf(iou, ious[p * I + q]);
     const bool is_fg = iou > fg;
@@ -492,7 +496,9 @@ __global__ __launch_bounds__(kThreads) void score_loss_kernel(const float* __res
     if (col >= 0 && col < C1) d_logits[p * C1 + col] = (sig - t) * inv_p;
   }
   const double total = block_sum(acc, scratch);
-  if (threadIdx.x == 0) loss[0] = (float)(total / (double)P);
+  __syncthreads();
+  const double n_bad = block_sum(bad, scratch);
+  if (threadIdx.x == 0) loss[0] = n_bad > 0.0 ? __builtin_nanf("") : (float)(total / (double)P);
 }
 
 }  // namespace

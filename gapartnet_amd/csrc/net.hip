@@ -290,6 +290,15 @@ extern "C" int gpn_net_bn_fusion(int on) {
   return on < 0 ? g_bn_fusion.load(std::memory_order_relaxed) : g_bn_fusion.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
 
+namespace {
+std::atomic<int>& wgrad_group_setting();
+}
+extern "C" int gpn_net_wgrad_group(int layers) {
+  std::atomic<int>& g = wgrad_group_setting();
+  if (layers < 1) return g.load(std::memory_order_relaxed);
+  return g.exchange(layers > gpn::kWgradSets ? gpn::kWgradSets : layers, std::memory_order_relaxed);
+}
+
 extern "C" size_t gpn_net_ws_bytes(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, int n_slots,
                                    const gpn_net_rulebook_t* rulebooks, const gpn_net_conv_t* convs) {
   (void)n_slots;
@@ -462,15 +471,19 @@ namespace {
 // waits) off the thread that issues the dgrad / BatchNorm chain shortens the host side of the pass by about a third.
 // Protocol: the caller publishes jobs (plain structs) through an atomic counter while the pass runs; the worker spins
 // on the counter during a pass and sleeps on a condition variable between passes.
-// layers per weight-gradient contraction launch (1 ... gpn::kWgradSets; env GPN_WGRAD_GROUP).  Default 1 = only the two
-// networks of a paired pass share a launch: that is what every measurement of round 3 ran (the knob was unreadable, see the
-// note at env_bn_fusion); consecutive same-shape layers in one launch (2 ... 4) are implemented and not yet measured.
+// layers per weight-gradient contraction launch (1 ... gpn::kWgradSets; env GPN_WGRAD_GROUP, gpn_net_wgrad_group()).  1 = only
+// the two networks of a paired pass share a launch (what every measurement of round 3 ran: the knob was unreadable, see the
+// note at env_bn_fusion).  First measurement, round 4 (tools/wgrad_group_ab.sh, profiles/r04_wgrad_group_ab.txt): the grouped
+// path is bit-equal (48 executor / paired-pass / golden tests at 4), 90 -> 67 launches per step on the weight-gradient stream,
+// step time 8.79 / 8.78 / 8.72 ms mean of three interleaved runs at 1 / 2 / 4 - inside the noise, fewer launches for the helper
+// thread to issue: default 4.
 int env_wgrad_group() {
   const char* e = getenv("GPN_WGRAD_GROUP");
-  const int v = e ? atoi(e) : 1;
+  const int v = e ? atoi(e) : 4;
   return v < 1 ? 1 : (v > gpn::kWgradSets ? gpn::kWgradSets : v);
 }
 std::atomic<int> g_wgrad_group{env_wgrad_group()};
+std::atomic<int>& wgrad_group_setting() { return g_wgrad_group; }
 
 int64_t env_wgrad_group_rows() {  // only layers with fewer rows than this share a launch (env GPN_WGRAD_GROUP_ROWS)
   const char* e = getenv("GPN_WGRAD_GROUP_ROWS");

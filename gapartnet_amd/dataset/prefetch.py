@@ -98,8 +98,20 @@ class DevicePrefetcher:
             self._ahead = self._prepare(self._pending)
             self._pending = None
 
+    def _mark_consumer(self):
+        """order everything the side stream does from now on behind what the training stream has been given so far"""
+        mark = torch.cuda.Event()
+        mark.record(torch.cuda.current_stream(self.device))
+        self._consumer_mark = mark
+
     def __iter__(self):
         it = iter(self.batches)
+        # Invariant of the ordering scheme below: a batch may be used by the training stream until the next-but-one batch is
+        # handed out.  A (re-)started iteration has no such history: the last batches of a previous pass over this object
+        # (or anything else the consumer still has in flight) may still be read by kernels enqueued AFTER the last mark,
+        # and their blocks are free for the side stream to reuse once `_held` was dropped - so the first preparation
+        # waits for the training stream as it stands now.
+        self._mark_consumer()
         self._ahead = self._prepare(next(it, None))
         self._pending, self._has_pending = None, False
         hook_owner = self.model if hasattr(self.model, "_prefetch_hook") else None
@@ -125,6 +137,12 @@ class DevicePrefetcher:
                 yield batch
                 self._prepare_pending()  # the consumer's step did not reach the hook (eval, early exit): prepare now
         finally:
+            # the batches held back are released here: whatever the side stream allocates next (a later iteration of this
+            # object) must come after every kernel the consumer enqueued on them
+            try:
+                self._mark_consumer()
+            except Exception:  # interpreter teardown: no device left to order against
+                self._consumer_mark = None
             self._held = (None, None)
             if hook_owner is not None:
                 hook_owner.__dict__["_prefetch_hook"] = None  # plain attribute; safe at interpreter teardown too

@@ -103,6 +103,9 @@ def estimate_pose_from_npcs_batched(xyz: torch.Tensor, npcs: torch.Tensor, offse
     picks = picks.to(dev).long()
     H = picks.shape[1]
     if xyz.is_cuda:  # the HIP entry point (csrc/pose.hip): two launches for all proposals and hypotheses
+        from .. import backend
+        if backend.raw().name != "hip":
+            raise RuntimeError("estimate_pose_from_npcs_batched on a GPU tensor needs the HIP library as the operator backend")
         return _fit_hip(xyz.to(f64).contiguous(), npcs.to(f64).contiguous(), offsets.contiguous(), picks.contiguous(), P, M, H,
                         stop_thrsh)
     src_pts, dst_pts = npcs.to(f64), xyz.to(f64)

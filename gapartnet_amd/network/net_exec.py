@@ -111,6 +111,8 @@ class NetProgram:
         self.grad_total = int(sum(self.grad_sizes))
         self.last_pgrad = None
         self._grad_cache = {}
+        self.retired_total = 0     # persistent gradient buffers replaced because somebody else held them (grad_buffer)
+        self.retired_in_a_row = 0
         self._static_tables = None
         self._anchor = torch.zeros(1, requires_grad=True)  # see _NetFn
         self.signature = self._signature(unet)
@@ -303,23 +305,73 @@ class NetProgram:
         if fresh:
             return make()
         cached = self._grad_cache.get(device)
-        if cached is None or any(v.shape != p.shape for v, p in zip(cached[1], params)) or _shared(cached, params):
+        if cached is None or any(v.shape != p.shape for v, p in zip(cached[1], params)):
             cached = make()
             self._grad_cache[device] = cached
+            self.retired_in_a_row = 0
+        elif _shared(cached, params):
+            cached = make()
+            self._grad_cache[device] = cached
+            # a buffer retired on EVERY pass means something keeps hold of the gradients (or the counts above are off): every
+            # gradient address then moves every step - FusedAdam re-learns its table, GradSync loses the in-place exchange
+            self.retired_total += 1
+            self.retired_in_a_row += 1
+            if self.retired_in_a_row == 8 and _REFCOUNTS is not None:
+                print("[gapartnet_amd] the persistent gradient buffer of a U-Net was replaced on 8 backward passes in a row: "
+                      "something holds references to its gradients past zero_grad() (clone what you keep), or "
+                      "GPN_NET_AUTOGRAD_PARAMS=1 is the form you want")
+        else:
+            self.retired_in_a_row = 0
         return cached
+
+
+def _calibrate_refcounts():
+    """The reference counts `_shared` compares against, MEASURED on a throw-away buffer with the statements `_shared` itself
+    uses - not constants of one CPython / torch build.  -> (references to an unshared view object, what a parameter's ``.grad``
+    adds to that, storage holders besides the views) or None when the private storage counter is not available (every
+    persistent buffer then counts as shared: private buffers per backward, slower but never overwritten under a holder)."""
+    try:
+        flat = torch.zeros(2)
+        views = list(flat.split([1, 1]))
+        param = nn.Parameter(torch.zeros(1))
+        base_use = torch._C._storage_Use_Count(flat.untyped_storage()._cdata) - len(views)
+        for i in range(len(views)):
+            v = views[i]
+            base_ref = sys.getrefcount(v)
+            break
+        param.grad = views[0]
+        for i in range(len(views)):
+            v = views[i]
+            with_grad = sys.getrefcount(v) if param.grad is v else base_ref
+            break
+        return base_ref, with_grad - base_ref, base_use
+    except Exception:
+        return None
+
+
+_REFCOUNTS = _calibrate_refcounts()
+_warned_no_counts = False
 
 
 def _shared(pair, params) -> bool:
     """is the persistent gradient buffer (or one of its per-parameter views) referenced by anything but the cache, the
-    parameters' own ``.grad`` and the program's ``last_pgrad``?"""
+    parameters' own ``.grad`` and the program's ``last_pgrad``?  Baselines from _calibrate_refcounts()."""
+    global _warned_no_counts
+    if _REFCOUNTS is None:
+        if not _warned_no_counts:
+            _warned_no_counts = True
+            print("[gapartnet_amd] reference counts of gradient buffers cannot be read in this interpreter / torch build: "
+                  "every backward pass of a U-Net uses a private gradient buffer (slower; no in-place gradient exchange)")
+        return True
+    base_ref, grad_ref, base_use = _REFCOUNTS
     flat, views = pair
-    # storage holders: the flat tensor, one per view, the temporary wrapper made by untyped_storage()
-    if torch._C._storage_Use_Count(flat.untyped_storage()._cdata) > len(views) + 2:
+    # storage holders: the flat tensor, one per view, the temporary wrapper made by untyped_storage() (= base_use, measured)
+    if torch._C._storage_Use_Count(flat.untyped_storage()._cdata) > len(views) + base_use:
         return True
     for i in range(len(views)):
         v = views[i]
         # references to the view object: the list slot, `v`, getrefcount's argument (+ the parameter's .grad)
-        if sys.getrefcount(v) > 3 + (1 if params[i].grad is v else 0):
+        if sys.getrefcount(v) > base_ref + (grad_ref if params[i].grad is v else 0):
             return True
     return False
 

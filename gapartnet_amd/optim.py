@@ -90,20 +90,20 @@ class FusedAdam(torch.optim.Adam):
         own, state = self._own_grad, self.state
         sig = []
         add = sig.append
-        for p in group["params"]:
+        for p in group["params"]:  # one entry per parameter: None = no gradient, else (gradient, value, exp_avg, exp_avg_sq)
             g = p.grad
             if g is None:
-                add(0)
+                add(None)
                 continue
-            add(1 if p in own else g.data_ptr()) if own else add(g.data_ptr())
-            add(p.data_ptr())
+            g_ptr = self._OWN_PTR if (own and p in own) else g.data_ptr()
             try:
                 st = state[p]
-                add(st["exp_avg"].data_ptr())
-                add(st["exp_avg_sq"].data_ptr())
+                add((g_ptr, p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
             except KeyError:  # no moments yet (first step of this parameter)
-                add(-1)
+                add((g_ptr, p.data_ptr(), None, None))
         return self._hyper(group), tuple(sig)
+
+    _OWN_PTR = "own"  # signature entry of a gradient that is copied into a buffer of this class every step (not an address)
 
     _OWN = object()  # snapshot marker: the gradient is copied into a buffer of this class every step
 
@@ -159,18 +159,9 @@ class FusedAdam(torch.optim.Adam):
 
     @staticmethod
     def _grad_entries(group, flat):
-        """parameter -> gradient entry of a flat signature (0 = no gradient: one slot; else four slots, or two before the
-        moments exist)"""
-        out, i = {}, 0
-        for p in group["params"]:
-            if i >= len(flat):
-                break
-            if flat[i] == 0:
-                i += 1
-                continue
-            out[p] = flat[i]
-            i += 3 if flat[i + 2] == -1 else 4
-        return out
+        """parameter -> gradient entry of a signature (per-parameter entries: nothing is recovered from sentinels inside
+        the data, so a zero address - an empty gradient - cannot shift the walk)"""
+        return {p: e[0] for p, e in zip(group["params"], flat) if e is not None}
 
     def _build(self, group, params):
         """device tables for the parameters that have a gradient, one per distinct step count (parameters the training
@@ -223,7 +214,7 @@ class FusedAdam(torch.optim.Adam):
         for gi, group in enumerate(self.param_groups):
             own = self._own_grad
             if own:
-                moved = [p for p in own if p.grad is not None]
+                moved = [p for p in group["params"] if p in own and p.grad is not None]  # this group's only
                 if moved:
                     torch._foreach_copy_([own[p] for p in moved], [p.grad for p in moved])
             sets = self._cache.setdefault(gi, {})
@@ -244,8 +235,8 @@ class FusedAdam(torch.optim.Adam):
                     old_grads = self._grad_entries(group, last[1])
                     new_grads = self._grad_entries(group, sig[1])
                     for p in group["params"]:
-                        old, new = old_grads.get(p, 0), new_grads.get(p, 0)
-                        if old > 1 and new > 1 and old != new and p.grad.is_cuda:
+                        old, new = old_grads.get(p), new_grads.get(p)
+                        if isinstance(old, int) and isinstance(new, int) and old != new and p.grad.is_cuda:
                             own[p] = p.grad.detach().clone()
                             changed = True
                     if changed:

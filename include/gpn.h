@@ -315,6 +315,11 @@ typedef struct gpn_net_op {
  * statistics launches (results agree to ~1e-7 relative; both forms are deterministic).  on < 0 queries.  Returns the previous
  * setting. */
 int gpn_net_bn_fusion(int on);
+/* consecutive weight-gradient contractions of one shape (the convs of a level's residual blocks, the two networks of a paired
+ * pass) that share a launch on the executor's second stream: 1 ... 4 layers (default 4, env GPN_WGRAD_GROUP; only layers with
+ * fewer than GPN_WGRAD_GROUP_ROWS = 16384 rows are held back for it).  Same arithmetic per layer for every setting (bit-equal
+ * gradients).  layers < 1 queries.  Returns the previous setting. */
+int gpn_net_wgrad_group(int layers);
 size_t gpn_net_ws_bytes(const gpn_net_op_t* ops, int n_ops, const gpn_net_slot_t* slots, int n_slots,
                         const gpn_net_rulebook_t* rulebooks, const gpn_net_conv_t* convs);
 int gpn_net_forward(const gpn_net_op_t* ops, int n_ops, gpn_net_slot_t* slots, int n_slots,

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from gapartnet_amd import backend
-from gapartnet_amd.smoke import make_batch, make_model, run_smoke
+from gapartnet_amd.smoke import make_batch, make_model
+from tests.smoke_check import run_smoke
 from gapartnet_amd.structure.point_cloud import PointCloud
 
 pytestmark = pytest.mark.gpu
@@ -428,6 +429,35 @@ def test_device_prefetcher_feeds_identical_steps(cuda):
 
 
 @pytest.mark.gpu
+def test_device_prefetcher_iterated_twice_without_a_host_sync(cuda):
+    """the SAME DevicePrefetcher object walked for two epochs back to back (no synchronisation in between): the second pass's
+    first preparation must wait for the training stream as it stands then, not for the stale mark of the first pass - the
+    side stream would otherwise reuse blocks the last step's kernels still read.  Same losses / parameters as the plain feed."""
+    from gapartnet_amd.dataset.prefetch import DevicePrefetcher
+    base = make_model((0, 0), channels=[16, 32, 48]).to(cuda)
+    scenes = [[pc.to(cuda) for pc in make_batch(2, 4000, seed0=70 + 10 * j)] for j in range(3)]
+    results = []
+    for use_prefetch in (False, True):
+        model = copy.deepcopy(base)
+        model.revoxelize_jitter = (torch.full((3,), 0.3, device=cuda), torch.full((3,), 0.6, device=cuda))
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+        feed = DevicePrefetcher(scenes, model, cuda) if use_prefetch else scenes
+        losses = []
+        for epoch in range(2):
+            for i, batch in enumerate(feed):
+                opt.zero_grad(set_to_none=True)
+                loss = model.training_step(batch, i)
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach())
+        torch.cuda.synchronize()
+        results.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+    assert torch.equal(results[0][0], results[1][0]), (results[0][0], results[1][0])
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_two_rank_bench_shares_one_device(cuda):
     """bench.py's multi-rank path (GradSync over the executor's flat gradient buffers, device prefetcher, per-rank scene shards,
     max-over-ranks timing) with two ranks time-slicing ONE GPU over gloo (GPN_DIST_SHARE_DEVICE): the code path the driver
@@ -634,3 +664,41 @@ def test_fused_adam_matches_torch_adam(cuda):
     # state_dict round trip into a plain torch Adam
     opt_c = torch.optim.Adam([torch.nn.Parameter(t.clone()) for t in base], lr=1e-3)
     opt_c.load_state_dict(opt_a.state_dict())
+
+
+def test_grouped_weight_gradient_contractions_are_bit_equal(cuda):
+    """gpn_net_wgrad_group: up to 4 consecutive same-shape layers of a level (and the two networks of a paired pass) share a
+    weight-gradient contraction launch on the executor's second stream.  Same per-layer arithmetic for every setting: all
+    parameter gradients of a U-Net backward - single and paired passes - are bit-equal at 1, 2 and 4 layers per launch."""
+    from gapartnet_amd import _C
+    from gapartnet_amd.network import net_exec
+    L = _C.lib()
+    prev = L.gpn_net_wgrad_group(-1)
+    assert prev == 4, "grouping of 4 is the default (csrc/net.hip)"
+    try:
+        results = {}
+        for layers in (1, 2, 4):
+            L.gpn_net_wgrad_group(layers)
+            assert L.gpn_net_wgrad_group(-1) == layers
+            net, idx, feats, spconv = _unet_case(cuda, True)
+            twin = copy.deepcopy(net)
+            with torch.no_grad():
+                for p in twin.parameters():
+                    p.mul_(0.5)
+            x = feats.clone().requires_grad_(True)
+            out = net(spconv.SparseConvTensor(x, idx, [64, 64, 64], 3)).features
+            out.square().sum().backward()
+            single = [p.grad.clone() for p in net.parameters()] + [x.grad.clone()]
+            net.zero_grad(set_to_none=True)
+            x2 = feats.clone().requires_grad_(True)
+            pair = net_exec.run_pair(net, twin, spconv.SparseConvTensor(x2, idx, [64, 64, 64], 3))
+            assert pair is not None
+            (pair[0].features.square().sum() + pair[1].features.sum()).backward()
+            paired = [p.grad.clone() for p in list(net.parameters()) + list(twin.parameters())] + [x2.grad.clone()]
+            torch.cuda.synchronize()
+            results[layers] = (single, paired)
+        for layers in (2, 4):
+            for a, b in zip(results[1][0] + results[1][1], results[layers][0] + results[layers][1]):
+                assert torch.equal(a, b), f"grouping {layers}: gradients differ from one layer per launch"
+    finally:
+        L.gpn_net_wgrad_group(prev)
