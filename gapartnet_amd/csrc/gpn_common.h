@@ -18,9 +18,16 @@ struct ProfScope {
   int id;
   hipStream_t stream;
   hipEvent_t start = nullptr;
-  ProfScope(int kernel_id, hipStream_t s, double flops, double bytes);
+  int64_t tag = 0;
+  ProfScope(int kernel_id, hipStream_t s, double flops, double bytes, int64_t tag = 0);
   ~ProfScope();
 };
+// shape of a conv launch as a profiler tag (gpn_prof_get_launches): rows of the launch's output, taps, channel blocks, and
+// whether the launch carries a second problem (paired pass)
+inline int64_t prof_shape_tag(int K, int64_t n_dst, int cin, int cout, bool twin) {
+  return ((int64_t)(twin ? 1 : 0) << 62) | ((int64_t)(K & 63) << 48) | ((int64_t)((cin / 16) & 255) << 40) |
+         ((int64_t)((cout / 16) & 255) << 32) | (n_dst & 0xffffffffll);
+}
 
 // per-device caches (occupancy, side streams, helper threads) are arrays indexed by the HIP device ordinal
 constexpr int kMaxDevices = 64;

@@ -11,6 +11,7 @@ thread_local char g_err[512] = "";
 
 struct ProfRec {
   hipEvent_t a, b;
+  int64_t tag;  // what the launch was (gpn::prof_shape_tag for the conv kernels), 0 = untagged
 };
 struct ProfSlot {
   std::vector<ProfRec> recs;
@@ -32,7 +33,7 @@ const char* kEntryPoints[] = {
     "gpn_pn2_furthest_point_sampling", "gpn_pn2_furthest_point_sampling_ws_bytes",
     "gpn_pn2_furthest_point_sampling_ws", "gpn_pn2_three_nn", "gpn_pn2_knn", "gpn_pn2_three_interpolate",
     "gpn_pn2_three_interpolate_grad", "gpn_proposals_max_proposals", "gpn_proposals_build_ws_bytes", "gpn_proposals_build", "gpn_proposals_voxel_mean",
-    "gpn_proposals_voxel_mean_bwd", "gpn_pose_fit_ws_bytes", "gpn_pose_fit", "gpn_adam_blocks", "gpn_adam_step", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get",
+    "gpn_proposals_voxel_mean_bwd", "gpn_pose_fit_ws_bytes", "gpn_pose_fit", "gpn_adam_blocks", "gpn_adam_step", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get", "gpn_prof_get_launches",
     "gpn_last_error", "gpn_version"};
 }  // namespace
 
@@ -44,7 +45,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-ProfScope::ProfScope(int kernel_id, hipStream_t s, double flops, double bytes) : id(kernel_id), stream(s) {
+ProfScope::ProfScope(int kernel_id, hipStream_t s, double flops, double bytes, int64_t tag_) : id(kernel_id), stream(s), tag(tag_) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof[id].flops += flops;
@@ -59,7 +60,7 @@ ProfScope::~ProfScope() {
   if (hipEventCreate(&stop) != hipSuccess) return;
   hipEventRecord(stop, stream);
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof[id].recs.push_back({start, stop});
+  g_prof[id].recs.push_back({start, stop, tag});
 }
 }  // namespace gpn
 
@@ -132,6 +133,26 @@ int gpn_prof_get(int kernel_id, int64_t* launches_host, double* ms_host, double*
   if (ms_host) *ms_host = ms;
   if (flops_host) *flops_host = s.flops;
   if (bytes_host) *bytes_host = s.bytes;
+  return GPN_OK;
+}
+// the same measurements launch by launch, in launch order: ms[i] / tag[i] of launch i (tag: see gpn.h); returns the number of
+// records through *count_host (only the first `cap` are written)
+int gpn_prof_get_launches(int kernel_id, int64_t cap, double* ms_host, int64_t* tag_host, int64_t* count_host) {
+  GPN_CHECK_ARG(kernel_id >= 0 && kernel_id < GPN_K_COUNT && cap >= 0 && count_host && (cap == 0 || (ms_host && tag_host)));
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfSlot& s = g_prof[kernel_id];
+  int64_t i = 0;
+  for (auto& r : s.recs) {
+    if (i < cap) {
+      GPN_CHECK_HIP(hipEventSynchronize(r.b));
+      float t = 0;
+      GPN_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+      ms_host[i] = t;
+      tag_host[i] = r.tag;
+    }
+    ++i;
+  }
+  *count_host = i;
   return GPN_OK;
 }
 }

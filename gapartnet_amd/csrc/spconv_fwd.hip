@@ -719,11 +719,11 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
   GPN_CHECK_ARG(!stats.twin.in || (stats.twin.packed && stats.twin.out && (stats.slab == nullptr) == (stats.twin.slab == nullptr)));
   const int nt = cout / 16;
   if (gpn::spconv_tiles_supported(K, n_dst, cin, cout)) {  // the masked-tile kernel (spconv_tiles.hip): every layer of >= 16 tiles
-    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
+    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout, gpn::prof_shape_tag(K, n_dst, cin, cout, stats.twin.in != nullptr));
     return gpn::spconv_tiles_launch(in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, cout, accumulate, stats, out, stream);
   }
   if (use_direct(K, n_dst, cin, cout)) {
-    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
+    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout, gpn::prof_shape_tag(K, n_dst, cin, cout, stats.twin.in != nullptr));
     const int32_t* table = nbr_p ? nbr_p : nbr;
     return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream)
            : K == 8 ? dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream)
@@ -750,7 +750,7 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
   }
   int rc;
   {
-    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout);
+    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout, gpn::prof_shape_tag(K, n_dst, cin, cout, stats.twin.in != nullptr));
     switch (p.ntw) {
       case 1: rc = dispatch_cw<1>(p, in, packed_w, nbr, K, n_dst, cin, nt, p.splits > 1 ? 0 : accumulate, target, stream); break;
       case 2: rc = dispatch_cw<2>(p, in, packed_w, nbr, K, n_dst, cin, nt, p.splits > 1 ? 0 : accumulate, target, stream); break;

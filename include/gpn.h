@@ -69,6 +69,10 @@ int gpn_prof_reset(void);
 /* synchronises the recorded events; returns launches, total milliseconds, algorithmic flops and bytes */
 int gpn_prof_get(int kernel_id, int64_t* launches_host, double* ms_host, double* flops_host,
                  double* bytes_host);
+/* the same measurements launch by launch, in launch order (first `cap` records; *count_host = how many there are).  tag of a
+ * conv fwd / dgrad launch: bit 62 = two problems in the launch (paired pass), bits 48-53 taps K, 40-47 cin / 16, 32-39
+ * cout / 16, 0-31 rows of the launch's output; 0 = untagged. */
+int gpn_prof_get_launches(int kernel_id, int64_t cap, double* ms_host, int64_t* tag_host, int64_t* count_host);
 
 /* ================================================================================================
  * V — voxelize.   replaces epic_ops.voxelize.voxelize (call sites dataset/gapartnet.py:188-195,
