@@ -34,6 +34,13 @@ FP_KEYS = ("pc_feature", "sem_logits", "offsets", "prop_voxel_features", "prop_p
            "prop_npcs_preds", "score_logits", "npcs_logits")
 
 
+# Gradient bound of the GPU run against the reference model's gradients: max|d| <= bound x max|g| per tensor.  Gradients pass
+# through ~70 training-mode BatchNorms whose batch statistics on the few-hundred-row deep levels amplify fp32 summation-order
+# differences, so this is looser than north_star's 1e-4 on features; it is set at ~2x the worst error the shipped kernels
+# achieve (printed by the test, recorded in profiles/r04_golden_grad_errors.json), not at a round number.
+GPU_GRAD_BOUND = 1e-3
+
+
 @pytest.fixture(scope="module")
 def gold():
     return np.load(os.path.join(HERE, "glue_step.npz"))
@@ -70,6 +77,7 @@ def _check_gradients(gold, grads, rel):
     assert names == list(grads.keys()), "parameter names / order differ from the reference model"
     # scale of a 'zero' gradient: relative to the largest gradient entry of the whole model
     top = float(gold["grad_maxabs"].max())
+    achieved = {}  # per tensor stored in full: max|d| / max|g| (what the bound is set from: 2 x the worst of these)
     for name, norm, maxabs in zip(names, gold["grad_norms"], gold["grad_maxabs"]):
         mine = grads[name].astype(np.float64)
         if maxabs <= 1e-6 * top:
@@ -79,7 +87,9 @@ def _check_gradients(gold, grads, rel):
         key = "train_grad/" + name
         if key in gold.files:
             err = np.abs(mine - gold[key]).max()
+            achieved[name] = float(err / maxabs)
             assert err <= rel * maxabs + 1e-7, f"{name}: grad |d| {err:.3e} > {rel} x max|g| {maxabs:.3e}"
+    return achieved
 
 
 def _check_buffers(gold, buffers, tol):
@@ -157,7 +167,16 @@ def test_training_step_on_the_gpu_matches_the_reference_model(cuda, gold, per_sc
     worst = _check_forward(gold, out, "train_", 1e-4)
     print("worst fp error / scale per output:", {k: f"{v:.2e}" for k, v in worst.items()})
     _check_logs(gold, out, "train_log/", 1e-4)
-    _check_gradients(gold, out["grads"], 1e-3)
+    achieved = _check_gradients(gold, out["grads"], GPU_GRAD_BOUND)
+    top5 = sorted(achieved.items(), key=lambda kv: -kv[1])[:5]
+    print("gradient error / max|g|, worst five tensors (bound %.1e):" % GPU_GRAD_BOUND, {k: f"{v:.2e}" for k, v in top5})
+    try:  # kept next to the GPU run's other outputs (gpurun_out/ travels back): what GPU_GRAD_BOUND is derived from
+        import json
+        os.makedirs(os.path.join(os.path.dirname(HERE), os.pardir, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(HERE), os.pardir, "gpurun_out", f"golden_grad_errors_per_scene{int(per_scene)}.json"), "w") as fh:
+            json.dump(dict(bound=GPU_GRAD_BOUND, worst=dict(top5), n_tensors=len(achieved)), fh, indent=1)
+    except OSError:
+        pass
     _check_buffers(gold, out["buffers"], 1e-4)
 
 

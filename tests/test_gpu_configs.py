@@ -191,3 +191,54 @@ def test_config5_mixed_batch32_npcs_and_pose_heads(cuda):
             r = fit["rotation"][ok]
             eye = torch.eye(3, dtype=r.dtype, device=cuda)
             assert torch.allclose(r @ r.transpose(1, 2), eye.expand_as(r), atol=1e-8), "rotations are orthonormal"
+
+
+def test_training_mode_backbone_levels_at_full_size_match_the_oracle(cuda):
+    """TRAINING-mode floating point at a full-size level (the full-size configs compared the fp stage in eval mode
+    only; training-mode BatchNorm at 144k rows was covered by run-to-run determinism alone, which a wrong-but-deterministic
+    sum epilogue would pass).  Stem + a two-level residual U-Net (16 / 32 channels: the masked-tile kernel with tile order,
+    BatchNorm sums in the conv / dgrad epilogues, stride-2 / inverse convs, weight-gradient contractions) on 8 x 20k-point
+    scenes, forward AND every parameter gradient against the CPU oracle running the same modules: features at north_star's
+    1e-4, gradients and BatchNorm running statistics at 1e-4 x their scale (two levels of > 80k rows: no tiny-level
+    amplification here)."""
+    import functools
+    import torch.nn as nn
+    from gapartnet_amd.network.backbone import SparseUNet
+    from oracle import torch_ops
+    scenes = make_batch(8, 20000, seed0=9100)
+    torch.manual_seed(11)
+    net = SparseUNet.build(6, [16, 32], 2, functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)).train()
+    with torch.no_grad():  # non-trivial affine parameters and running statistics
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-0.3, 0.3)
+    gnet = copy.deepcopy(net).to(cuda)
+    gbatch = PointCloud.collate([pc.to(cuda) for pc in scenes], voxel_size=VOXEL)
+    assert gbatch.voxel_tensor.features.shape[0] > 130000
+    g_out = gnet(gbatch.voxel_tensor).features
+    weight = torch.linspace(-1.0, 1.0, g_out.shape[1], device=cuda)
+    (g_out * weight).sum().backward()
+    with backend.using(torch_ops):
+        cbatch = PointCloud.collate(scenes, voxel_size=VOXEL)
+        c_out = net(cbatch.voxel_tensor).features
+        (c_out * weight.cpu()).sum().backward()
+    assert torch.equal(gbatch.voxel_tensor.indices.cpu(), cbatch.voxel_tensor.indices)
+    err = float((g_out.detach().cpu() - c_out.detach()).abs().max())
+    assert err <= 1e-4 * max(1.0, float(c_out.abs().max())), f"training-mode features: {err:.3e}"
+    worst = {}
+    for (name, p), (_, q) in zip(gnet.named_parameters(), net.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), name
+        if q.grad is None:
+            continue
+        scale = float(q.grad.abs().max())
+        d = float((p.grad.cpu() - q.grad).abs().max())
+        if scale <= 1e-9:
+            assert d <= 1e-6, name
+            continue
+        worst[name] = d / scale
+    top = max(worst.items(), key=lambda kv: kv[1])
+    print("training-mode full-size gradients: worst |d| / max|g| =", f"{top[1]:.2e}", "at", top[0])
+    assert top[1] <= 1e-4, top
+    for (name, b), (_, c) in zip(gnet.named_buffers(), net.named_buffers()):
+        if b.dtype.is_floating_point:
+            assert torch.allclose(b.cpu(), c, rtol=1e-4, atol=1e-6), f"running statistic {name}"

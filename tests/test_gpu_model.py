@@ -702,3 +702,26 @@ def test_grouped_weight_gradient_contractions_are_bit_equal(cuda):
                 assert torch.equal(a, b), f"grouping {layers}: gradients differ from one layer per launch"
     finally:
         L.gpn_net_wgrad_group(prev)
+
+
+def test_step_switches_keep_the_step(cuda):
+    """the two step-level switches of network/model.py that keep a second formulation reachable on GPU tensors - the proposal
+    stage as torch ops (use_fused_proposals = False) and ScoreNet / NPCS-Net one after the other (pair_proposal_unets = False) -
+    give the same training step as the default (fused stage, paired passes): loss and every gradient bit-equal."""
+    batch = [pc.to(cuda) for pc in make_batch(2, 5000, seed0=321)]
+    base = make_model((0, 0), channels=[16, 32, 48]).to(cuda)
+    jitter = (torch.tensor([0.3, 0.6, 0.1], device=cuda), torch.tensor([0.5, 0.2, 0.9], device=cuda))
+    runs = {}
+    for fused, pair in ((True, True), (True, False), (False, True)):
+        model = copy.deepcopy(base)
+        model.revoxelize_jitter = jitter
+        model.use_fused_proposals, model.pair_proposal_unets = fused, pair
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        runs[(fused, pair)] = (loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    ref_loss, ref_grads = runs[(True, True)]
+    for key in ((True, False), (False, True)):
+        loss, grads = runs[key]
+        assert torch.equal(loss, ref_loss), (key, float(loss), float(ref_loss))
+        for k in ref_grads:
+            assert torch.equal(grads[k], ref_grads[k]), (key, k)
