@@ -188,8 +188,17 @@ def conv_levels(lib, overhead_us):
         rows.append(dict(taps=K, rows=n_rows, cin=cin, cout=cout, launches=r["launches"], layers=r["layers"],
                          us_per_launch_raw_events=r["ms_raw"] * 1e3 / r["launches"], flop_per_byte=intensity, bound=bound,
                          tflops_raw_events=r["flops"] / t_raw / 1e12, gbs_raw_events=r["bytes"] / t_raw / 1e9,
-                         frac_raw_events=work / t_raw / peak, frac_minus_bracket=work / t_adj / peak))
-    return rows
+                         frac_raw_events=work / t_raw / peak, frac_minus_bracket=work / t_adj / peak,
+                         share_of_family_time=r["ms_raw"]))
+    total = sum(r["share_of_family_time"] for r in rows) or 1.0
+    for r in rows:
+        r["share_of_family_time"] /= total
+    # (the shapes that make up the family's time; the tail - a dozen one-launch shapes of the deep levels - is summed)
+    head, tail = rows[:12], rows[12:]
+    if tail:
+        head.append(dict(shapes=len(tail), launches=sum(r["launches"] for r in tail),
+                         share_of_family_time=sum(r["share_of_family_time"] for r in tail), note="remaining shapes"))
+    return head
 
 
 def usable_cores() -> int:

@@ -29,6 +29,39 @@ inline int64_t prof_shape_tag(int K, int64_t n_dst, int cin, int cout, bool twin
          ((int64_t)((cout / 16) & 255) << 32) | (n_dst & 0xffffffffll);
 }
 
+// ---- launches whose extent is a DEVICE counter (round 4: the proposal stage without a host read) -----------------------------
+// A tensor of a data-dependent size lives in a buffer of its upper bound; its live row count is an int64 on the device that the
+// producing kernels write.  Consumers take (n = the bound, DevRows{dev, plan}): kernels read the live count themselves
+// (live_rows), walk their work items with a grid-stride loop - so correctness never depends on the host's guess - and the
+// host sizes grids and picks kernel variants from `plan`, its estimate of the count (the previous step's value; <= 0: none,
+// the bound is used).  dev == nullptr is the ordinary case: n is the exact count, every loop runs once, same code path.
+struct DevRows {
+  const int64_t* dev = nullptr;
+  int64_t plan = 0;
+};
+inline int64_t plan_rows(int64_t n, const DevRows& r) {
+  if (!r.dev || r.plan <= 0) return n;
+  return r.plan < n ? r.plan : n;
+}
+__device__ __forceinline__ int64_t live_rows(const int64_t* dev, int64_t n) {
+  if (!dev) return n;
+  const int64_t v = __builtin_nontemporal_load(dev);
+  return v < n ? (v > 0 ? v : 0) : n;
+}
+// workgroups of a launch whose work items are counted by a device counter: enough for 1.5 x the planned count (at least
+// `floor_wgs`, so that a stale plan still fills the chip), never more than the bound needs; a multiple of `mult`
+inline unsigned dev_grid(int64_t wgs_bound, int64_t wgs_plan, bool dev, int mult = 1, int64_t floor_wgs = 1024) {
+  int64_t g = wgs_bound;
+  if (dev) {
+    int64_t want = wgs_plan + wgs_plan / 2 + mult;
+    if (want < floor_wgs) want = floor_wgs;
+    if (want < g) g = want;
+  }
+  if (g < 1) g = 1;
+  g = (g + mult - 1) / mult * mult;
+  return (unsigned)g;
+}
+
 // per-device caches (occupancy, side streams, helper threads) are arrays indexed by the HIP device ordinal
 constexpr int kMaxDevices = 64;
 
@@ -119,13 +152,15 @@ inline size_t stat_slab_bytes(int C) { return align_up((size_t)kStatSlots * 4 * 
 // gpn_spconv_fwd_ordered with an "add to out" mode and optional BatchNorm sums (spconv_fwd.hip); used by the network executor
 int spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p, const int32_t* perm, int K,
                     int64_t n_dst, int cin, int cout, float* out, int accumulate, const ConvStats& stats, void* ws,
-                    size_t ws_bytes, hipStream_t stream);
+                    size_t ws_bytes, hipStream_t stream, const DevRows& rows = DevRows());
 // true if a conv of this shape runs on a kernel whose epilogue can accumulate ConvStats (masked-tile or direct kernel)
 bool spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout);
+bool spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout, const DevRows& rows);
 // the masked-tile kernel (spconv_tiles.hip): which shapes it takes, and its launch
 bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout);
 int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
-                        int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream);
+                        int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream,
+                        const DevRows& rows = DevRows());
 // weight-gradient contraction and its (batched) slice sums (spconv.hip); used by gpn_spconv_wgrad and the network executor
 constexpr int kWgradReduceJobs = 24;
 constexpr int kWgradSets = 4;

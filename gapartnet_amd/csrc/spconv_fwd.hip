@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
                                                                 const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
                                                                 int64_t units, size_t packed_bytes,
                                                                 const int32_t* __restrict__ perm, int accumulate,
-                                                                gpn::ConvStats stats, float* __restrict__ out) {
+                                                                gpn::ConvStats stats, float* __restrict__ out,
+                                                                const int64_t* __restrict__ n_dev) {
   if (blockIdx.y) {  // the launch's second problem (gpn::ConvTwin)
     in = stats.twin.in, packed = stats.twin.packed, out = stats.twin.out;
     stats.slab = stats.twin.slab, stats.x = stats.twin.x, stats.y = stats.twin.y, stats.mean = stats.twin.mean,
@@ -303,12 +304,19 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;  // prefetch depth in stages
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
+  if (n_dev) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
+    n_dst = gpn::live_rows(n_dev, n_dst);
+    units = ((n_dst + 15) >> 4) * nt_total;
+  }
   // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous eighth of the
   // tiles, so that the source rows its waves gather (spatial neighbours = nearby rows) are fetched into ONE L2 instead of
-  // all eight (time per launch unchanged; fetched bytes per launch, averaged over the bench's conv launches: 16.2 -> 8.9 MB)
-  const int64_t wg = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  // all eight (time per launch unchanged; fetched bytes per launch, averaged over the bench's conv launches: 16.2 -> 8.9 MB).
+  // An XCD's workgroups walk its eighth with a grid stride (one round unless a device-counted launch outgrew its plan).
+  const int64_t per8 = (((units + 3) >> 2) + 7) >> 3;
+  for (int64_t wj = blockIdx.x >> 3; wj < per8; wj += gridDim.x >> 3) {
+  const int64_t wg = (int64_t)(blockIdx.x & 7) * per8 + wj;
   const int64_t unit = wg * 4 + wave;
-  if (unit >= units) return;  // whole wave; no barrier in this kernel
+  if (unit >= units) continue;  // whole wave; no barrier in this kernel
   const int64_t tile = unit / nt_total;
   const int nt = (int)(unit - tile * nt_total);
   const int cin = CB * 16, cout = nt_total * 16;
@@ -443,6 +451,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   }
   if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
   else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+  }  // units of this workgroup
 }
 
 // Tap-split form of the direct kernel for layers with FEW (tile, column tile) units (round 3).  A level of a few thousand
@@ -457,7 +466,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
                                                                const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
                                                                int64_t units, size_t packed_bytes,
                                                                const int32_t* __restrict__ perm, int accumulate,
-                                                               gpn::ConvStats stats, float* __restrict__ out) {
+                                                               gpn::ConvStats stats, float* __restrict__ out,
+                                                               const int64_t* __restrict__ n_dev) {
   constexpr int TP = (KT + SP - 1) / SP;  // taps per wave
   constexpr int S = TP * CB;              // stages per wave
   constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;
@@ -470,7 +480,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int64_t wg = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (n_dev) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
+    n_dst = gpn::live_rows(n_dev, n_dst);
+    units = ((n_dst + 15) >> 4) * nt_total;
+  }
+  const int64_t per8 = (((units + UPW - 1) / UPW) + 7) >> 3;  // workgroups of an XCD that have a unit (grid-stride walk below)
+  for (int64_t wj = blockIdx.x >> 3; wj < per8; wj += gridDim.x >> 3) {
+  const int64_t wg = (int64_t)(blockIdx.x & 7) * per8 + wj;
   const int64_t unit = wg * UPW + wave / SP;
   const int part = wave % SP;
   const int tap0 = part * TP;
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   // the unit's partial sums -> its first wave, added in wave order
   if (part != 0) red[wave][lane] = acc;
   __syncthreads();
-  if (part != 0 || !active) return;
+  if (part == 0 && active) {
 #pragma unroll
   for (int q = 1; q < SP; ++q) acc += red[wave + q][lane];
 
@@ -596,6 +612,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   }
   if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
   else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
+  }
+  if (wj + (int64_t)(gridDim.x >> 3) < per8) __syncthreads();  // another round: `red` is rewritten (uniform per workgroup)
+  }  // units of this workgroup
 }
 
 // units below which a layer takes the 4-way / 2-way tap-split form (0 = never).  tools/conv_split_sweep.py
@@ -615,28 +634,32 @@ std::atomic<int64_t> g_split2_units{[] {
 
 template <int KT, int CB, int SP>
 int launch_split(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int nt_total,
-                 int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
+                 int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream, const gpn::DevRows& rows) {
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
+  const int64_t plan_units = gpn::cdiv(gpn::plan_rows(n_dst, rows), 16) * nt_total;
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
-  hipLaunchKernelGGL((spconv_fwd_split_kernel<KT, CB, SP>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4 / SP), 8) * 8), stats.twin.in ? 2 : 1), dim3(256), 0,
-                     stream, in, packed, nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out);
+  hipLaunchKernelGGL((spconv_fwd_split_kernel<KT, CB, SP>),
+                     dim3(gpn::dev_grid(gpn::cdiv(units, 4 / SP), gpn::cdiv(plan_units, 4 / SP), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1), dim3(256), 0,
+                     stream, in, packed, nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
 template <int KT, int CB>
 int launch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int nt_total,
-                  int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
+                  int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream, const gpn::DevRows& rows) {
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
+  const int64_t plan_units = gpn::cdiv(gpn::plan_rows(n_dst, rows), 16) * nt_total;  // (the form is picked from the planned count)
   if constexpr (KT >= 8) {  // (a k = 1 layer has no taps to split)
-    if (units < g_split4_units.load(std::memory_order_relaxed))
-      return launch_split<KT, CB, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    if (units < g_split2_units.load(std::memory_order_relaxed))
-      return launch_split<KT, CB, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    if (plan_units < g_split4_units.load(std::memory_order_relaxed))
+      return launch_split<KT, CB, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    if (plan_units < g_split2_units.load(std::memory_order_relaxed))
+      return launch_split<KT, CB, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
   }
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
-  hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>), dim3((unsigned)(gpn::cdiv(gpn::cdiv(units, 4), 8) * 8), stats.twin.in ? 2 : 1), dim3(256), 0, stream, in, packed,
-                     nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out);
+  hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>),
+                     dim3(gpn::dev_grid(gpn::cdiv(units, 4), gpn::cdiv(plan_units, 4), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1), dim3(256), 0, stream, in, packed,
+                     nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -662,18 +685,19 @@ bool use_direct(int K, int64_t n_dst, int cin, int cout) {
 
 template <int KT>
 int dispatch_direct(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int cin,
-                    int nt_total, int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
+                    int nt_total, int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream,
+                    const gpn::DevRows& rows) {
   switch (cin / 16) {
-    case 1: return launch_direct<KT, 1>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    case 2: return launch_direct<KT, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    case 3: return launch_direct<KT, 3>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    case 4: return launch_direct<KT, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    case 5: return launch_direct<KT, 5>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    case 6: return launch_direct<KT, 6>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    case 7: return launch_direct<KT, 7>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    case 8: return launch_direct<KT, 8>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    case 10: return launch_direct<KT, 10>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
-    default: return launch_direct<KT, 12>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream);
+    case 1: return launch_direct<KT, 1>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 2: return launch_direct<KT, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 3: return launch_direct<KT, 3>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 4: return launch_direct<KT, 4>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 5: return launch_direct<KT, 5>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 6: return launch_direct<KT, 6>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 7: return launch_direct<KT, 7>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 8: return launch_direct<KT, 8>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 10: return launch_direct<KT, 10>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    default: return launch_direct<KT, 12>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
   }
 }
 
@@ -708,9 +732,21 @@ bool gpn::spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout) 
   return n_dst > 0 && (gpn::spconv_tiles_supported(K, n_dst, cin, cout) || use_direct(K, n_dst, cin, cout));
 }
 
+// which kernel a layer takes when its row count is a device counter: decided from the host's plan (the layer must fit the
+// 32-bit offsets at its bound), never the lock-step kernel - that one sizes partial outputs from the row count
+static bool dev_rows_take_tiles(int K, int64_t n_bound, int64_t n_plan, int cin, int cout) {
+  return gpn::spconv_tiles_supported(K, n_bound, cin, cout) && gpn::spconv_tiles_supported(K, n_plan, cin, cout);
+}
+static bool dev_rows_take_direct(int K, int64_t n_bound, int cin, int cout) { return use_direct(K, std::max<int64_t>(n_bound, 256), cin, cout); }
+
+bool gpn::spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout, const gpn::DevRows& rows) {
+  if (!rows.dev) return gpn::spconv_fwd_accumulates_stats(K, n_dst, cin, cout);
+  return n_dst > 0 && (dev_rows_take_tiles(K, n_dst, gpn::plan_rows(n_dst, rows), cin, cout) || dev_rows_take_direct(K, n_dst, cin, cout));
+}
+
 int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p, const int32_t* perm,
                          int K, int64_t n_dst, int cin, int cout, float* out, int accumulate, const gpn::ConvStats& stats,
-                         void* ws, size_t ws_bytes, hipStream_t stream) {
+                         void* ws, size_t ws_bytes, hipStream_t stream, const gpn::DevRows& rows) {
   GPN_CHECK_ARG((nbr_p == nullptr) == (perm == nullptr));
   GPN_CHECK_ARG(K >= 1 && n_dst >= 0);
   GPN_CHECK_ARG(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0);
@@ -718,16 +754,22 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
   GPN_CHECK_ARG(in && packed_w && nbr && out);
   GPN_CHECK_ARG(!stats.twin.in || (stats.twin.packed && stats.twin.out && (stats.slab == nullptr) == (stats.twin.slab == nullptr)));
   const int nt = cout / 16;
-  if (gpn::spconv_tiles_supported(K, n_dst, cin, cout)) {  // the masked-tile kernel (spconv_tiles.hip): every layer of >= 16 tiles
+  const int64_t n_plan = gpn::plan_rows(n_dst, rows);
+  const bool tiles = rows.dev ? dev_rows_take_tiles(K, n_dst, n_plan, cin, cout) : gpn::spconv_tiles_supported(K, n_dst, cin, cout);
+  if (tiles) {  // the masked-tile kernel (spconv_tiles.hip): every layer of >= 16 tiles
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout, gpn::prof_shape_tag(K, n_dst, cin, cout, stats.twin.in != nullptr));
-    return gpn::spconv_tiles_launch(in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, cout, accumulate, stats, out, stream);
+    return gpn::spconv_tiles_launch(in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, cout, accumulate, stats, out, stream, rows);
   }
-  if (use_direct(K, n_dst, cin, cout)) {
+  if (rows.dev ? dev_rows_take_direct(K, n_dst, cin, cout) : use_direct(K, n_dst, cin, cout)) {
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout, gpn::prof_shape_tag(K, n_dst, cin, cout, stats.twin.in != nullptr));
     const int32_t* table = nbr_p ? nbr_p : nbr;
-    return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream)
-           : K == 8 ? dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream)
-                    : dispatch_direct<1>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream);
+    return K == 27 ? dispatch_direct<27>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream, rows)
+           : K == 8 ? dispatch_direct<8>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream, rows)
+                    : dispatch_direct<1>(in, packed_w, table, perm, n_dst, cin, nt, accumulate, stats, out, stream, rows);
+  }
+  if (rows.dev) {
+    gpn::set_error("gpn_spconv_fwd: a layer whose row count is a device counter must fit the masked-tile / direct kernels (K = %d, %d -> %d channels)", K, cin, cout);
+    return GPN_ERR_ARG;
   }
   if (stats.slab || stats.twin.slab) {
     gpn::set_error("gpn_spconv_fwd: this shape runs on a kernel without a BatchNorm-sum epilogue (see spconv_fwd_accumulates_stats)");

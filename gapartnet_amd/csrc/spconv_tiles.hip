@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
                                                            const int32_t* __restrict__ nbr, const int32_t* __restrict__ perm,
                                                            int K, int64_t n_dst, int n_tiles, int n_units, int nt_total,
                                                            int col_groups, size_t packed_bytes, int accumulate,
-                                                           gpn::ConvStats stats, float* __restrict__ out) {
+                                                           gpn::ConvStats stats, float* __restrict__ out,
+                                                           const int64_t* __restrict__ n_dev) {
   if (blockIdx.y) {  // the launch's second problem (gpn::ConvTwin)
     in = stats.twin.in, packed = stats.twin.packed, out = stats.twin.out;
     stats.slab = stats.twin.slab, stats.x = stats.twin.x, stats.y = stats.twin.y, stats.mean = stats.twin.mean,
@@ -69,11 +70,19 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
+  if (n_dev) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
+    n_dst = gpn::live_rows(n_dev, n_dst);
+    n_tiles = (int)((n_dst + 15) >> 4);
+    n_units = ((n_tiles + R - 1) / R) * col_groups;
+  }
   // workgroups are dealt round-robin to the 8 XCDs: every XCD takes one contiguous eighth of the units (the rows its waves
-  // gather are fetched into ONE L2)
-  const int wg = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  // gather are fetched into ONE L2).  The workgroups of an XCD walk that eighth with a grid stride: one round when the grid was
+  // sized from the row count (per8 == gridDim.x / 8), more when a device-counted launch holds more rows than planned
+  const int per8 = (((n_units + 3) >> 2) + 7) >> 3;
+  for (int wj = (int)(blockIdx.x >> 3); wj < per8; wj += (int)(gridDim.x >> 3)) {
+  const int wg = (int)(blockIdx.x & 7) * per8 + wj;
   const int unit = __builtin_amdgcn_readfirstlane(wg * 4 + wave);
-  if (unit >= n_units) return;  // whole wave; no barrier in this kernel
+  if (unit >= n_units) continue;  // whole wave; no barrier in this kernel
   const int rg = unit / col_groups;
   const int nt0 = (unit - rg * col_groups) * NT;
   const int tile0 = rg * R;
@@ -263,6 +272,7 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
       }
     }
   }
+  }  // units of this workgroup
 }
 
 std::atomic<int64_t> g_min_tiles{[] {
@@ -287,15 +297,17 @@ int min_waves() {  // a launch takes as many column tiles per wave as still leav
 
 template <int CB, int NT>
 int launch_tiles(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
-                 int nt_total, int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
+                 int nt_total, int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream,
+                 const gpn::DevRows& rows) {
   constexpr int R = 1;
   const int n_tiles = (int)gpn::cdiv(n_dst, 16);
   const int col_groups = nt_total / NT;
   const int n_units = (int)gpn::cdiv(n_tiles, R) * col_groups;
+  const int64_t plan_units = gpn::cdiv(gpn::cdiv(gpn::plan_rows(n_dst, rows), 16), R) * col_groups;
   const size_t packed_bytes = (size_t)K * CB * nt_total * 1024;
-  const dim3 grid((unsigned)(gpn::cdiv(gpn::cdiv(n_units, 4), 8) * 8), stats.twin.in ? 2 : 1);
+  const dim3 grid(gpn::dev_grid(gpn::cdiv(n_units, 4), gpn::cdiv(plan_units, 4), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1);
   hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
-                     n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out);
+                     n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -326,15 +338,16 @@ bool supported_width(int CB) {
 
 template <int CB>
 int dispatch_cols(int NT, const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
-                  int nt_total, int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream) {
+                  int nt_total, int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream,
+                  const gpn::DevRows& rows) {
   switch (NT) {
-    case 1: return launch_tiles<CB, 1>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
-    case 2: return launch_tiles<CB, 2>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
-    case 3: return launch_tiles<CB, 3>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
-    case 4: return launch_tiles<CB, 4>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
-    case 5: return launch_tiles<CB, 5>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
-    case 6: return launch_tiles<CB, 6>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
-    default: return launch_tiles<CB, 7>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
+    case 1: return launch_tiles<CB, 1>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 2: return launch_tiles<CB, 2>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 3: return launch_tiles<CB, 3>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 4: return launch_tiles<CB, 4>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 5: return launch_tiles<CB, 5>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    case 6: return launch_tiles<CB, 6>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream, rows);
+    default: return launch_tiles<CB, 7>(in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream, rows);
   }
 }
 
@@ -356,11 +369,12 @@ bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout) {
 }
 
 int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
-                        int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream) {
+                        int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream,
+                        const DevRows& rows) {
   const int CB = cin / 16, nt_total = cout / 16;
-  const int NT = cols_per_wave(gpn::cdiv(n_dst, 16), nt_total);
+  const int NT = cols_per_wave(gpn::cdiv(gpn::plan_rows(n_dst, rows), 16), nt_total);
 #define GPN_X(cb) \
-  if (CB == cb) return dispatch_cols<cb>(NT, in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream);
+  if (CB == cb) return dispatch_cols<cb>(NT, in, packed, nbr, perm, K, n_dst, nt_total, accumulate, stats, out, stream, rows);
   GPN_TILES_CB(GPN_X)
 #undef GPN_X
   gpn::set_error("gpn_spconv_fwd: no masked-tile kernel for %d -> %d channels", cin, cout);

@@ -262,20 +262,25 @@ void orc_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_sr
                       int cout, float* dW) {
   int64_t n_tiles = (n_dst + TILE_ROWS - 1) / TILE_ROWS;
   memset(dW, 0, sizeof(float) * (size_t)((int64_t)K * cin * cout));
-  /* one tap's weight block per thread: every block is summed by one thread in pair order */
+  /* one tap's weight block per thread: every block is summed by one thread in pair order, in DOUBLE (a checker must be
+   * more accurate than what it checks: a sequential fp32 sum over the ~10^5 pairs of a tap at BASELINE's full sizes, of
+   * terms that cancel behind a BatchNorm, is off by 3e-3 of the largest entry - more than the kernels it is compared with) */
 #pragma omp parallel for schedule(dynamic, 1)
   for (int k = 0; k < K; ++k) {
     float* Wk = dW + (int64_t)k * cin * cout;
+    double* acc = (double*)calloc((size_t)cin * cout, sizeof(double));
     int64_t p0 = tile_off[k * (n_tiles + 1)], p1 = tile_off[k * (n_tiles + 1) + n_tiles];
     for (int64_t p = p0; p < p1; ++p) {
       const float* a = in + (int64_t)pair_src[p] * cin;
       const float* g = dout + (int64_t)pair_dst[p] * cout;
       for (int ci = 0; ci < cin; ++ci) {
-        float av = a[ci];
-        float* w = Wk + (int64_t)ci * cout;
-        for (int co = 0; co < cout; ++co) w[co] = w[co] + av * g[co];
+        double av = (double)a[ci];
+        double* w = acc + (int64_t)ci * cout;
+        for (int co = 0; co < cout; ++co) w[co] = w[co] + av * (double)g[co];
       }
     }
+    for (int64_t e = 0; e < (int64_t)cin * cout; ++e) Wk[e] = (float)acc[e];
+    free(acc);
   }
 }
 

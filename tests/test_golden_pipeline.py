@@ -38,7 +38,7 @@ FP_KEYS = ("pc_feature", "sem_logits", "offsets", "prop_voxel_features", "prop_p
 # through ~70 training-mode BatchNorms whose batch statistics on the few-hundred-row deep levels amplify fp32 summation-order
 # differences, so this is looser than north_star's 1e-4 on features; it is set at ~2x the worst error the shipped kernels
 # achieve (printed by the test, recorded in profiles/r04_golden_grad_errors.json), not at a round number.
-GPU_GRAD_BOUND = 1e-3
+GPU_GRAD_BOUND = 8e-4  # achieved (round 4): 3.8e-4 worst of 228 tensors (a BatchNorm bias of level 3's decoder), 2.2e-4 next
 
 
 @pytest.fixture(scope="module")
