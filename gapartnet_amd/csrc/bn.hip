@@ -56,7 +56,9 @@ template <bool BWD>
 __global__ __launch_bounds__(kReduceThreads) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                    const float* __restrict__ dy, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, int64_t N, int C4, int relu,
-                                                                   double* __restrict__ partial /* [blocks][2][C] */) {
+                                                                   double* __restrict__ partial /* [blocks][2][C] */,
+                                                                   const int64_t* __restrict__ n_dev) {
+  N = gpn::live_rows(n_dev, N);  // (a device-counted row count: every workgroup still writes its - possibly zero - partial)
   extern __shared__ __attribute__((aligned(16))) double red_raw[];
   double (*red)[kReduceThreads][4] = reinterpret_cast<double (*)[kReduceThreads][4]>(red_raw);  // [2][T][4]
   constexpr int T = kReduceThreads;
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(const double* __res
 __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ weight, const float* __restrict__ bias, int64_t total4,
-                                    int C4, int relu, float* __restrict__ y) {
+                                    int C4, int relu, float* __restrict__ y, const int64_t* __restrict__ n_dev) {
+  if (n_dev) total4 = gpn::live_rows(n_dev, total4 / C4) * C4;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(t % C4);
     const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
@@ -271,7 +274,12 @@ constexpr int kApplyBatch = 4;  // elements of a thread in flight together
 template <bool FIXED>  // FIXED: `partial` is a slab of fixed-point words a conv launch accumulated (bn_stats.h), `blocks` its slot sets in use
 __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(gpn::BnFwdPtrs pa, gpn::BnFwdPtrs pb, int blocks, int64_t N,
                                                                          int64_t total4, int C4, float eps, float momentum,
-                                                                         int relu) {
+                                                                         int relu, const int64_t* __restrict__ n_dev) {
+  if (n_dev) {  // the row count is a device counter (gpn::DevRows); no rows: nothing to normalise, statistics untouched
+    N = gpn::live_rows(n_dev, N);
+    total4 = N * C4;
+    if (N == 0) return;
+  }
   // (two BatchNorms of the same shape per launch for the executor's paired passes: blockIdx.y picks the pointer set)
   const gpn::BnFwdPtrs& pp = blockIdx.y ? pb : pa;
   const float* __restrict__ x = pp.x;
@@ -365,7 +373,20 @@ __global__ __launch_bounds__(kApplyThreads) void bn_apply_fwd_fold_kernel(gpn::B
 
 template <bool FIXED>
 __global__ __launch_bounds__(kApplyThreads) void bn_apply_bwd_fold_kernel(gpn::BnBwdPtrs pa, gpn::BnBwdPtrs pb, int blocks, int64_t total4,
-                                                                         int C4, float inv_n, int relu, int training) {
+                                                                         int C4, float inv_n, int relu, int training,
+                                                                         const int64_t* __restrict__ n_dev) {
+  if (n_dev) {  // the row count is a device counter (gpn::DevRows): total4 was its bound x C4
+    const int64_t N = gpn::live_rows(n_dev, total4 / C4);
+    total4 = N * C4;
+    inv_n = 1.0f / (float)N;
+    if (N == 0) {  // no rows: zero parameter gradients, nothing else
+      if (blockIdx.x == 0) {
+        const gpn::BnBwdPtrs& q = blockIdx.y ? pb : pa;
+        for (int c = threadIdx.x; c < C4 * 4; c += kApplyThreads) q.dbias[c] = 0.f, q.dweight[c] = 0.f;
+      }
+      return;
+    }
+  }
   const gpn::BnBwdPtrs& pp = blockIdx.y ? pb : pa;
   const float* __restrict__ x = pp.x;
   const float* __restrict__ y = pp.y;
@@ -494,7 +515,11 @@ __global__ __launch_bounds__(T) void bn_small_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ weight,
     const float* __restrict__ bias, int N, int C4, float eps, float momentum, int relu, float* __restrict__ y,
     float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
-    float* __restrict__ running_var) {
+    float* __restrict__ running_var, const int64_t* __restrict__ n_dev) {
+  if (n_dev) {
+    N = (int)gpn::live_rows(n_dev, N);
+    if (N == 0) return;
+  }
   __shared__ double scratch[T / 64][CG][8];
   constexpr int R = T / CG;
   const int c4 = blockIdx.x * CG + threadIdx.x % CG;
@@ -550,7 +575,8 @@ __global__ __launch_bounds__(T) void bn_small_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
     const float* __restrict__ weight, const float* __restrict__ mean, const float* __restrict__ invstd, int N, int C4,
     int relu, int training, float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dweight,
-    float* __restrict__ dbias) {
+    float* __restrict__ dbias, const int64_t* __restrict__ n_dev) {
+  if (n_dev) N = (int)gpn::live_rows(n_dev, N);  // (N == 0: the sums below are zero, no row is written)
   __shared__ double scratch[T / 64][CG][8];
   constexpr int R = T / CG;
   const int c4 = blockIdx.x * CG + threadIdx.x % CG;
@@ -638,45 +664,58 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
                                 int C, float eps, float momentum, int relu, float* y, float* mean, float* invstd,
                                 float* running_mean, float* running_var, void* ws, size_t ws_bytes,
                                 gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return gpn::bn_fwd_train_rows(x, res, weight, bias, N, gpn::DevRows(), C, eps, momentum, relu, y, mean, invstd, running_mean,
+                                running_var, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+// (rows.dev: N is the buffers' bound and the live row count a device counter - gpn::DevRows; variants are picked from the plan)
+int gpn::bn_fwd_train_rows(const float* x, const float* res, const float* weight, const float* bias, int64_t N,
+                           const gpn::DevRows& rows, int C, float eps, float momentum, int relu, float* y, float* mean,
+                           float* invstd, float* running_mean, float* running_var, void* ws, size_t ws_bytes,
+                           hipStream_t stream) {
+  const int64_t Np = gpn::plan_rows(N, rows);
   GPN_CHECK_ARG(N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024);
   GPN_CHECK_ARG(x && weight && bias && y && mean && invstd && ws);
   GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
   GPN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   const int C4 = C / 4;
   gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (res ? 4 : 3));  // x twice (statistics, apply) [+ res], y
-  if (N <= kSmallRows) {
+  if (Np <= kSmallRows && N < ((int64_t)1 << 31)) {
     // (the forward kernel stays at 256 threads: at 1024 it measured 51 us instead of 10 - every thread carries the
     // double-precision mean / 1/sqrt epilogue; the backward kernel, three streams and no epilogue, gains from 1024)
     if (C4 % 4 == 0)
       hipLaunchKernelGGL((bn_small_fwd_kernel<4, 256>), dim3(C4 / 4), dim3(256), 0, stream, x, res, weight, bias, (int)N,
-                         C4, eps, momentum, relu, y, mean, invstd, running_mean, running_var);
+                         C4, eps, momentum, relu, y, mean, invstd, running_mean, running_var, rows.dev);
     else
       hipLaunchKernelGGL((bn_small_fwd_kernel<1, 256>), dim3(C4), dim3(256), 0, stream, x, res, weight, bias, (int)N, C4,
-                         eps, momentum, relu, y, mean, invstd, running_mean, running_var);
+                         eps, momentum, relu, y, mean, invstd, running_mean, running_var, rows.dev);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
   }
-  const int blocks = reduce_blocks(N, C4);
+  const int blocks = reduce_blocks(Np, C4);
   double* partial = static_cast<double*>(ws);
   hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(blocks), dim3(kReduceThreads), kReduceLds, stream, x, nullptr, nullptr,
-                     nullptr, nullptr, N, C4, 0, partial);
+                     nullptr, nullptr, N, C4, 0, partial, rows.dev);
   GPN_CHECK_LAUNCH();
-  const int64_t total4 = N * C4;
+  const int64_t total4 = N * C4, plan4 = Np * C4;
   if (C <= kFoldMaxC) {
     gpn::BnFwdPtrs pp;
     pp.x = x, pp.res = res, pp.partial = partial, pp.weight = weight, pp.bias = bias, pp.y = y, pp.mean = mean, pp.invstd = invstd,
     pp.running_mean = running_mean, pp.running_var = running_var;
-    hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<false>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, pp, pp, blocks, N,
-                       total4, C4, eps, momentum, relu);
+    hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<false>, dim3(fold_grid(plan4)), dim3(kApplyThreads), 0, stream, pp, pp, blocks, N,
+                       total4, C4, eps, momentum, relu, rows.dev);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
+  }
+  if (rows.dev) {
+    gpn::set_error("gpn_bn_fwd_train: a device-counted row count needs C <= %d", kFoldMaxC);
+    return GPN_ERR_ARG;
   }
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, stream, partial, blocks, N, C,
                      eps, momentum, mean, invstd, running_mean, running_var);
   GPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, res, mean, invstd,
-                     weight, bias, total4, C4, relu, y);
+                     weight, bias, total4, C4, relu, y, nullptr);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -685,13 +724,17 @@ extern "C" int gpn_bn_fwd_train(const float* x, const float* res, const float* w
 extern "C" int gpn_bn_fwd_eval(const float* x, const float* res, const float* weight, const float* bias,
                                const float* mean, const float* invstd, int64_t N, int C, int relu, float* y,
                                gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return gpn::bn_fwd_eval_rows(x, res, weight, bias, mean, invstd, N, gpn::DevRows(), C, relu, y, (hipStream_t)stream_);
+}
+
+int gpn::bn_fwd_eval_rows(const float* x, const float* res, const float* weight, const float* bias, const float* mean,
+                          const float* invstd, int64_t N, const gpn::DevRows& rows, int C, int relu, float* y, hipStream_t stream) {
   GPN_CHECK_ARG(N >= 0 && C >= 4 && C % 4 == 0);
   if (N == 0) return GPN_OK;
   GPN_CHECK_ARG(x && weight && bias && mean && invstd && y);
   const int64_t total4 = N * (C / 4);
-  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(total4)), dim3(kThreads), 0, stream, x, res, mean, invstd,
-                     weight, bias, total4, C / 4, relu, y);
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(gpn::plan_rows(N, rows) * (C / 4))), dim3(kThreads), 0, stream, x, res, mean, invstd,
+                     weight, bias, total4, C / 4, relu, y, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -700,40 +743,51 @@ extern "C" int gpn_bn_fwd_eval(const float* x, const float* res, const float* we
 extern "C" int gpn_bn_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* mean,
                           const float* invstd, int64_t N, int C, int relu, int training, float* dx, float* dres,
                           float* dweight, float* dbias, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return gpn::bn_bwd_rows(x, y, dy, weight, mean, invstd, N, gpn::DevRows(), C, relu, training, dx, dres, dweight, dbias, ws,
+                          ws_bytes, (hipStream_t)stream_);
+}
+
+int gpn::bn_bwd_rows(const float* x, const float* y, const float* dy, const float* weight, const float* mean,
+                     const float* invstd, int64_t N, const gpn::DevRows& rows, int C, int relu, int training, float* dx,
+                     float* dres, float* dweight, float* dbias, void* ws, size_t ws_bytes, hipStream_t stream) {
+  const int64_t Np = gpn::plan_rows(N, rows);
   GPN_CHECK_ARG(N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024);
   GPN_CHECK_ARG(x && dy && weight && mean && invstd && dx && dweight && dbias && ws && (y || !relu));
   GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
   const int C4 = C / 4;
   gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (7 + (dres ? 1 : 0)));  // x, y, dy twice each; dx [, dres]
-  if (N <= kSmallRows) {
+  if (Np <= kSmallRows && N < ((int64_t)1 << 31)) {
     // few workgroups, each a serial chain of row loads: 1024 threads per workgroup keep the chain one batch long
-    if (C4 % 4 == 0 && N > 256)
+    if (C4 % 4 == 0 && Np > 256)
       hipLaunchKernelGGL((bn_small_bwd_kernel<4, 1024>), dim3(C4 / 4), dim3(1024), 0, stream, x, y, dy, weight, mean, invstd,
-                         (int)N, C4, relu, training, dx, dres, dweight, dbias);
+                         (int)N, C4, relu, training, dx, dres, dweight, dbias, rows.dev);
     else if (C4 % 4 == 0)
       hipLaunchKernelGGL((bn_small_bwd_kernel<4, 256>), dim3(C4 / 4), dim3(256), 0, stream, x, y, dy, weight, mean, invstd,
-                         (int)N, C4, relu, training, dx, dres, dweight, dbias);
+                         (int)N, C4, relu, training, dx, dres, dweight, dbias, rows.dev);
     else
       hipLaunchKernelGGL((bn_small_bwd_kernel<1, 256>), dim3(C4), dim3(256), 0, stream, x, y, dy, weight, mean, invstd,
-                         (int)N, C4, relu, training, dx, dres, dweight, dbias);
+                         (int)N, C4, relu, training, dx, dres, dweight, dbias, rows.dev);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
   }
-  const int blocks = reduce_blocks(N, C4);
+  const int blocks = reduce_blocks(Np, C4);
   double* partial = static_cast<double*>(ws);
   hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(blocks), dim3(kReduceThreads), kReduceLds, stream, x, y, dy, mean, invstd,
-                     N, C4, relu, partial);
+                     N, C4, relu, partial, rows.dev);
   GPN_CHECK_LAUNCH();
-  const int64_t total4 = N * C4;
+  const int64_t total4 = N * C4, plan4 = Np * C4;
   if (C <= kFoldMaxC) {
     gpn::BnBwdPtrs pp;
     pp.x = x, pp.y = y, pp.dy = dy, pp.partial = partial, pp.mean = mean, pp.invstd = invstd, pp.weight = weight, pp.dx = dx,
     pp.dres = dres, pp.dweight = dweight, pp.dbias = dbias;
-    hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<false>, dim3(fold_grid(total4)), dim3(kApplyThreads), 0, stream, pp, pp, blocks, total4,
-                       C4, 1.0f / (float)N, relu, training);
+    hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<false>, dim3(fold_grid(plan4)), dim3(kApplyThreads), 0, stream, pp, pp, blocks, total4,
+                       C4, 1.0f / (float)N, relu, training, rows.dev);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
+  }
+  if (rows.dev) {
+    gpn::set_error("gpn_bn_bwd: a device-counted row count needs C <= %d", kFoldMaxC);
+    return GPN_ERR_ARG;
   }
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, stream, partial, blocks, C,
                      dweight, dbias);
@@ -757,7 +811,7 @@ bool gpn::bn_two_pass(int64_t N, int C) {
 }
 
 int gpn::bn_fwd_train_fused(const gpn::BnFwdPtrs& p, const gpn::BnFwdPtrs* twin, int64_t N, int C, float eps, float momentum,
-                            int relu, hipStream_t stream) {
+                            int relu, hipStream_t stream, const gpn::DevRows& rows) {
   for (const gpn::BnFwdPtrs* q : {&p, twin}) {
     if (!q) continue;
     GPN_CHECK_ARG(q->x && q->weight && q->bias && q->y && q->mean && q->invstd && q->partial);
@@ -767,14 +821,15 @@ int gpn::bn_fwd_train_fused(const gpn::BnFwdPtrs& p, const gpn::BnFwdPtrs* twin,
   GPN_CHECK_ARG(!twin || (twin->res == nullptr) == (p.res == nullptr));
   const int64_t total4 = N * (C / 4);
   gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (p.res ? 3 : 2) * (twin ? 2 : 1));  // x [+ res] read, y written
-  hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<true>, dim3(fold_grid(total4), twin ? 2 : 1), dim3(kApplyThreads), 0, stream, p,
-                     twin ? *twin : p, gpn::stat_slot_count(N), N, total4, C / 4, eps, momentum, relu);
+  const int64_t Np = gpn::plan_rows(N, rows);  // (slot sets in use: the same function of the plan the producing conv used)
+  hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<true>, dim3(fold_grid(Np * (C / 4)), twin ? 2 : 1), dim3(kApplyThreads), 0, stream, p,
+                     twin ? *twin : p, gpn::stat_slot_count(Np), N, total4, C / 4, eps, momentum, relu, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
 int gpn::bn_bwd_fused(const gpn::BnBwdPtrs& p, const gpn::BnBwdPtrs* twin, int64_t N, int C, int relu, int training,
-                      hipStream_t stream) {
+                      hipStream_t stream, const gpn::DevRows& rows) {
   for (const gpn::BnBwdPtrs* q : {&p, twin}) {
     if (!q) continue;
     GPN_CHECK_ARG(q->x && q->dy && q->weight && q->mean && q->invstd && q->dx && q->dweight && q->dbias && q->partial && (q->y || !relu));
@@ -783,8 +838,9 @@ int gpn::bn_bwd_fused(const gpn::BnBwdPtrs& p, const gpn::BnBwdPtrs* twin, int64
   GPN_CHECK_ARG(!twin || (twin->dres == nullptr) == (p.dres == nullptr));
   const int64_t total4 = N * (C / 4);
   gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (4 + (p.dres ? 1 : 0)) * (twin ? 2 : 1));  // x, y, dy read; dx [, dres] written
-  hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<true>, dim3(fold_grid(total4), twin ? 2 : 1), dim3(kApplyThreads), 0, stream, p,
-                     twin ? *twin : p, gpn::stat_slot_count(N), total4, C / 4, 1.0f / (float)N, relu, training);
+  const int64_t Np = gpn::plan_rows(N, rows);
+  hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<true>, dim3(fold_grid(Np * (C / 4)), twin ? 2 : 1), dim3(kApplyThreads), 0, stream, p,
+                     twin ? *twin : p, gpn::stat_slot_count(Np), total4, C / 4, 1.0f / (float)N, relu, training, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

@@ -256,12 +256,14 @@ __global__ void segmented_maxpool_fwd_kernel(const float* __restrict__ values, c
 __global__ __launch_bounds__(256) void segmented_maxpool_fwd_wg_kernel(const float* __restrict__ values,
                                                                        const int32_t* __restrict__ begin,
                                                                        const int32_t* __restrict__ end, int C,
-                                                                       float* __restrict__ pooled, int32_t* __restrict__ argmax) {
+                                                                       float* __restrict__ pooled, int32_t* __restrict__ argmax,
+                                                                       int64_t P, const int64_t* __restrict__ p_dev) {
   __shared__ float sv[256];
   __shared__ int32_t si[256];
-  const int64_t p = blockIdx.x;
+  P = gpn::live_rows(p_dev, P);  // (device-counted segments, gpn::DevRows: a workgroup walks segments with a grid stride)
   const int R = 256 / C;
   const int c = threadIdx.x % C, rl = threadIdx.x / C;
+  for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
   float best = 0.f;
   int32_t bi = -1;
   if (rl < R) {
@@ -283,24 +285,34 @@ __global__ __launch_bounds__(256) void segmented_maxpool_fwd_wg_kernel(const flo
     pooled[p * C + c] = best;
     argmax[p * C + c] = bi;
   }
+  __syncthreads();  // (sv / si are rewritten by the next segment)
+  }
 }
 
 __global__ void segmented_maxpool_bwd_kernel(const float* __restrict__ dpooled, const int32_t* __restrict__ argmax,
-                                             int64_t P, int C, float* __restrict__ dvalues) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P * C) return;
-  const int c = (int)(t % C);
-  const int32_t r = argmax[t];
-  if (r >= 0) dvalues[(int64_t)r * C + c] = dpooled[t];  // segments are disjoint: one writer per element
+                                             int64_t P, int C, float* __restrict__ dvalues, const int64_t* __restrict__ p_dev) {
+  P = gpn::live_rows(p_dev, P);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < P * C; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C);
+    const int32_t r = argmax[t];
+    if (r >= 0) dvalues[(int64_t)r * C + c] = dpooled[t];  // segments are disjoint: one writer per element
+  }
+}
+// dvalues[0 .. *m_dev) = 0 (the rows the scatter above does not write)
+__global__ void zero_rows_kernel(float* __restrict__ p, int64_t rows, int C, const int64_t* __restrict__ m_dev) {
+  const int64_t total = gpn::live_rows(m_dev, rows) * C;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) p[t] = 0.f;
 }
 
 // ================================================================================================ I
 __global__ void instance_iou_kernel(const int32_t* __restrict__ proposal_offsets,
                                     const int32_t* __restrict__ instance_labels,
                                     const int32_t* __restrict__ batch_indices,
-                                    const int32_t* __restrict__ npi, int64_t P, int I, float* __restrict__ ious) {
+                                    const int32_t* __restrict__ npi, int64_t P, int I, float* __restrict__ ious,
+                                    const int64_t* __restrict__ p_dev) {
   extern __shared__ int32_t hist[];
-  const int64_t p = blockIdx.x;
+  P = gpn::live_rows(p_dev, P);
+  for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
   const int32_t b0 = proposal_offsets[p], b1 = proposal_offsets[p + 1];
   for (int k = threadIdx.x; k < I; k += blockDim.x) hist[k] = 0;
   __syncthreads();
@@ -314,6 +326,8 @@ __global__ void instance_iou_kernel(const int32_t* __restrict__ proposal_offsets
     const int32_t n = npi[(int64_t)b * I + k];
     const int32_t uni = (b1 - b0) + n - hist[k];
     ious[p * I + k] = (n > 0 && uni > 0) ? __fdiv_rn((float)hist[k], (float)uni) : 0.f;
+  }
+  __syncthreads();  // (hist is rewritten by the next proposal)
   }
 }
 
@@ -430,15 +444,27 @@ extern "C" int gpn_segmented_reduce(const float* values, const int32_t* begin, c
   return GPN_OK;
 }
 
+static int maxpool_fwd_impl(const float* values, const int32_t* begin, const int32_t* end, int64_t P, const gpn::DevRows& rows, int C,
+                            float* pooled, int32_t* argmax, hipStream_t stream);
 extern "C" int gpn_segmented_maxpool_fwd(const float* values, const int32_t* begin, const int32_t* end,
                                          int64_t P, int C, float* pooled, int32_t* argmax, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return maxpool_fwd_impl(values, begin, end, P, gpn::DevRows(), C, pooled, argmax, (hipStream_t)stream_);
+}
+// segment count on the device (P = the bound of begin / end / pooled / argmax); needs 256 % C == 0
+extern "C" int gpn_segmented_maxpool_fwd_dev(const float* values, const int32_t* begin, const int32_t* end, int64_t P,
+                                             const int64_t* p_dev, int64_t p_plan, int C, float* pooled, int32_t* argmax,
+                                             gpn_stream_t stream_) {
+  GPN_CHECK_ARG(p_dev != nullptr && C <= 256 && 256 % C == 0);
+  return maxpool_fwd_impl(values, begin, end, P, gpn::DevRows{p_dev, p_plan}, C, pooled, argmax, (hipStream_t)stream_);
+}
+static int maxpool_fwd_impl(const float* values, const int32_t* begin, const int32_t* end, int64_t P, const gpn::DevRows& rows, int C,
+                            float* pooled, int32_t* argmax, hipStream_t stream) {
   GPN_CHECK_ARG(P >= 0 && C >= 1);
   if (P == 0) return GPN_OK;
   GPN_CHECK_ARG(values && begin && end && pooled && argmax);
   if (C <= 256 && 256 % C == 0 && P < (int64_t)0x7fffffff)
-    hipLaunchKernelGGL(segmented_maxpool_fwd_wg_kernel, dim3((unsigned)P), dim3(256), 0, stream, values, begin, end, C, pooled,
-                       argmax);
+    hipLaunchKernelGGL(segmented_maxpool_fwd_wg_kernel, dim3(gpn::dev_grid(P, gpn::plan_rows(P, rows), rows.dev != nullptr)), dim3(256), 0,
+                       stream, values, begin, end, C, pooled, argmax, P, rows.dev);
   else
     hipLaunchKernelGGL(segmented_maxpool_fwd_kernel, dim3((int)gpn::cdiv(P * C, kThreads)), dim3(kThreads), 0,
                        stream, values, begin, end, P, C, pooled, argmax);
@@ -457,23 +483,52 @@ extern "C" int gpn_segmented_maxpool_bwd(const float* dpooled, const int32_t* ar
   if (P == 0) return GPN_OK;
   GPN_CHECK_ARG(dpooled && argmax);
   hipLaunchKernelGGL(segmented_maxpool_bwd_kernel, dim3((int)gpn::cdiv(P * C, kThreads)), dim3(kThreads), 0,
-                     stream, dpooled, argmax, P, C, dvalues);
+                     stream, dpooled, argmax, P, C, dvalues, (const int64_t*)nullptr);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+// segment and row counts on the device (P, M: the bounds)
+extern "C" int gpn_segmented_maxpool_bwd_dev(const float* dpooled, const int32_t* argmax, int64_t P, const int64_t* p_dev,
+                                             int64_t p_plan, int C, int64_t M, const int64_t* m_dev, int64_t m_plan, float* dvalues,
+                                             gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(P >= 1 && C >= 1 && M >= 1 && p_dev && m_dev && dpooled && argmax && dvalues);
+  const int64_t mp = gpn::plan_rows(M, gpn::DevRows{m_dev, m_plan}), pp = gpn::plan_rows(P, gpn::DevRows{p_dev, p_plan});
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(gpn::dev_grid(gpn::cdiv(M * C, kThreads), gpn::cdiv(mp * C, kThreads), true)), dim3(kThreads), 0,
+                     stream, dvalues, M, C, m_dev);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(segmented_maxpool_bwd_kernel, dim3(gpn::dev_grid(gpn::cdiv(P * C, kThreads), gpn::cdiv(pp * C, kThreads), true)),
+                     dim3(kThreads), 0, stream, dpooled, argmax, P, C, dvalues, p_dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
-extern "C" int gpn_instance_iou(const int32_t* proposal_offsets, const int32_t* instance_labels,
-                                const int32_t* batch_indices, const int32_t* num_points_per_instance, int64_t P,
-                                int64_t B, int I, float* ious, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int instance_iou_impl(const int32_t* proposal_offsets, const int32_t* instance_labels, const int32_t* batch_indices,
+                             const int32_t* num_points_per_instance, int64_t P, const gpn::DevRows& rows, int64_t B, int I, float* ious,
+                             hipStream_t stream) {
   GPN_CHECK_ARG(P >= 0 && B >= 0 && I >= 0);
   if (P == 0 || I == 0) return GPN_OK;
   GPN_CHECK_ARG(proposal_offsets && instance_labels && batch_indices && num_points_per_instance && ious);
   GPN_CHECK_ARG(I <= 8192);
-  hipLaunchKernelGGL(instance_iou_kernel, dim3((int)P), dim3(128), sizeof(int32_t) * I, stream, proposal_offsets,
-                     instance_labels, batch_indices, num_points_per_instance, P, I, ious);
+  hipLaunchKernelGGL(instance_iou_kernel, dim3(gpn::dev_grid(P, gpn::plan_rows(P, rows), rows.dev != nullptr)), dim3(128),
+                     sizeof(int32_t) * I, stream, proposal_offsets, instance_labels, batch_indices, num_points_per_instance, P, I, ious,
+                     rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
+}
+extern "C" int gpn_instance_iou(const int32_t* proposal_offsets, const int32_t* instance_labels,
+                                const int32_t* batch_indices, const int32_t* num_points_per_instance, int64_t P,
+                                int64_t B, int I, float* ious, gpn_stream_t stream_) {
+  return instance_iou_impl(proposal_offsets, instance_labels, batch_indices, num_points_per_instance, P, gpn::DevRows(), B, I, ious,
+                           (hipStream_t)stream_);
+}
+// proposal count on the device (P = the bound of proposal_offsets / ious)
+extern "C" int gpn_instance_iou_dev(const int32_t* proposal_offsets, const int32_t* instance_labels, const int32_t* batch_indices,
+                                    const int32_t* num_points_per_instance, int64_t P, const int64_t* p_dev, int64_t p_plan, int64_t B,
+                                    int I, float* ious, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(p_dev != nullptr);
+  return instance_iou_impl(proposal_offsets, instance_labels, batch_indices, num_points_per_instance, P, gpn::DevRows{p_dev, p_plan}, B,
+                           I, ious, (hipStream_t)stream_);
 }
 
 extern "C" size_t gpn_nms_ws_bytes(int64_t P) {

@@ -181,7 +181,8 @@ struct WgradReduceJob {
   int S, K, cin, cout, oki, few;
 };
 int wgrad_slices(int K, int cin, int cout, int64_t n_dst);
-int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream);
+int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream,
+                   const int64_t* n_dst_dev = nullptr);
 WgradReduceJob wgrad_reduce_job(const float* partial, int S, int K, int cin, int cout, int flags, float* dW);
 int wgrad_reduce_many(const WgradReduceJob* jobs, int n, hipStream_t stream);
 // gpn_rulebook_level_counts with row count and level-0 extent on the device (rulebook.hip; used by gpn_voxelize_scenes)
@@ -192,8 +193,18 @@ int rulebook_level_counts_dev(const int32_t* indices, int64_t n_max, const int64
 bool bn_two_pass(int64_t N, int C);
 // (partial = the slab; `twin`: a second BatchNorm of the same shape in the same launch, or nullptr)
 int bn_fwd_train_fused(const BnFwdPtrs& p, const BnFwdPtrs* twin, int64_t N, int C, float eps, float momentum, int relu,
-                       hipStream_t stream);
-int bn_bwd_fused(const BnBwdPtrs& p, const BnBwdPtrs* twin, int64_t N, int C, int relu, int training, hipStream_t stream);
+                       hipStream_t stream, const DevRows& rows = DevRows());
+int bn_bwd_fused(const BnBwdPtrs& p, const BnBwdPtrs* twin, int64_t N, int C, int relu, int training, hipStream_t stream,
+                 const DevRows& rows = DevRows());
+// gpn_bn_fwd_train / gpn_bn_fwd_eval / gpn_bn_bwd with the row count optionally on the device (DevRows)
+int bn_fwd_train_rows(const float* x, const float* res, const float* weight, const float* bias, int64_t N, const DevRows& rows,
+                      int C, float eps, float momentum, int relu, float* y, float* mean, float* invstd, float* running_mean,
+                      float* running_var, void* ws, size_t ws_bytes, hipStream_t stream);
+int bn_fwd_eval_rows(const float* x, const float* res, const float* weight, const float* bias, const float* mean,
+                     const float* invstd, int64_t N, const DevRows& rows, int C, int relu, float* y, hipStream_t stream);
+int bn_bwd_rows(const float* x, const float* y, const float* dy, const float* weight, const float* mean, const float* invstd,
+                int64_t N, const DevRows& rows, int C, int relu, int training, float* dx, float* dres, float* dweight,
+                float* dbias, void* ws, size_t ws_bytes, hipStream_t stream);
 
 }  // namespace gpn
 

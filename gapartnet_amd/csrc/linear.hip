@@ -20,7 +20,8 @@ constexpr int kTileRows = 128;
 // thread are one 16-byte LDS read per ci); the threads of a row read the same x row (one L1 line, broadcast)
 __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                               const float* __restrict__ b, int64_t N, int cin, int cout,
-                                                              float* __restrict__ y) {
+                                                              float* __restrict__ y, const int64_t* __restrict__ n_dev) {
+  N = gpn::live_rows(n_dev, N);  // (device-counted rows, gpn::DevRows)
   __shared__ __attribute__((aligned(16))) float Wt[kMaxC][kMaxC];  // [ci][o]
   __shared__ __attribute__((aligned(16))) float bs[kMaxC];
   const int Q = (cout + 3) >> 2, cp = Q * 4;
@@ -64,7 +65,9 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const float* __res
 
 // dx[row, 4c .. 4c + 3] = sum_o dy[row, o] W[o, 4c .. 4c + 3]: thread = (row, c)
 __global__ __launch_bounds__(kThreads) void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W, int64_t N,
-                                                             int cin, int cout, float* __restrict__ dx) {
+                                                             int cin, int cout, float* __restrict__ dx,
+                                                             const int64_t* __restrict__ n_dev) {
+  N = gpn::live_rows(n_dev, N);
   __shared__ __attribute__((aligned(16))) float Ws[kMaxC][kMaxC];  // [o][ci]
   for (int e = threadIdx.x; e < cout * cin; e += kThreads) Ws[e / cin][e % cin] = W[e];
   __syncthreads();
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(kThreads) void linear_dx_kernel(const float* __rest
 // chain of 16 load round trips per workgroup, 36 us per layer); thread (o, c) owns four adjacent ci of one o.
 __global__ __launch_bounds__(kThreads) void linear_dw_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                      int64_t N, int cin, int cout, int tile_rows,
-                                                                     float* __restrict__ partial) {
+                                                                     float* __restrict__ partial, const int64_t* __restrict__ n_dev) {
+  N = gpn::live_rows(n_dev, N);  // (workgroups past the live rows write zero partials: the sum below runs over the bound's)
   extern __shared__ __attribute__((aligned(16))) float lin_smem[];
   float* xs = lin_smem;                       // [tile_rows][cin]
   const int gp = cout + 1;                    // (odd pitch: the o-th column of consecutive rows in different banks)
@@ -228,16 +232,26 @@ inline int grid_for(int64_t total) {
 extern "C" int gpn_linear_supported(int cin, int cout) { return shape_ok(0, cin, cout) ? 1 : 0; }
 
 // y [N, cout] = x [N, cin] W^T + b;  W [cout, cin] (torch.nn.Linear's layout), b [cout] or NULL
-extern "C" int gpn_linear_fwd(const float* x, const float* W, const float* b, int64_t N, int cin, int cout, float* y,
-                              gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int linear_fwd_impl(const float* x, const float* W, const float* b, int64_t N, const gpn::DevRows& rows, int cin, int cout,
+                           float* y, hipStream_t stream) {
   GPN_CHECK_ARG(shape_ok(N, cin, cout));
   if (N == 0) return GPN_OK;
   GPN_CHECK_ARG(x && W && y);
   gpn::ProfScope prof(GPN_K_LINEAR, stream, 2.0 * (double)N * cin * cout, 4.0 * (double)N * (cin + cout));
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid_for(N * ((cout + 3) / 4))), dim3(kThreads), 0, stream, x, W, b, N, cin, cout, y);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid_for(gpn::plan_rows(N, rows) * ((cout + 3) / 4))), dim3(kThreads), 0, stream, x, W, b, N,
+                     cin, cout, y, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
+}
+extern "C" int gpn_linear_fwd(const float* x, const float* W, const float* b, int64_t N, int cin, int cout, float* y,
+                              gpn_stream_t stream_) {
+  return linear_fwd_impl(x, W, b, N, gpn::DevRows(), cin, cout, y, (hipStream_t)stream_);
+}
+// row count on the device (N = the bound of x / y)
+extern "C" int gpn_linear_fwd_dev(const float* x, const float* W, const float* b, int64_t N, const int64_t* n_dev, int64_t n_plan,
+                                  int cin, int cout, float* y, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(n_dev != nullptr);
+  return linear_fwd_impl(x, W, b, N, gpn::DevRows{n_dev, n_plan}, cin, cout, y, (hipStream_t)stream_);
 }
 
 extern "C" size_t gpn_linear_bwd_ws_bytes(int64_t N, int cin, int cout) {
@@ -245,9 +259,19 @@ extern "C" size_t gpn_linear_bwd_ws_bytes(int64_t N, int cin, int cout) {
 }
 
 // dx [N, cin] = dy W, dW [cout, cin] = dy^T x, db [cout] = column sums of dy; any of the three outputs may be NULL (skipped)
+static int linear_bwd_impl(const float* x, const float* W, const float* dy, int64_t N, const gpn::DevRows& rows, int cin, int cout,
+                           float* dx, float* dW, float* db, void* ws, size_t ws_bytes, hipStream_t stream);
 extern "C" int gpn_linear_bwd(const float* x, const float* W, const float* dy, int64_t N, int cin, int cout, float* dx, float* dW,
                               float* db, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return linear_bwd_impl(x, W, dy, N, gpn::DevRows(), cin, cout, dx, dW, db, ws, ws_bytes, (hipStream_t)stream_);
+}
+extern "C" int gpn_linear_bwd_dev(const float* x, const float* W, const float* dy, int64_t N, const int64_t* n_dev, int64_t n_plan,
+                                  int cin, int cout, float* dx, float* dW, float* db, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(n_dev != nullptr);
+  return linear_bwd_impl(x, W, dy, N, gpn::DevRows{n_dev, n_plan}, cin, cout, dx, dW, db, ws, ws_bytes, (hipStream_t)stream_);
+}
+static int linear_bwd_impl(const float* x, const float* W, const float* dy, int64_t N, const gpn::DevRows& rows, int cin, int cout,
+                           float* dx, float* dW, float* db, void* ws, size_t ws_bytes, hipStream_t stream) {
   GPN_CHECK_ARG(shape_ok(N, cin, cout));
   if (N == 0) {
     if (dW) GPN_CHECK_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)cout * cin, stream));
@@ -258,7 +282,8 @@ extern "C" int gpn_linear_bwd(const float* x, const float* W, const float* dy, i
   gpn::ProfScope prof(GPN_K_LINEAR, stream, (dx ? 2.0 : 0.0) * (double)N * cin * cout + (dW ? 2.0 : 0.0) * (double)N * cin * cout,
                       4.0 * (double)N * ((dx ? cin + cout : 0) + (dW || db ? cin + cout : 0)));
   if (dx) {
-    hipLaunchKernelGGL(linear_dx_kernel, dim3(grid_for(N * (cin / 4))), dim3(kThreads), 0, stream, dy, W, N, cin, cout, dx);
+    hipLaunchKernelGGL(linear_dx_kernel, dim3(grid_for(gpn::plan_rows(N, rows) * (cin / 4))), dim3(kThreads), 0, stream, dy, W, N, cin, cout,
+                       dx, rows.dev);
     GPN_CHECK_LAUNCH();
   }
   if (dW || db) {
@@ -271,7 +296,8 @@ extern "C" int gpn_linear_bwd(const float* x, const float* W, const float* dy, i
     float* partial = static_cast<float*>(ws);
     const int tile_rows = (size_t)kTileRows * (cin + cout + 1) * sizeof(float) <= 65536 ? kTileRows : kTileRows / 2;
     const size_t lds = (size_t)tile_rows * (cin + cout + 1) * sizeof(float);  // 22 KB for a 16 -> 27 head
-    hipLaunchKernelGGL(linear_dw_partial_kernel, dim3(blocks), dim3(kThreads), lds, stream, x, dy, N, cin, cout, tile_rows, partial);
+    hipLaunchKernelGGL(linear_dw_partial_kernel, dim3(blocks), dim3(kThreads), lds, stream, x, dy, N, cin, cout, tile_rows, partial,
+                       rows.dev);
     GPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(linear_dw_sum_kernel, dim3((cout * cin + cout + kThreads / 16 - 1) / (kThreads / 16)), dim3(kThreads), 0, stream,
                        (const float*)partial, blocks, cin, cout, dW, db);

@@ -269,10 +269,11 @@ __global__ __launch_bounds__(256) void npcs_loss_proposal_kernel(
     const float* __restrict__ logits, int n_cls3, const float* __restrict__ gt, const int32_t* __restrict__ sem_preds,
     const int64_t* __restrict__ sem_labels, const int32_t* __restrict__ proposal_offsets, int64_t P,
     const int64_t* __restrict__ sym_of_class, const float* __restrict__ mats, NpcsTypeInfo info,
-    float* __restrict__ best /* [P,3] */, int32_t* __restrict__ arg /* [P,3] */, int32_t* __restrict__ cnt /* [P,3] */) {
+    float* __restrict__ best /* [P,3] */, int32_t* __restrict__ arg /* [P,3] */, int32_t* __restrict__ cnt /* [P,3] */,
+    const int64_t* __restrict__ p_dev) {
   const int lane = threadIdx.x & 63;
-  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= P) return;
+  P = gpn::live_rows(p_dev, P);  // (device-counted proposals, gpn::DevRows: a wave walks proposals with a grid stride)
+  for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += (int64_t)gridDim.x * 4) {
   const int32_t b = proposal_offsets[p], e = proposal_offsets[p + 1];
   int members[3] = {0, 0, 0};
   for (int32_t m = b + lane; m < e; m += 64) {
@@ -333,11 +334,14 @@ __global__ __launch_bounds__(256) void npcs_loss_proposal_kernel(
       cnt[p * 3 + g] = members[g];
     }
   }
+  }
 }
 
 // loss = sum_g (sum over proposals with members of best) / (their number); stats = {n_has[3]} for the backward
 __global__ __launch_bounds__(1024) void npcs_loss_finish_kernel(const float* __restrict__ best, const int32_t* __restrict__ cnt,
-                                                                int64_t P, float* __restrict__ loss, float* __restrict__ n_has) {
+                                                                int64_t P, float* __restrict__ loss, float* __restrict__ n_has,
+                                                                const int64_t* __restrict__ p_dev) {
+  P = gpn::live_rows(p_dev, P);  // (no proposal: every group is empty, the loss is 0)
   __shared__ double ssum[3][1024];
   __shared__ int scnt[3][1024];
   double s[3] = {0.0, 0.0, 0.0};
@@ -375,26 +379,27 @@ __global__ __launch_bounds__(256) void npcs_loss_bwd_kernel(
     const int64_t* __restrict__ sem_labels, const int64_t* __restrict__ proposal_indices, int64_t M,
     const int64_t* __restrict__ sym_of_class, const float* __restrict__ mats, NpcsTypeInfo info,
     const int32_t* __restrict__ arg, const int32_t* __restrict__ cnt, const float* __restrict__ n_has,
-    const float* __restrict__ grad_loss, float* __restrict__ d_logits) {
-  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
-  float* drow = d_logits + m * n_cls3;
-  for (int c = 0; c < n_cls3; ++c) drow[c] = 0.f;
-  const int32_t cls = sem_preds[m];
-  const float gv[3] = {gt[m * 3], gt[m * 3 + 1], gt[m * 3 + 2]};
-  const bool valid = (int64_t)cls == sem_labels[m] && (gv[0] != 0.f || gv[1] != 0.f || gv[2] != 0.f);
-  if (!valid) return;
-  const int t = (int)sym_of_class[cls];
-  const int g = info.group[t];
-  const int64_t p = proposal_indices[m];
-  const float* row = logits + m * n_cls3 + 3 * (cls - 1);
-  const float pv[3] = {row[0], row[1], row[2]};
-  float r[3];
-  const float d2 = npcs_cost(pv, gv, mats + (info.first[t] + arg[p * 3 + g]) * 9, r);
-  const float coef = grad_loss[0] / (n_has[g] * (float)cnt[p * 3 + g]);
-  const float k = d2 <= 0.01f ? 10.f : 1.f / sqrtf(d2);
+    const float* __restrict__ grad_loss, float* __restrict__ d_logits, const int64_t* __restrict__ m_dev) {
+  M = gpn::live_rows(m_dev, M);
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    float* drow = d_logits + m * n_cls3;
+    for (int c = 0; c < n_cls3; ++c) drow[c] = 0.f;
+    const int32_t cls = sem_preds[m];
+    const float gv[3] = {gt[m * 3], gt[m * 3 + 1], gt[m * 3 + 2]};
+    const bool valid = (int64_t)cls == sem_labels[m] && (gv[0] != 0.f || gv[1] != 0.f || gv[2] != 0.f);
+    if (!valid) continue;
+    const int t = (int)sym_of_class[cls];
+    const int g = info.group[t];
+    const int64_t p = proposal_indices[m];
+    const float* row = logits + m * n_cls3 + 3 * (cls - 1);
+    const float pv[3] = {row[0], row[1], row[2]};
+    float r[3];
+    const float d2 = npcs_cost(pv, gv, mats + (info.first[t] + arg[p * 3 + g]) * 9, r);
+    const float coef = grad_loss[0] / (n_has[g] * (float)cnt[p * 3 + g]);
+    const float k = d2 <= 0.01f ? 10.f : 1.f / sqrtf(d2);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) drow[3 * (cls - 1) + c] = coef * k * r[c];
+    for (int c = 0; c < 3; ++c) drow[3 * (cls - 1) + c] = coef * k * r[c];
+  }
 }
 
 }  // namespace
@@ -402,12 +407,32 @@ __global__ __launch_bounds__(256) void npcs_loss_bwd_kernel(
 // sym_of_class [n_classes] i64 (symmetry type of every class, gapartnet.yaml symmetry_indices); mats [n_mats,3,3] f32 =
 // the candidate rotations of all types back to back; type_first / type_count / type_group [n_types] (host).
 // scratch [P * 9 + 4] floats (best [P,3] | arg [P,3] i32 | cnt [P,3] i32 | n_has [3]) is kept by the caller for the backward.
+static int npcs_loss_fwd_impl(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                              const int64_t* sem_labels, const int32_t* proposal_offsets, int64_t P, const gpn::DevRows& rows,
+                              const int64_t* sym_of_class, const float* mats, const int32_t* type_first, const int32_t* type_count,
+                              const int32_t* type_group, int n_types, float* loss, void* scratch, hipStream_t stream);
 extern "C" int gpn_npcs_loss_fwd(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
                                  const int64_t* sem_labels, const int32_t* proposal_offsets, int64_t P,
                                  const int64_t* sym_of_class, const float* mats, const int32_t* type_first,
                                  const int32_t* type_count, const int32_t* type_group, int n_types, float* loss, void* scratch,
                                  gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return npcs_loss_fwd_impl(logits, n_cls3, gt_npcs, sem_preds, sem_labels, proposal_offsets, P, gpn::DevRows(), sym_of_class, mats,
+                            type_first, type_count, type_group, n_types, loss, scratch, (hipStream_t)stream_);
+}
+// proposal count on the device (P = the bound of proposal_offsets and of the scratch layout)
+extern "C" int gpn_npcs_loss_fwd_dev(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                                     const int64_t* sem_labels, const int32_t* proposal_offsets, int64_t P, const int64_t* p_dev,
+                                     int64_t p_plan, const int64_t* sym_of_class, const float* mats, const int32_t* type_first,
+                                     const int32_t* type_count, const int32_t* type_group, int n_types, float* loss, void* scratch,
+                                     gpn_stream_t stream_) {
+  GPN_CHECK_ARG(p_dev != nullptr);
+  return npcs_loss_fwd_impl(logits, n_cls3, gt_npcs, sem_preds, sem_labels, proposal_offsets, P, gpn::DevRows{p_dev, p_plan},
+                            sym_of_class, mats, type_first, type_count, type_group, n_types, loss, scratch, (hipStream_t)stream_);
+}
+static int npcs_loss_fwd_impl(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                              const int64_t* sem_labels, const int32_t* proposal_offsets, int64_t P, const gpn::DevRows& rows,
+                              const int64_t* sym_of_class, const float* mats, const int32_t* type_first, const int32_t* type_count,
+                              const int32_t* type_group, int n_types, float* loss, void* scratch, hipStream_t stream) {
   GPN_CHECK_ARG(P >= 1 && n_cls3 >= 3 && n_types >= 1 && n_types <= 8);
   GPN_CHECK_ARG(logits && gt_npcs && sem_preds && sem_labels && proposal_offsets && sym_of_class && mats && loss && scratch);
   NpcsTypeInfo info;
@@ -420,20 +445,44 @@ extern "C" int gpn_npcs_loss_fwd(const float* logits, int n_cls3, const float* g
   int32_t* arg = reinterpret_cast<int32_t*>(best + P * 3);
   int32_t* cnt = arg + P * 3;
   float* n_has = reinterpret_cast<float*>(cnt + P * 3);
-  hipLaunchKernelGGL(npcs_loss_proposal_kernel, dim3((unsigned)gpn::cdiv(P, 4)), dim3(256), 0, stream, logits, n_cls3, gt_npcs,
-                     sem_preds, sem_labels, proposal_offsets, P, sym_of_class, mats, info, best, arg, cnt);
+  hipLaunchKernelGGL(npcs_loss_proposal_kernel, dim3(gpn::dev_grid(gpn::cdiv(P, 4), gpn::cdiv(gpn::plan_rows(P, rows), 4), rows.dev != nullptr)),
+                     dim3(256), 0, stream, logits, n_cls3, gt_npcs, sem_preds, sem_labels, proposal_offsets, P, sym_of_class, mats, info,
+                     best, arg, cnt, rows.dev);
   GPN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(npcs_loss_finish_kernel, dim3(1), dim3(1024), 0, stream, best, cnt, P, loss, n_has);
+  hipLaunchKernelGGL(npcs_loss_finish_kernel, dim3(1), dim3(1024), 0, stream, best, cnt, P, loss, n_has, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
+static int npcs_loss_bwd_impl(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                              const int64_t* sem_labels, const int64_t* proposal_indices, int64_t M, const gpn::DevRows& rows, int64_t P,
+                              const int64_t* sym_of_class, const float* mats, const int32_t* type_first, const int32_t* type_count,
+                              const int32_t* type_group, int n_types, const void* scratch, const float* grad_loss, float* d_logits,
+                              hipStream_t stream);
 extern "C" int gpn_npcs_loss_bwd(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
                                  const int64_t* sem_labels, const int64_t* proposal_indices, int64_t M, int64_t P,
                                  const int64_t* sym_of_class, const float* mats, const int32_t* type_first,
                                  const int32_t* type_count, const int32_t* type_group, int n_types, const void* scratch,
                                  const float* grad_loss, float* d_logits, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return npcs_loss_bwd_impl(logits, n_cls3, gt_npcs, sem_preds, sem_labels, proposal_indices, M, gpn::DevRows(), P, sym_of_class, mats,
+                            type_first, type_count, type_group, n_types, scratch, grad_loss, d_logits, (hipStream_t)stream_);
+}
+// point count on the device (M = the bound of the per-point arrays; P = the bound the forward call's scratch was laid out for)
+extern "C" int gpn_npcs_loss_bwd_dev(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                                     const int64_t* sem_labels, const int64_t* proposal_indices, int64_t M, const int64_t* m_dev,
+                                     int64_t m_plan, int64_t P, const int64_t* sym_of_class, const float* mats,
+                                     const int32_t* type_first, const int32_t* type_count, const int32_t* type_group, int n_types,
+                                     const void* scratch, const float* grad_loss, float* d_logits, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(m_dev != nullptr);
+  return npcs_loss_bwd_impl(logits, n_cls3, gt_npcs, sem_preds, sem_labels, proposal_indices, M, gpn::DevRows{m_dev, m_plan}, P,
+                            sym_of_class, mats, type_first, type_count, type_group, n_types, scratch, grad_loss, d_logits,
+                            (hipStream_t)stream_);
+}
+static int npcs_loss_bwd_impl(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds,
+                              const int64_t* sem_labels, const int64_t* proposal_indices, int64_t M, const gpn::DevRows& rows, int64_t P,
+                              const int64_t* sym_of_class, const float* mats, const int32_t* type_first, const int32_t* type_count,
+                              const int32_t* type_group, int n_types, const void* scratch, const float* grad_loss, float* d_logits,
+                              hipStream_t stream) {
   GPN_CHECK_ARG(M >= 0 && P >= 1 && n_types >= 1 && n_types <= 8);
   if (M == 0) return GPN_OK;
   GPN_CHECK_ARG(logits && gt_npcs && sem_preds && sem_labels && proposal_indices && scratch && grad_loss && d_logits);
@@ -444,8 +493,9 @@ extern "C" int gpn_npcs_loss_bwd(const float* logits, int n_cls3, const float* g
   const int32_t* arg = reinterpret_cast<const int32_t*>(best + P * 3);
   const int32_t* cnt = arg + P * 3;
   const float* n_has = reinterpret_cast<const float*>(cnt + P * 3);
-  hipLaunchKernelGGL(npcs_loss_bwd_kernel, dim3((unsigned)gpn::cdiv(M, 256)), dim3(256), 0, stream, logits, n_cls3, gt_npcs,
-                     sem_preds, sem_labels, proposal_indices, M, sym_of_class, mats, info, arg, cnt, n_has, grad_loss, d_logits);
+  hipLaunchKernelGGL(npcs_loss_bwd_kernel, dim3(gpn::dev_grid(gpn::cdiv(M, 256), gpn::cdiv(gpn::plan_rows(M, rows), 256), rows.dev != nullptr)),
+                     dim3(256), 0, stream, logits, n_cls3, gt_npcs, sem_preds, sem_labels, proposal_indices, M, sym_of_class, mats, info,
+                     arg, cnt, n_has, grad_loss, d_logits, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -470,9 +520,14 @@ __global__ __launch_bounds__(kThreads) void score_loss_kernel(const float* __res
                                                               const int32_t* __restrict__ offsets, const float* __restrict__ ious,
                                                               int I, int64_t P, float fg, float bg, float k, float b,
                                                               float* __restrict__ loss, float* __restrict__ score_preds,
-                                                              float* __restrict__ d_logits) {
+                                                              float* __restrict__ d_logits, const int64_t* __restrict__ p_dev) {
   __shared__ double scratch[4];
   double acc = 0.0, bad = 0.0;
+  P = gpn::live_rows(p_dev, P);
+  if (P == 0) {  // (only with a device-counted P: no proposal survived - the term is absent from the step, model.py:560)
+    if (threadIdx.x == 0) loss[0] = 0.f;
+    return;
+  }
   const float inv_p = 1.0f / (float)P;
   for (int64_t p = threadIdx.x; p < P; p += kThreads) {
     const int32_t first = offsets[p];
@@ -505,17 +560,33 @@ __global__ __launch_bounds__(kThreads) void score_loss_kernel(const float* __res
 
 // logits [P, C1] f32; cls_i64 / cls_i32: per proposal-point class (exactly one non-NULL); offsets [P+1] i32 (CSR of the
 // proposals); ious [P, I] f32 (gpn_instance_iou).  Outputs: loss [1], score_preds [P], d_logits [P, C1] (fully written).
+static int score_loss_impl(const float* logits, int C1, const int64_t* cls_i64, const int32_t* cls_i32, const int32_t* offsets,
+                           const float* ious, int I, int64_t P, const int64_t* p_dev, float fg_thresh, float bg_thresh, float* loss,
+                           float* score_preds, float* d_logits, hipStream_t stream);
 extern "C" int gpn_score_loss(const float* logits, int C1, const int64_t* cls_i64, const int32_t* cls_i32, const int32_t* offsets,
                               const float* ious, int I, int64_t P, float fg_thresh, float bg_thresh, float* loss,
                               float* score_preds, float* d_logits, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return score_loss_impl(logits, C1, cls_i64, cls_i32, offsets, ious, I, P, nullptr, fg_thresh, bg_thresh, loss, score_preds, d_logits,
+                         (hipStream_t)stream_);
+}
+// proposal count on the device (P = the bound of the per-proposal arrays); *p_dev == 0 gives loss 0 and writes nothing else
+extern "C" int gpn_score_loss_dev(const float* logits, int C1, const int64_t* cls_i64, const int32_t* cls_i32, const int32_t* offsets,
+                                  const float* ious, int I, int64_t P, const int64_t* p_dev, float fg_thresh, float bg_thresh,
+                                  float* loss, float* score_preds, float* d_logits, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(p_dev != nullptr);
+  return score_loss_impl(logits, C1, cls_i64, cls_i32, offsets, ious, I, P, p_dev, fg_thresh, bg_thresh, loss, score_preds, d_logits,
+                         (hipStream_t)stream_);
+}
+static int score_loss_impl(const float* logits, int C1, const int64_t* cls_i64, const int32_t* cls_i32, const int32_t* offsets,
+                           const float* ious, int I, int64_t P, const int64_t* p_dev, float fg_thresh, float bg_thresh, float* loss,
+                           float* score_preds, float* d_logits, hipStream_t stream) {
   GPN_CHECK_ARG(P >= 1 && C1 >= 1 && I >= 1 && fg_thresh > bg_thresh);
   GPN_CHECK_ARG(logits && offsets && ious && loss && score_preds && d_logits && ((cls_i64 != nullptr) != (cls_i32 != nullptr)));
   // (the reference computes k and b in Python doubles and multiplies / adds float tensors by them: rounded to float here)
   const float k = (float)(1.0 / ((double)fg_thresh - (double)bg_thresh));
   const float b = (float)((double)bg_thresh / ((double)bg_thresh - (double)fg_thresh));
   hipLaunchKernelGGL(score_loss_kernel, dim3(1), dim3(kThreads), 0, stream, logits, C1, cls_i64, cls_i32, offsets, ious, I, P,
-                     fg_thresh, bg_thresh, k, b, loss, score_preds, d_logits);
+                     fg_thresh, bg_thresh, k, b, loss, score_preds, d_logits, p_dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

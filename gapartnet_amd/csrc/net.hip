@@ -48,7 +48,9 @@ struct ConcatPtrs {
   const float4* b;
   float4* dst;
 };
-__global__ __launch_bounds__(kThreads) void concat_kernel(ConcatPtrs pa, ConcatPtrs pb, int64_t rows, int ca4, int cb4) {
+__global__ __launch_bounds__(kThreads) void concat_kernel(ConcatPtrs pa, ConcatPtrs pb, int64_t rows, int ca4, int cb4,
+                                                          const int64_t* __restrict__ rows_dev) {
+  rows = gpn::live_rows(rows_dev, rows);
   const ConcatPtrs& p = blockIdx.y ? pb : pa;
   const float4* __restrict__ a = p.a;
   const float4* __restrict__ b = p.b;
@@ -69,7 +71,8 @@ struct SplitPtrs {
   float4* db;
 };
 __global__ __launch_bounds__(kThreads) void split_kernel(SplitPtrs pa, SplitPtrs pb, int64_t rows, int ca4, int cb4, int acc_a,
-                                                         int acc_b) {
+                                                         int acc_b, const int64_t* __restrict__ rows_dev) {
+  rows = gpn::live_rows(rows_dev, rows);
   const SplitPtrs& pp = blockIdx.y ? pb : pa;
   const float4* __restrict__ dsrc = pp.dsrc;
   float4* __restrict__ da = pp.da;
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(kThreads) void split_kernel(SplitPtrs pa, SplitPtrs
 }
 
 __global__ __launch_bounds__(kThreads) void accumulate_kernel(float4* __restrict__ dst, const float4* __restrict__ src,
-                                                              int64_t total4) {
+                                                              int64_t total4, int c4, const int64_t* __restrict__ rows_dev) {
+  if (rows_dev) total4 = gpn::live_rows(rows_dev, total4 / c4) * c4;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kThreads) {
     float4 o = dst[i];
     const float4 g = src[i];
@@ -130,6 +134,8 @@ inline int grid_for(int64_t total) {
 }
 
 inline size_t slot_bytes(const gpn_net_slot_t& s) { return (size_t)s.rows * s.channels * sizeof(float); }
+inline gpn::DevRows dev_rows(const gpn_net_slot_t& s) { return gpn::DevRows{s.rows_dev, s.rows_plan}; }
+inline int64_t plan_of(const gpn_net_slot_t& s) { return gpn::plan_rows(s.rows, dev_rows(s)); }
 
 // partials of the layers whose slice sums are batched into one launch: at most this much (they are written and read back
 // within a few launches - the bound keeps them inside the 256 MB memory-side cache)
@@ -359,7 +365,10 @@ int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const 
         if (cv_op.kind != GPN_NET_CONV || bn_op.kind != GPN_NET_BN || bn_op.src0 != cv_op.dst || readers[cv_op.dst] != 1) continue;
         const gpn_net_rulebook_t& rb = rbs[cv_op.rulebook];
         const gpn_net_conv_t& cv = nets[t].convs[cv_op.param];
-        if (!gpn::bn_two_pass(rb.n_dst, cv.cout) || !gpn::spconv_fwd_accumulates_stats(rb.K, rb.n_dst, cv.cin, cv.cout)) continue;
+        const gpn_net_slot_t& out_slot = nets[0].slots[cv_op.dst];
+        if (!gpn::bn_two_pass(plan_of(out_slot), cv.cout) ||
+            !gpn::spconv_fwd_accumulates_stats(rb.K, rb.n_dst, cv.cin, cv.cout, dev_rows(out_slot)))
+          continue;
         slab_of[t][i] = slab_of[t][i + 1] = reinterpret_cast<unsigned long long*>(area + off);
         off += gpn::stat_slab_bytes(cv.cout);
       }
@@ -380,7 +389,7 @@ int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const 
       const gpn_net_conv_t& cv = nets[0].convs[op.param];
       gpn::ConvStats st;
       st.slab = slab_of[0][i];
-      st.slot_mask = gpn::stat_slot_count(rb.n_dst) - 1;
+      st.slot_mask = gpn::stat_slot_count(plan_of(d)) - 1;
       if (pair) {
         st.twin.in = nets[1].slots[op.src0].data;
         st.twin.packed = packed_of[1][i];
@@ -388,7 +397,7 @@ int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const 
         st.twin.slab = slab_of[1][i];
       }
       rc = gpn::spconv_fwd_into(s0.data, packed_of[0][i], rb.nbr, rb.nbr_p, rb.perm, rb.K, rb.n_dst, cv.cin, cv.cout, d.data, 0, st,
-                                op_ws, op_ws_bytes, stream);
+                                op_ws, op_ws_bytes, stream, dev_rows(d));
     } else if (op.kind == GPN_NET_BN) {
       const int relu = (op.flags & GPN_NET_RELU) ? 1 : 0;
       gpn::BnFwdPtrs pp[2];
@@ -404,15 +413,15 @@ int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const 
       const gpn_net_bn_t& bn0 = nets[0].bns[op.param];
       const bool together = pair && nets[1].bns[op.param].eps == bn0.eps && nets[1].bns[op.param].momentum == bn0.momentum;
       if (training && slab_of[0][i] && together) {
-        rc = gpn::bn_fwd_train_fused(pp[0], &pp[1], s0.rows, bn0.C, bn0.eps, bn0.momentum, relu, stream);
+        rc = gpn::bn_fwd_train_fused(pp[0], &pp[1], s0.rows, bn0.C, bn0.eps, bn0.momentum, relu, stream, dev_rows(s0));
       } else {
         for (int t = 0; t < n_nets && rc == GPN_OK; ++t) {
           const gpn_net_bn_t& bn = nets[t].bns[op.param];
           if (training && slab_of[t][i]) {
-            rc = gpn::bn_fwd_train_fused(pp[t], nullptr, s0.rows, bn.C, bn.eps, bn.momentum, relu, stream);
+            rc = gpn::bn_fwd_train_fused(pp[t], nullptr, s0.rows, bn.C, bn.eps, bn.momentum, relu, stream, dev_rows(s0));
           } else if (training) {
-            rc = gpn_bn_fwd_train(pp[t].x, pp[t].res, bn.weight, bn.bias, s0.rows, bn.C, bn.eps, bn.momentum, relu, pp[t].y,
-                                  bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, op_ws, op_ws_bytes, (gpn_stream_t)stream);
+            rc = gpn::bn_fwd_train_rows(pp[t].x, pp[t].res, bn.weight, bn.bias, s0.rows, dev_rows(s0), bn.C, bn.eps, bn.momentum, relu,
+                                        pp[t].y, bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, op_ws, op_ws_bytes, stream);
           } else {
             if (!bn.running_mean || !bn.running_var || !bn.save_invstd) {
               gpn::set_error("%s: op %d: eval-mode BatchNorm needs running statistics", who, i);
@@ -421,8 +430,8 @@ int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const 
             hipLaunchKernelGGL(invstd_kernel, dim3((bn.C + 63) / 64), dim3(64), 0, stream, bn.running_var, bn.eps, bn.C,
                                bn.save_invstd);
             GPN_CHECK_LAUNCH();
-            rc = gpn_bn_fwd_eval(pp[t].x, pp[t].res, bn.weight, bn.bias, bn.running_mean, bn.save_invstd, s0.rows, bn.C, relu,
-                                 pp[t].y, (gpn_stream_t)stream);
+            rc = gpn::bn_fwd_eval_rows(pp[t].x, pp[t].res, bn.weight, bn.bias, bn.running_mean, bn.save_invstd, s0.rows,
+                                       dev_rows(s0), bn.C, relu, pp[t].y, stream);
           }
         }
       }
@@ -432,8 +441,8 @@ int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const 
       if (pair)
         cb = ConcatPtrs{(const float4*)nets[1].slots[op.src0].data, (const float4*)nets[1].slots[op.src1].data,
                         (float4*)nets[1].slots[op.dst].data};
-      hipLaunchKernelGGL(concat_kernel, dim3(grid_for(d.rows * (d.channels / 4)), n_nets), dim3(kThreads), 0, stream, ca, cb,
-                         d.rows, s0.channels / 4, s1.channels / 4);
+      hipLaunchKernelGGL(concat_kernel, dim3(grid_for(plan_of(d) * (d.channels / 4)), n_nets), dim3(kThreads), 0, stream, ca, cb,
+                         d.rows, s0.channels / 4, s1.channels / 4, d.rows_dev);
       GPN_CHECK_LAUNCH();
       rc = GPN_OK;
     }
@@ -497,6 +506,7 @@ struct WgradJob {
   const int32_t *pair_src, *pair_dst, *tile_off;
   int K;
   int64_t n_dst;
+  gpn::DevRows rows;  // n_dst is a bound and the live count of destination rows a device counter (or {nullptr, 0})
   int cin, cout;
   float* dW;
   hipEvent_t after;  // recorded on the caller's stream once dout is final
@@ -579,7 +589,7 @@ class WgradWorker {
       WgradJob group[gpn::kWgradSets];
       int n_group = 0, group_sets = 0;
       auto same_shape = [](const WgradJob& a, const WgradJob& b) {
-        return a.K == b.K && a.n_dst == b.n_dst && a.cin == b.cin && a.cout == b.cout;
+        return a.K == b.K && a.n_dst == b.n_dst && a.cin == b.cin && a.cout == b.cout && a.rows.dev == b.rows.dev;
       };
       auto launch_group = [&]() -> int {
         if (!n_group) return GPN_OK;
@@ -599,7 +609,7 @@ class WgradWorker {
           }
           return GPN_OK;
         }
-        const int S = gpn::wgrad_slices(j0.K, j0.cin, j0.cout, j0.n_dst);
+        const int S = gpn::wgrad_slices(j0.K, j0.cin, j0.cout, gpn::plan_rows(j0.n_dst, j0.rows));
         const size_t bytes = gpn::align_up((size_t)S * elems * sizeof(float));
         if (used + n_sets * bytes > room || n_pending + n_sets > gpn::kWgradReduceJobs) flush();
         if (n_sets * bytes > ws_bytes_ || !ws_) {
@@ -619,7 +629,7 @@ class WgradWorker {
             sets.s[sets.n++] = gpn::WgradSet{j.in2, j.dout2, j.pair_src, j.pair_dst, j.tile_off, partial};
           }
         }
-        const int rc = gpn::wgrad_contract(sets, j0.K, j0.n_dst, j0.cin, j0.cout, S, side_);
+        const int rc = gpn::wgrad_contract(sets, j0.K, j0.n_dst, j0.cin, j0.cout, S, side_, j0.rows.dev);
         if (rc != GPN_OK) return rc;
         for (int q = 0; q < sets.n; ++q)
           pending[n_pending++] = gpn::wgrad_reduce_job(sets.s[q].partial, S, j0.K, j0.cin, j0.cout, GPN_LAYOUT_OKI, dW_of[q]);
@@ -629,7 +639,7 @@ class WgradWorker {
       auto issue = [&](const WgradJob& j) -> int {
         const int n_sets = j.dW2 ? 2 : 1;
         // (a layer with many rows fills the chip on its own: holding it back only delays it)
-        const int limit = j.n_dst < g_wgrad_group_rows ? g_wgrad_group.load(std::memory_order_relaxed) : 1;
+        const int limit = gpn::plan_rows(j.n_dst, j.rows) < g_wgrad_group_rows ? g_wgrad_group.load(std::memory_order_relaxed) : 1;
         if (n_group && (!same_shape(group[0], j) || group_sets + n_sets > limit)) {
           const int rc = launch_group();
           if (rc != GPN_OK) return rc;
@@ -704,8 +714,8 @@ inline GradTarget grad_target(gpn_net_slot_t& s, float* tmp) {
 int commit(gpn_net_slot_t& s, const GradTarget& t, hipStream_t stream) {
   if (t.staged) {
     const int64_t total4 = s.rows * s.channels / 4;
-    hipLaunchKernelGGL(accumulate_kernel, dim3(grid_for(total4)), dim3(kThreads), 0, stream, (float4*)s.grad,
-                       (const float4*)t.ptr, total4);
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid_for(plan_of(s) * s.channels / 4)), dim3(kThreads), 0, stream, (float4*)s.grad,
+                       (const float4*)t.ptr, total4, s.channels / 4, s.rows_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
       gpn::set_error("gpn_net_backward: accumulate launch failed: %s", hipGetErrorString(e));
@@ -768,7 +778,10 @@ int net_backward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const
       if (ops[i].src0 == 0 && !need_input_grad) continue;
       const gpn_net_rulebook_t& rb = rbs[ops[i].rulebook];
       const gpn_net_conv_t& cv = nets[0].convs[ops[i].param];
-      if (!gpn::bn_two_pass(rb.n_src, cv.cin) || !gpn::spconv_fwd_accumulates_stats(rb.K, rb.n_src, cv.cout, cv.cin)) continue;
+      const gpn_net_slot_t& in_slot = nets[0].slots[ops[i].src0];
+      if (!gpn::bn_two_pass(plan_of(in_slot), cv.cin) ||
+          !gpn::spconv_fwd_accumulates_stats(rb.K, rb.n_src, cv.cout, cv.cin, dev_rows(in_slot)))
+        continue;
       for (int t = 0; t < n_nets; ++t)
         bn_slab[t][j] = reinterpret_cast<unsigned long long*>(base + t * per_net + need.tmp + need.packed + off);
       off += gpn::stat_slab_bytes(cv.cin);
@@ -832,13 +845,13 @@ int net_backward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const
         GPN_CHECK_HIP(hipEventRecord(ev, stream));
         if (pair && nets[0].convs[op.param].dW && nets[1].convs[op.param].dW) {
           worker.push(WgradJob{nets[0].slots[op.src0].data, nets[0].slots[op.dst].grad, rb.pair_src, rb.pair_dst, rb.tile_off,
-                               rb.K, rb.n_dst, cv.cin, cv.cout, nets[0].convs[op.param].dW, ev, nets[1].slots[op.src0].data,
+                               rb.K, rb.n_dst, dev_rows(d), cv.cin, cv.cout, nets[0].convs[op.param].dW, ev, nets[1].slots[op.src0].data,
                                nets[1].slots[op.dst].grad, nets[1].convs[op.param].dW});
         } else {
           for (int t = 0; t < n_nets; ++t)
             if (nets[t].convs[op.param].dW)
               worker.push(WgradJob{nets[t].slots[op.src0].data, nets[t].slots[op.dst].grad, rb.pair_src, rb.pair_dst, rb.tile_off,
-                                   rb.K, rb.n_dst, cv.cin, cv.cout, nets[t].convs[op.param].dW, ev, nullptr, nullptr, nullptr});
+                                   rb.K, rb.n_dst, dev_rows(d), cv.cin, cv.cout, nets[t].convs[op.param].dW, ev, nullptr, nullptr, nullptr});
         }
         forked = true;
       }
@@ -859,7 +872,7 @@ int net_backward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const
           const gpn_net_op_t& bo = ops[fused_by[i]];
           const gpn_net_bn_t& bn = nets[0].bns[bo.param];
           st.slab = bn_slab[0][fused_by[i]];
-          st.slot_mask = gpn::stat_slot_count(rb.n_src) - 1;
+          st.slot_mask = gpn::stat_slot_count(plan_of(s0)) - 1;
           st.x = nets[0].slots[bo.src0].data;
           st.y = s0.data;
           st.mean = training ? bn.save_mean : bn.running_mean;
@@ -876,7 +889,7 @@ int net_backward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const
           sums_done[fused_by[i]] = 1;
         }
         rc = gpn::spconv_fwd_into(d.grad, packed_of[0][i], rb.nbr_t, rb.nbr_t_p, rb.perm_t, rb.K, rb.n_src, cv.cout, cv.cin, s0.grad,
-                                  s0.grad_state ? 1 : 0, st, op_ws, op_ws_bytes, stream);
+                                  s0.grad_state ? 1 : 0, st, op_ws, op_ws_bytes, stream, dev_rows(s0));
         if (rc) return rc;
         for (int t = 0; t < n_nets; ++t) nets[t].slots[op.src0].grad_state = 1;
       }
@@ -911,14 +924,14 @@ int net_backward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const
       }
       const gpn_net_bn_t& bn0 = nets[0].bns[op.param];
       if (sums_done[i] && pair) {
-        rc = gpn::bn_bwd_fused(pp[0], &pp[1], s0.rows, bn0.C, relu, training ? 1 : 0, stream);
+        rc = gpn::bn_bwd_fused(pp[0], &pp[1], s0.rows, bn0.C, relu, training ? 1 : 0, stream, dev_rows(s0));
       } else {
         for (int t = 0; t < n_nets && rc == GPN_OK; ++t) {
           if (sums_done[i])
-            rc = gpn::bn_bwd_fused(pp[t], nullptr, s0.rows, bn0.C, relu, training ? 1 : 0, stream);
+            rc = gpn::bn_bwd_fused(pp[t], nullptr, s0.rows, bn0.C, relu, training ? 1 : 0, stream, dev_rows(s0));
           else
-            rc = gpn_bn_bwd(pp[t].x, pp[t].y, pp[t].dy, pp[t].weight, pp[t].mean, pp[t].invstd, s0.rows, bn0.C, relu,
-                            training ? 1 : 0, pp[t].dx, pp[t].dres, pp[t].dweight, pp[t].dbias, op_ws, op_ws_bytes, (gpn_stream_t)stream);
+            rc = gpn::bn_bwd_rows(pp[t].x, pp[t].y, pp[t].dy, pp[t].weight, pp[t].mean, pp[t].invstd, s0.rows, dev_rows(s0), bn0.C, relu,
+                                  training ? 1 : 0, pp[t].dx, pp[t].dres, pp[t].dweight, pp[t].dbias, op_ws, op_ws_bytes, stream);
         }
       }
       if (rc) return rc;
@@ -940,8 +953,8 @@ int net_backward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const
       if (pair)
         sb = SplitPtrs{(const float4*)nets[1].slots[op.dst].grad, (float4*)nets[1].slots[op.src0].grad,
                        (float4*)nets[1].slots[op.src1].grad};
-      hipLaunchKernelGGL(split_kernel, dim3(grid_for(d.rows * (d.channels / 4)), n_nets), dim3(kThreads), 0, stream, sa, sb, d.rows,
-                         s0.channels / 4, s1.channels / 4, s0.grad_state, s1.grad_state);
+      hipLaunchKernelGGL(split_kernel, dim3(grid_for(plan_of(d) * (d.channels / 4)), n_nets), dim3(kThreads), 0, stream, sa, sb, d.rows,
+                         s0.channels / 4, s1.channels / 4, s0.grad_state, s1.grad_state, d.rows_dev);
       GPN_CHECK_LAUNCH();
       for (int t = 0; t < n_nets; ++t) nets[t].slots[op.src0].grad_state = nets[t].slots[op.src1].grad_state = 1;
     }

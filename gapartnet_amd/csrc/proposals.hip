@@ -302,15 +302,32 @@ __global__ __launch_bounds__(kThreads) void prop_voxel_mean_kernel(const float* 
                                                                    const int64_t* __restrict__ point_indices,
                                                                    const int32_t* __restrict__ order,
                                                                    const int32_t* __restrict__ vstart, int64_t V, int C,
-                                                                   float* __restrict__ out) {
-  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  const int64_t v = t / C;
-  const int c = (int)(t - v * C);
-  if (v >= V) return;
-  const int32_t b = vstart[v], e = vstart[v + 1];
-  float acc = 0.f;
-  for (int32_t j = b; j < e; ++j) acc = __fadd_rn(acc, feats[point_indices[order[j]] * C + c]);
-  out[v * C + c] = __fdiv_rn(acc, (float)(e - b));
+                                                                   float* __restrict__ out, const int64_t* __restrict__ v_dev) {
+  V = gpn::live_rows(v_dev, V);  // (device-counted voxel rows, gpn::DevRows: grid-stride walk)
+  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < V * C; t += (int64_t)gridDim.x * kThreads) {
+    const int64_t v = t / C;
+    const int c = (int)(t - v * C);
+    const int32_t b = vstart[v], e = vstart[v + 1];
+    float acc = 0.f;
+    for (int32_t j = b; j < e; ++j) acc = __fadd_rn(acc, feats[point_indices[order[j]] * C + c]);
+    out[v * C + c] = __fdiv_rn(acc, (float)(e - b));
+  }
+}
+
+// per-point targets of the proposal points: sem_labels / gt_npcs rows of the points the proposals are made of (the
+// reference's sem_labels[rows], gt_npcs[rows] index ops, model.py:556-571) with the point count on the device
+__global__ __launch_bounds__(kThreads) void prop_targets_kernel(const int64_t* __restrict__ sem_labels, const float* __restrict__ gt_npcs,
+                                                                const int64_t* __restrict__ point_indices, int64_t M,
+                                                                const int64_t* __restrict__ m_dev, int64_t* __restrict__ sem_out,
+                                                                float* __restrict__ npcs_out) {
+  M = gpn::live_rows(m_dev, M);
+  for (int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x; m < M; m += (int64_t)gridDim.x * kThreads) {
+    const int64_t i = point_indices[m];
+    if (sem_labels) sem_out[m] = sem_labels[i];
+    if (gt_npcs) {
+      npcs_out[m * 3] = gt_npcs[i * 3], npcs_out[m * 3 + 1] = gt_npcs[i * 3 + 1], npcs_out[m * 3 + 2] = gt_npcs[i * 3 + 2];
+    }
+  }
 }
 
 // d feats[i] = sum over the (at most two) proposals point i belongs to of d out[voxel] / count[voxel]; set A's membership
@@ -506,14 +523,39 @@ extern "C" int gpn_proposals_build(const float* points, int point_stride, const 
                                    stream_);
 }
 
-extern "C" int gpn_proposals_voxel_mean(const float* feats, const int64_t* point_indices, const int32_t* point_order,
-                                        const int32_t* voxel_point_start, int64_t V, int C, float* out, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int voxel_mean_impl(const float* feats, const int64_t* point_indices, const int32_t* point_order,
+                           const int32_t* voxel_point_start, int64_t V, const gpn::DevRows& rows, int C, float* out, hipStream_t stream) {
   GPN_CHECK_ARG(V >= 0 && C >= 1);
   if (V == 0) return GPN_OK;
   GPN_CHECK_ARG(feats && point_indices && point_order && voxel_point_start && out);
-  hipLaunchKernelGGL(prop_voxel_mean_kernel, dim3(grid_of(V * C)), dim3(kThreads), 0, stream, feats, point_indices, point_order,
-                     voxel_point_start, V, C, out);
+  hipLaunchKernelGGL(prop_voxel_mean_kernel,
+                     dim3(gpn::dev_grid(gpn::cdiv(V * C, kThreads), gpn::cdiv(gpn::plan_rows(V, rows) * C, kThreads), rows.dev != nullptr)),
+                     dim3(kThreads), 0, stream, feats, point_indices, point_order, voxel_point_start, V, C, out, rows.dev);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_proposals_voxel_mean(const float* feats, const int64_t* point_indices, const int32_t* point_order,
+                                        const int32_t* voxel_point_start, int64_t V, int C, float* out, gpn_stream_t stream_) {
+  return voxel_mean_impl(feats, point_indices, point_order, voxel_point_start, V, gpn::DevRows(), C, out, (hipStream_t)stream_);
+}
+// voxel count on the device (V = the bound of `out`)
+extern "C" int gpn_proposals_voxel_mean_dev(const float* feats, const int64_t* point_indices, const int32_t* point_order,
+                                            const int32_t* voxel_point_start, int64_t V, const int64_t* v_dev, int64_t v_plan, int C,
+                                            float* out, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(v_dev != nullptr);
+  return voxel_mean_impl(feats, point_indices, point_order, voxel_point_start, V, gpn::DevRows{v_dev, v_plan}, C, out,
+                         (hipStream_t)stream_);
+}
+// sem_labels [N] i64 and / or gt_npcs [N,3] f32 at the proposal points: sem_out [M] i64, npcs_out [M,3] f32 for the first *m_dev
+// of the M rows (either source may be NULL)
+extern "C" int gpn_proposals_targets_dev(const int64_t* sem_labels, const float* gt_npcs, const int64_t* point_indices, int64_t M,
+                                         const int64_t* m_dev, int64_t m_plan, int64_t* sem_out, float* npcs_out, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(M >= 1 && m_dev && point_indices && (!sem_labels || sem_out) && (!gt_npcs || npcs_out));
+  hipLaunchKernelGGL(prop_targets_kernel,
+                     dim3(gpn::dev_grid(gpn::cdiv(M, kThreads), gpn::cdiv(gpn::plan_rows(M, gpn::DevRows{m_dev, m_plan}), kThreads), true)),
+                     dim3(kThreads), 0, stream, sem_labels, gt_npcs, point_indices, M, m_dev, sem_out, npcs_out);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

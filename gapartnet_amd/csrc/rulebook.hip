@@ -30,23 +30,26 @@ __device__ __forceinline__ uint64_t lin_key(int b, int x, int y, int z, int s0, 
   return (((uint64_t)b * (uint64_t)s0 + (uint64_t)x) * (uint64_t)s1 + (uint64_t)y) * (uint64_t)s2 + (uint64_t)z;
 }
 
+// (every builder kernel below takes the row count either as an argument or - n_dev != nullptr, gpn::DevRows - from a device
+// counter, and walks its elements with a grid stride: one round when the grid was sized from the count)
 __global__ void hash_insert_kernel(const int32_t* __restrict__ indices, int64_t N, int s0, int s1, int s2,
                                    uint64_t* __restrict__ hkeys, int32_t* __restrict__ hvals,
-                                   uint64_t mask) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int4 c = reinterpret_cast<const int4*>(indices)[i];
-  const uint64_t key = lin_key(c.x, c.y, c.z, c.w, s0, s1, s2);
-  uint64_t slot = mix64(key) & mask;
-  while (true) {
-    unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(hkeys + slot),
-                                        (unsigned long long)kEmpty, (unsigned long long)key);
-    if (prev == kEmpty || prev == key) {
-      // duplicates: the highest row id wins deterministically
-      atomicMax(hvals + slot, (int32_t)i);
-      return;
+                                   uint64_t mask, const int64_t* __restrict__ n_dev) {
+  N = gpn::live_rows(n_dev, N);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[i];
+    const uint64_t key = lin_key(c.x, c.y, c.z, c.w, s0, s1, s2);
+    uint64_t slot = mix64(key) & mask;
+    while (true) {
+      unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(hkeys + slot),
+                                          (unsigned long long)kEmpty, (unsigned long long)key);
+      if (prev == kEmpty || prev == key) {
+        // duplicates: the highest row id wins deterministically
+        atomicMax(hvals + slot, (int32_t)i);
+        break;
+      }
+      slot = (slot + 1) & mask;
     }
-    slot = (slot + 1) & mask;
   }
 }
 
@@ -65,21 +68,22 @@ __device__ __forceinline__ int32_t hash_find(const uint64_t* __restrict__ hkeys,
 // table[k][o] = row of the voxel at coord(o)+delta_k, or -1.  One thread per (k,o); o fastest.
 __global__ void subm3_lookup_kernel(const int32_t* __restrict__ indices, int64_t N, int s0, int s1, int s2,
                                     const uint64_t* __restrict__ hkeys, const int32_t* __restrict__ hvals,
-                                    uint64_t mask, int32_t* __restrict__ table) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 27 * N) return;
-  if (t == 0) table[27 * N] = -1;  // sentinel entry behind the table (the compaction scan runs over 27 N + 1 entries)
-  const int k = (int)(t / N);
-  const int64_t o = t - (int64_t)k * N;
-  const int4 c = reinterpret_cast<const int4*>(indices)[o];
-  const int x = c.y + (k / 9 - 1), y = c.z + ((k / 3) % 3 - 1), z = c.w + (k % 3 - 1);
-  int32_t r = -1;
-  if (k == 13) {
-    r = (int32_t)o;  // centre tap: the row itself
-  } else if (x >= 0 && x < s0 && y >= 0 && y < s1 && z >= 0 && z < s2) {
-    r = hash_find(hkeys, hvals, mask, lin_key(c.x, x, y, z, s0, s1, s2));
+                                    uint64_t mask, int32_t* __restrict__ table, const int64_t* __restrict__ n_dev) {
+  N = gpn::live_rows(n_dev, N);
+  if (blockIdx.x == 0 && threadIdx.x == 0) table[27 * N] = -1;  // sentinel entry behind the table
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < 27 * N; t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t / N);
+    const int64_t o = t - (int64_t)k * N;
+    const int4 c = reinterpret_cast<const int4*>(indices)[o];
+    const int x = c.y + (k / 9 - 1), y = c.z + ((k / 3) % 3 - 1), z = c.w + (k % 3 - 1);
+    int32_t r = -1;
+    if (k == 13) {
+      r = (int32_t)o;  // centre tap: the row itself
+    } else if (x >= 0 && x < s0 && y >= 0 && y < s1 && z >= 0 && z < s2) {
+      r = hash_find(hkeys, hvals, mask, lin_key(c.x, x, y, z, s0, s1, s2));
+    }
+    table[t] = r;
   }
-  table[t] = r;
 }
 
 struct ValidFlag {
@@ -111,33 +115,50 @@ __device__ __forceinline__ bool lists_entry(const int32_t* __restrict__ table, i
 }
 
 __global__ __launch_bounds__(256) void lists_count_kernel(const int32_t* __restrict__ table, int K, int64_t n_dst, int64_t n_tiles,
-                                                          int32_t* __restrict__ counts, int32_t* __restrict__ wg_sum) {
+                                                          int32_t* __restrict__ counts, int32_t* __restrict__ wg_sum,
+                                                          const int64_t* __restrict__ n_dev) {
   __shared__ int32_t c[kListTilesPerWg];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-  const int64_t f = (int64_t)blockIdx.x * kListTilesPerWg + wave * 2 + half;
-  int k;
-  int64_t row;
-  int32_t v;
-  const bool valid = lists_entry(table, K, n_dst, n_tiles, f, lane & 31, k, row, v);
-  const uint64_t m = __builtin_amdgcn_ballot_w64(valid);
-  const int cnt = __popcll(half ? (m >> 32) : (m & 0xffffffffull));
-  if ((lane & 31) == 0) {
-    c[wave * 2 + half] = cnt;
-    if (f < (int64_t)K * n_tiles) counts[f] = cnt;
+  if (n_dev) {
+    n_dst = gpn::live_rows(n_dev, n_dst);
+    n_tiles = (n_dst + GPN_TILE_ROWS - 1) / GPN_TILE_ROWS;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int32_t sum = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const int64_t n_wg = ((int64_t)K * n_tiles + kListTilesPerWg - 1) / kListTilesPerWg;
+  for (int64_t b = blockIdx.x; b < n_wg; b += gridDim.x) {
+    const int64_t f = b * kListTilesPerWg + wave * 2 + half;
+    int k;
+    int64_t row;
+    int32_t v;
+    const bool valid = lists_entry(table, K, n_dst, n_tiles, f, lane & 31, k, row, v);
+    const uint64_t m = __builtin_amdgcn_ballot_w64(valid);
+    const int cnt = __popcll(half ? (m >> 32) : (m & 0xffffffffull));
+    if ((lane & 31) == 0) {
+      c[wave * 2 + half] = cnt;
+      if (f < (int64_t)K * n_tiles) counts[f] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int32_t sum = 0;
 #pragma unroll
-    for (int i = 0; i < kListTilesPerWg; ++i) sum += c[i];
-    wg_sum[blockIdx.x] = sum;
+      for (int i = 0; i < kListTilesPerWg; ++i) sum += c[i];
+      wg_sum[b] = sum;
+    }
+    __syncthreads();  // (c[] is rewritten by the next round)
   }
 }
 
 // in place: wg_sum[b] -> exclusive prefix; the grand total to *total (int32) and, if given, *num_pairs (int64)
+// (n_dev != nullptr: n and `total` = the end marker of the last tap are derived from the live row count - `total` then points at
+// the offset table's base)
 __global__ __launch_bounds__(1024) void lists_block_scan_kernel(int32_t* __restrict__ wg_sum, int64_t n, int32_t* __restrict__ total,
-                                                                int64_t* __restrict__ num_pairs) {
+                                                                int64_t* __restrict__ num_pairs, int K, int64_t n_dst_bound,
+                                                                const int64_t* __restrict__ n_dev) {
   __shared__ int32_t part[1024];
+  if (n_dev) {
+    const int64_t n_tiles = (gpn::live_rows(n_dev, n_dst_bound) + GPN_TILE_ROWS - 1) / GPN_TILE_ROWS;
+    n = ((int64_t)K * n_tiles + kListTilesPerWg - 1) / kListTilesPerWg;
+    total += (int64_t)(K - 1) * (n_tiles + 1) + n_tiles;
+  }
   const int tid = threadIdx.x;
   const int64_t chunk = (n + 1023) / 1024;
   const int64_t b = tid * chunk, e = b + chunk < n ? b + chunk : n;
@@ -166,29 +187,37 @@ __global__ __launch_bounds__(1024) void lists_block_scan_kernel(int32_t* __restr
 __global__ __launch_bounds__(256) void lists_compact_kernel(const int32_t* __restrict__ table, int K, int64_t n_dst, int64_t n_tiles,
                                                             const int32_t* __restrict__ counts, const int32_t* __restrict__ wg_off,
                                                             int32_t* __restrict__ pair_src, int32_t* __restrict__ pair_dst,
-                                                            int32_t* __restrict__ tile_off) {
+                                                            int32_t* __restrict__ tile_off, const int64_t* __restrict__ n_dev) {
+  if (n_dev) {
+    n_dst = gpn::live_rows(n_dev, n_dst);
+    n_tiles = (n_dst + GPN_TILE_ROWS - 1) / GPN_TILE_ROWS;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
   const int slot = wave * 2 + half;
-  const int64_t f0 = (int64_t)blockIdx.x * kListTilesPerWg;
-  const int64_t f = f0 + slot, F = (int64_t)K * n_tiles;
-  int k;
-  int64_t row;
-  int32_t v;
-  const bool valid = lists_entry(table, K, n_dst, n_tiles, f, lane & 31, k, row, v);
-  const uint64_t m = __builtin_amdgcn_ballot_w64(valid);
-  const uint32_t mh = (uint32_t)(half ? (m >> 32) : (m & 0xffffffffull));
-  int32_t base = wg_off[blockIdx.x];
-  for (int i = 0; i < slot; ++i) base += (f0 + i < F) ? counts[f0 + i] : 0;  // (<= 7 L2-resident reads, the same in every lane)
-  if (f < F) {
-    if ((lane & 31) == 0) {
-      const int64_t t = f - (int64_t)k * n_tiles;
-      tile_off[(int64_t)k * (n_tiles + 1) + t] = base;
-      if (t == 0 && k > 0) tile_off[(int64_t)(k - 1) * (n_tiles + 1) + n_tiles] = base;  // end of the previous tap
-    }
-    if (valid) {
-      const int32_t p = base + __popc(mh & ((1u << (lane & 31)) - 1u));
-      pair_src[p] = v;
-      pair_dst[p] = (int32_t)row;
+  const int64_t F = (int64_t)K * n_tiles;
+  const int64_t n_wg = (F + kListTilesPerWg - 1) / kListTilesPerWg;
+  for (int64_t b = blockIdx.x; b < n_wg; b += gridDim.x) {
+    const int64_t f0 = b * kListTilesPerWg;
+    const int64_t f = f0 + slot;
+    int k;
+    int64_t row;
+    int32_t v;
+    const bool valid = lists_entry(table, K, n_dst, n_tiles, f, lane & 31, k, row, v);
+    const uint64_t m = __builtin_amdgcn_ballot_w64(valid);
+    const uint32_t mh = (uint32_t)(half ? (m >> 32) : (m & 0xffffffffull));
+    int32_t base = wg_off[b];
+    for (int i = 0; i < slot; ++i) base += (f0 + i < F) ? counts[f0 + i] : 0;  // (<= 7 L2-resident reads, the same in every lane)
+    if (f < F) {
+      if ((lane & 31) == 0) {
+        const int64_t t = f - (int64_t)k * n_tiles;
+        tile_off[(int64_t)k * (n_tiles + 1) + t] = base;
+        if (t == 0 && k > 0) tile_off[(int64_t)(k - 1) * (n_tiles + 1) + n_tiles] = base;  // end of the previous tap
+      }
+      if (valid) {
+        const int32_t p = base + __popc(mh & ((1u << (lane & 31)) - 1u));
+        pair_src[p] = v;
+        pair_dst[p] = (int32_t)row;
+      }
     }
   }
 }
@@ -197,10 +226,15 @@ __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) p[t] = v;
 }
-__global__ void fill_two_i32_kernel(int32_t* a, int64_t na, int32_t* b, int64_t nb, int32_t v) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < na) a[t] = v;
-  else if (t < na + nb) b[t - na] = v;
+// a[0 .. na) = b[0 .. nb) = v; with device counters: na = ka * *na_dev + 1, nb = kb * *nb_dev + 1 (tables of live size)
+__global__ void fill_two_i32_kernel(int32_t* a, int64_t na, int32_t* b, int64_t nb, int32_t v, int ka, const int64_t* na_dev,
+                                    int kb, const int64_t* nb_dev) {
+  if (na_dev) na = (int64_t)ka * gpn::live_rows(na_dev, (na - 1) / ka) + 1;
+  if (nb_dev) nb = (int64_t)kb * gpn::live_rows(nb_dev, (nb - 1) / kb) + 1;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < na + nb; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t < na) a[t] = v;
+    else b[t - na] = v;
+  }
 }
 
 size_t scan_temp_bytes(int64_t n) {
@@ -215,21 +249,23 @@ size_t scan_temp_bytes(int64_t n) {
 // scratch (`pos`): K n_tiles tile counts + one sum per workgroup of 8 tiles; callers size it K n_dst + 64 ints
 int lists_from_table(const int32_t* table, int32_t* pos, int K, int64_t n_dst, int32_t* pair_src,
                      int32_t* pair_dst, int32_t* tile_off, int64_t* num_pairs, void* prim_tmp,
-                     size_t prim_bytes, hipStream_t stream) {
+                     size_t prim_bytes, hipStream_t stream, const gpn::DevRows& rows = gpn::DevRows()) {
   (void)prim_tmp;
   (void)prim_bytes;
   const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
   const int64_t F = (int64_t)K * n_tiles;
   const int64_t n_wg = gpn::cdiv(F, kListTilesPerWg);
+  const int64_t plan_wg = gpn::cdiv((int64_t)K * gpn::cdiv(gpn::plan_rows(n_dst, rows), GPN_TILE_ROWS), kListTilesPerWg);
+  const unsigned grid = gpn::dev_grid(n_wg, plan_wg, rows.dev != nullptr);
   int32_t* counts = pos;
-  int32_t* wg_sum = pos + F;
-  hipLaunchKernelGGL(lists_count_kernel, dim3((unsigned)n_wg), dim3(256), 0, stream, table, K, n_dst, n_tiles, counts, wg_sum);
+  int32_t* wg_sum = pos + F;  // (behind the counts of the BOUND: valid for every live count)
+  hipLaunchKernelGGL(lists_count_kernel, dim3(grid), dim3(256), 0, stream, table, K, n_dst, n_tiles, counts, wg_sum, rows.dev);
   GPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(lists_block_scan_kernel, dim3(1), dim3(1024), 0, stream, wg_sum, n_wg,
-                     tile_off + (int64_t)(K - 1) * (n_tiles + 1) + n_tiles, num_pairs);
+                     rows.dev ? tile_off : tile_off + (int64_t)(K - 1) * (n_tiles + 1) + n_tiles, num_pairs, K, n_dst, rows.dev);
   GPN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lists_compact_kernel, dim3((unsigned)n_wg), dim3(256), 0, stream, table, K, n_dst, n_tiles,
-                     (const int32_t*)counts, (const int32_t*)wg_sum, pair_src, pair_dst, tile_off);
+  hipLaunchKernelGGL(lists_compact_kernel, dim3(grid), dim3(256), 0, stream, table, K, n_dst, n_tiles,
+                     (const int32_t*)counts, (const int32_t*)wg_sum, pair_src, pair_dst, tile_off, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -285,14 +321,17 @@ __global__ void down_emit_kernel(const uint64_t* __restrict__ ks, const uint32_t
 
 __global__ void down_scatter_tables_kernel(const int32_t* __restrict__ fine_to_coarse,
                                            const int32_t* __restrict__ tap, int64_t N, int64_t n_out,
-                                           int32_t* __restrict__ tf, int32_t* __restrict__ tb) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int32_t o = fine_to_coarse[i];
-  if (o < 0) return;
-  const int k = tap[i];
-  tf[(int64_t)k * n_out + o] = (int32_t)i;
-  tb[(int64_t)k * N + i] = o;
+                                           int32_t* __restrict__ tf, int32_t* __restrict__ tb,
+                                           const int64_t* __restrict__ n_dev, const int64_t* __restrict__ n_out_dev) {
+  N = gpn::live_rows(n_dev, N);
+  n_out = gpn::live_rows(n_out_dev, n_out);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t o = fine_to_coarse[i];
+    if (o < 0) continue;
+    const int k = tap[i];
+    tf[(int64_t)k * n_out + o] = (int32_t)i;
+    tb[(int64_t)k * N + i] = o;
+  }
 }
 
 // ---- stride-2 level through an occupancy BITMAP of the coarse grid (round 3): no sort ----------------------------------------
@@ -304,51 +343,74 @@ __global__ void down_scatter_tables_kernel(const int32_t* __restrict__ fine_to_c
 constexpr int kScanBlock = 1024;  // words per block of the word-popcount scan
 
 __global__ void down_mark_kernel(const int32_t* __restrict__ indices, int64_t N, int nb, int o0, int o1, int o2,
-                                 unsigned long long* __restrict__ bitmap, int32_t* __restrict__ tap) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int4 c = reinterpret_cast<const int4*>(indices)[i];
-  const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
-  tap[i] = (c.y & 1) * 4 + (c.z & 1) * 2 + (c.w & 1);
-  const bool ok = c.x >= 0 && c.x < nb && c.y >= 0 && c.z >= 0 && c.w >= 0 && x < o0 && y < o1 && z < o2;
-  if (!ok) return;
-  const uint64_t key = lin_key(c.x, x, y, z, o0, o1, o2);
-  atomicOr(bitmap + (key >> 6), 1ull << (key & 63));
+                                 unsigned long long* __restrict__ bitmap, int32_t* __restrict__ tap,
+                                 const int64_t* __restrict__ n_dev) {
+  N = gpn::live_rows(n_dev, N);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[i];
+    const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
+    tap[i] = (c.y & 1) * 4 + (c.z & 1) * 2 + (c.w & 1);
+    const bool ok = c.x >= 0 && c.x < nb && c.y >= 0 && c.z >= 0 && c.w >= 0 && x < o0 && y < o1 && z < o2;
+    if (!ok) continue;
+    const uint64_t key = lin_key(c.x, x, y, z, o0, o1, o2);
+    atomicOr(bitmap + (key >> 6), 1ull << (key & 63));
+  }
+}
+
+// words of the coarse grid's bitmap that can be set: all of them, or - device-counted batch entries (the proposals of a step) -
+// those of the first *batch_dev entries
+__device__ __forceinline__ int64_t live_words(int64_t n_words, int64_t cells_per_entry, const int64_t* batch_dev) {
+  if (!batch_dev) return n_words;
+  const int64_t w = (gpn::live_rows(batch_dev, (int64_t)1 << 40) * cells_per_entry + 63) >> 6;
+  return w < n_words ? w : n_words;
+}
+__global__ void bitmap_clear_kernel(unsigned long long* __restrict__ bitmap, int64_t n_words, int64_t cells_per_entry,
+                                    const int64_t* __restrict__ batch_dev) {
+  n_words = live_words(n_words, cells_per_entry, batch_dev);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) bitmap[i] = 0ull;
 }
 
 // exclusive prefix of the word popcounts inside blocks of kScanBlock words; block totals to `block_sum`
 __global__ __launch_bounds__(256) void bitmap_scan_blocks_kernel(const unsigned long long* __restrict__ bitmap, int64_t n_words,
-                                                                 int32_t* __restrict__ prefix, int32_t* __restrict__ block_sum) {
+                                                                 int32_t* __restrict__ prefix, int32_t* __restrict__ block_sum,
+                                                                 int64_t cells_per_entry, const int64_t* __restrict__ batch_dev) {
   __shared__ int32_t wave_tot[4];
+  n_words = live_words(n_words, cells_per_entry, batch_dev);
+  const int64_t n_blocks = (n_words + kScanBlock - 1) / kScanBlock;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t base = (int64_t)blockIdx.x * kScanBlock + t * 4;
-  int32_t c[4];
+  for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int64_t base = blk * kScanBlock + t * 4;
+    int32_t c[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) c[q] = base + q < n_words ? __popcll(bitmap[base + q]) : 0;
-  const int32_t mine = c[0] + c[1] + c[2] + c[3];
-  int32_t incl = mine;  // inclusive scan over the wave (ballot-free shuffle tree, fixed order)
+    for (int q = 0; q < 4; ++q) c[q] = base + q < n_words ? __popcll(bitmap[base + q]) : 0;
+    const int32_t mine = c[0] + c[1] + c[2] + c[3];
+    int32_t incl = mine;  // inclusive scan over the wave (ballot-free shuffle tree, fixed order)
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int32_t v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+    int32_t run = wbase + incl - mine;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (base + q < n_words) prefix[base + q] = run;
+      run += c[q];
+    }
+    if (t == 255) block_sum[blk] = wbase + incl;
+    __syncthreads();  // (wave_tot is rewritten by the next round)
   }
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  int32_t wbase = 0;
-  for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
-  int32_t run = wbase + incl - mine;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (base + q < n_words) prefix[base + q] = run;
-    run += c[q];
-  }
-  if (t == 255) block_sum[blockIdx.x] = wbase + incl;
 }
 
 // exclusive scan of the block totals by one workgroup (<= 256 K blocks); total -> num_out
 __global__ __launch_bounds__(1024) void bitmap_scan_totals_kernel(int32_t* __restrict__ block_sum, int64_t n_blocks,
-                                                                  int64_t* __restrict__ num_out) {
+                                                                  int64_t* __restrict__ num_out, int64_t n_words,
+                                                                  int64_t cells_per_entry, const int64_t* __restrict__ batch_dev) {
   __shared__ int32_t part[1024];
+  if (batch_dev) n_blocks = (live_words(n_words, cells_per_entry, batch_dev) + kScanBlock - 1) / kScanBlock;
   const int t = threadIdx.x;
   const int64_t per = (n_blocks + 1023) / 1024;
   const int64_t b = t * per, e = b + per < n_blocks ? b + per : n_blocks;
@@ -377,21 +439,22 @@ __global__ __launch_bounds__(1024) void bitmap_scan_totals_kernel(int32_t* __res
 __global__ void down_rank_kernel(const int32_t* __restrict__ indices, int64_t N, int nb, int o0, int o1, int o2,
                                  const unsigned long long* __restrict__ bitmap, const int32_t* __restrict__ prefix,
                                  const int32_t* __restrict__ block_sum, int32_t* __restrict__ out_indices,
-                                 int32_t* __restrict__ fine_to_coarse) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int4 c = reinterpret_cast<const int4*>(indices)[i];
-  const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
-  const bool ok = c.x >= 0 && c.x < nb && c.y >= 0 && c.z >= 0 && c.w >= 0 && x < o0 && y < o1 && z < o2;
-  if (!ok) {
-    fine_to_coarse[i] = -1;
-    return;
+                                 int32_t* __restrict__ fine_to_coarse, const int64_t* __restrict__ n_dev) {
+  N = gpn::live_rows(n_dev, N);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[i];
+    const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
+    const bool ok = c.x >= 0 && c.x < nb && c.y >= 0 && c.z >= 0 && c.w >= 0 && x < o0 && y < o1 && z < o2;
+    if (!ok) {
+      fine_to_coarse[i] = -1;
+      continue;
+    }
+    const uint64_t key = lin_key(c.x, x, y, z, o0, o1, o2);
+    const uint64_t word = key >> 6;
+    const int32_t v = block_sum[word / kScanBlock] + prefix[word] + __popcll(bitmap[word] & ((1ull << (key & 63)) - 1ull));
+    fine_to_coarse[i] = v;
+    reinterpret_cast<int4*>(out_indices)[v] = make_int4(c.x, x, y, z);  // (every child writes the same row: idempotent)
   }
-  const uint64_t key = lin_key(c.x, x, y, z, o0, o1, o2);
-  const uint64_t word = key >> 6;
-  const int32_t v = block_sum[word / kScanBlock] + prefix[word] + __popcll(bitmap[word] & ((1ull << (key & 63)) - 1ull));
-  fine_to_coarse[i] = v;
-  reinterpret_cast<int4*>(out_indices)[v] = make_int4(c.x, x, y, z);  // (every child writes the same row: idempotent)
 }
 
 constexpr uint64_t kBitmapMaxWords = (uint64_t)kScanBlock * 256 * 1024;  // one totals workgroup covers 256 K blocks
@@ -467,12 +530,17 @@ __global__ __launch_bounds__(kThreads) void level_counts_kernel(const int32_t* _
 // K = 1 "rulebook": every row is its own (only) neighbour.  rows [n], tile_off [n_tiles + 1], nbr [n + 1] (last = -1)
 __global__ __launch_bounds__(kThreads) void identity_rulebook_kernel(int64_t n, int64_t n_tiles, int32_t* __restrict__ rows,
                                                                      int32_t* __restrict__ tile_off, int32_t* __restrict__ nbr,
-                                                                     int64_t* __restrict__ num_pairs) {
-  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) rows[i] = (int32_t)i, nbr[i] = (int32_t)i;
-  if (i == n) nbr[n] = -1;
-  if (i <= n_tiles) tile_off[i] = (int32_t)(i * GPN_TILE_ROWS < n ? i * GPN_TILE_ROWS : n);
-  if (i == 0) num_pairs[0] = n;
+                                                                     int64_t* __restrict__ num_pairs, const int64_t* __restrict__ n_dev) {
+  if (n_dev) {
+    n = gpn::live_rows(n_dev, n);
+    n_tiles = (n + GPN_TILE_ROWS - 1) / GPN_TILE_ROWS;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i <= n; i += (int64_t)gridDim.x * kThreads) {
+    if (i < n) rows[i] = (int32_t)i, nbr[i] = (int32_t)i;
+    if (i == n) nbr[n] = -1;
+    if (i <= n_tiles) tile_off[i] = (int32_t)(i * GPN_TILE_ROWS < n ? i * GPN_TILE_ROWS : n);
+    if (i == 0) num_pairs[0] = n;
+  }
 }
 
 }  // namespace
@@ -489,10 +557,31 @@ extern "C" size_t gpn_rulebook_subm3_ws_bytes(int64_t N) {
   return w.used;
 }
 
+static int rulebook_subm3_impl(const int32_t* indices, int64_t N, const gpn::DevRows& rows, const int32_t* spatial_shape_host,
+                               int32_t* nbr, int32_t* pair_src, int32_t* pair_dst, int32_t* tile_off, int64_t* num_pairs, void* ws,
+                               size_t ws_bytes, hipStream_t stream);
+
 extern "C" int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32_t* spatial_shape_host, int32_t* nbr,
                                   int32_t* pair_src, int32_t* pair_dst, int32_t* tile_off,
                                   int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return rulebook_subm3_impl(indices, N, gpn::DevRows(), spatial_shape_host, nbr, pair_src, pair_dst, tile_off, num_pairs, ws,
+                             ws_bytes, (hipStream_t)stream_);
+}
+
+// the same with the row count on the device: N = the bound every buffer is sized for (workspace from
+// gpn_rulebook_subm3_ws_bytes(N)), *n_dev the live count, n_plan the host's estimate of it (grid sizes only; <= 0: none).
+// Outputs are laid out for the LIVE count (nbr [27][*n_dev] + sentinel, tile_off [27][ceil(*n_dev / 32) + 1]).
+extern "C" int gpn_rulebook_subm3_dev(const int32_t* indices, int64_t N, const int64_t* n_dev, int64_t n_plan,
+                                      const int32_t* spatial_shape_host, int32_t* nbr, int32_t* pair_src, int32_t* pair_dst,
+                                      int32_t* tile_off, int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(n_dev != nullptr && N >= 1);
+  return rulebook_subm3_impl(indices, N, gpn::DevRows{n_dev, n_plan}, spatial_shape_host, nbr, pair_src, pair_dst, tile_off,
+                             num_pairs, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+static int rulebook_subm3_impl(const int32_t* indices, int64_t N, const gpn::DevRows& rows, const int32_t* spatial_shape_host,
+                               int32_t* nbr, int32_t* pair_src, int32_t* pair_dst, int32_t* tile_off, int64_t* num_pairs, void* ws,
+                               size_t ws_bytes, hipStream_t stream) {
   GPN_CHECK_ARG(N >= 0 && spatial_shape_host && tile_off);
   GPN_CHECK_ARG(27 * N + 1 < (int64_t)0x7fffffff);
   const int s0 = spatial_shape_host[0], s1 = spatial_shape_host[1], s2 = spatial_shape_host[2];
@@ -519,14 +608,17 @@ extern "C" int gpn_rulebook_subm3(const int32_t* indices, int64_t N, const int32
   // empty keys (kEmpty = all ones) and values (-1) in ONE fill: the two arrays are adjacent in the workspace
   static_assert(kEmpty == ~0ull, "the key / value tables are initialised by one byte fill");
   GPN_CHECK_HIP(hipMemsetAsync(hkeys, 0xff, (size_t)(reinterpret_cast<char*>(hvals + cap) - reinterpret_cast<char*>(hkeys)), stream));
-  hipLaunchKernelGGL(hash_insert_kernel, dim3((int)gpn::cdiv(N, kThreads)), dim3(kThreads), 0, stream, indices,
-                     N, s0, s1, s2, hkeys, hvals, cap - 1);
+  const int64_t Np = gpn::plan_rows(N, rows);
+  const bool dev = rows.dev != nullptr;
+  hipLaunchKernelGGL(hash_insert_kernel, dim3(gpn::dev_grid(gpn::cdiv(N, kThreads), gpn::cdiv(Np, kThreads), dev)), dim3(kThreads), 0,
+                     stream, indices, N, s0, s1, s2, hkeys, hvals, cap - 1, rows.dev);
   GPN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(subm3_lookup_kernel, dim3((int)gpn::cdiv(27 * N, kThreads)), dim3(kThreads), 0, stream,
-                     indices, N, s0, s1, s2, hkeys, hvals, cap - 1, table);  // (also writes the -1 sentinel table[27 N])
+  hipLaunchKernelGGL(subm3_lookup_kernel, dim3(gpn::dev_grid(gpn::cdiv(27 * N, kThreads), gpn::cdiv(27 * Np, kThreads), dev)),
+                     dim3(kThreads), 0, stream, indices, N, s0, s1, s2, hkeys, hvals, cap - 1, table,
+                     rows.dev);  // (also writes the -1 sentinel table[27 N])
   GPN_CHECK_LAUNCH();
   return lists_from_table(table, pos, 27, N, pair_src, pair_dst, tile_off, num_pairs, prim_tmp, prim_bytes,
-                          stream);
+                          stream, rows);
 }
 
 // ================================================================================================ tile order
@@ -669,10 +761,43 @@ extern "C" size_t gpn_rulebook_down_ws_bytes(int64_t N) {
   return w.used;
 }
 
+static int rulebook_down_impl(const int32_t* indices, int64_t N, const gpn::DevRows& rows, int64_t batch_size,
+                              const gpn::DevRows& batch, const int32_t* spatial_shape_host, int32_t* out_indices,
+                              int32_t* fine_to_coarse, int32_t* tap, int64_t* num_out, void* ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int gpn_rulebook_down(const int32_t* indices, int64_t N, int64_t batch_size,
                                  const int32_t* spatial_shape_host, int32_t* out_indices, int32_t* fine_to_coarse, int32_t* tap,
                                  int64_t* num_out, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return rulebook_down_impl(indices, N, gpn::DevRows(), batch_size, gpn::DevRows(), spatial_shape_host, out_indices, fine_to_coarse,
+                            tap, num_out, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+// row count and batch-entry count (the proposals of a step) on the device: N / batch_size are the bounds the buffers are sized
+// for, *_plan the host's estimates (grid sizes).  Needs the bitmap form (workspace sized for the bounds).
+extern "C" int gpn_rulebook_down_dev(const int32_t* indices, int64_t N, const int64_t* n_dev, int64_t n_plan, int64_t batch_size,
+                                     const int64_t* batch_dev, int64_t batch_plan, const int32_t* spatial_shape_host,
+                                     int32_t* out_indices, int32_t* fine_to_coarse, int32_t* tap, int64_t* num_out, void* ws,
+                                     size_t ws_bytes, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(n_dev != nullptr && N >= 1);
+  return rulebook_down_impl(indices, N, gpn::DevRows{n_dev, n_plan}, batch_size, gpn::DevRows{batch_dev, batch_plan},
+                            spatial_shape_host, out_indices, fine_to_coarse, tap, num_out, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+extern "C" size_t gpn_rulebook_down_dev_ws_bytes(int64_t N, int64_t batch_size, const int32_t* spatial_shape_host) {
+  if (!spatial_shape_host) return 0;
+  const uint64_t cells = (uint64_t)(spatial_shape_host[0] / 2) * (uint64_t)(spatial_shape_host[1] / 2) * (uint64_t)(spatial_shape_host[2] / 2);
+  const uint64_t n_words = ((uint64_t)(batch_size > 0 ? batch_size : 1) * cells + 63) / 64;
+  gpn::WsCarver w(nullptr, 0);
+  w.take<unsigned long long>((size_t)n_words);
+  w.take<int32_t>((size_t)n_words);
+  w.take<int32_t>((size_t)gpn::cdiv((int64_t)n_words, kScanBlock));
+  const size_t a = w.used, b = gpn_rulebook_down_ws_bytes(N);
+  return a > b ? a : b;
+}
+
+static int rulebook_down_impl(const int32_t* indices, int64_t N, const gpn::DevRows& rows, int64_t batch_size,
+                              const gpn::DevRows& batch, const int32_t* spatial_shape_host, int32_t* out_indices,
+                              int32_t* fine_to_coarse, int32_t* tap, int64_t* num_out, void* ws, size_t ws_bytes, hipStream_t stream) {
   GPN_CHECK_ARG(N >= 0 && spatial_shape_host && num_out);
   if (N == 0) {
     GPN_CHECK_HIP(hipMemsetAsync(num_out, 0, sizeof(int64_t), stream));
@@ -698,20 +823,37 @@ extern "C" int gpn_rulebook_down(const int32_t* indices, int64_t N, int64_t batc
   int32_t* prefix = wb.take<int32_t>((size_t)n_words);
   int32_t* block_sum = wb.take<int32_t>((size_t)n_blocks);
   if (n_words <= kBitmapMaxWords && wb.ok()) {
-    const int gridN = (int)gpn::cdiv(N, kThreads);
+    const bool dev = rows.dev != nullptr;
+    const unsigned gridN = gpn::dev_grid(gpn::cdiv(N, kThreads), gpn::cdiv(gpn::plan_rows(N, rows), kThreads), dev);
+    const int64_t cells = (int64_t)o0 * o1 * o2;
+    // (bitmap words that can be set: those of the batch entries that exist - all of them unless their count is on the device)
+    const int64_t plan_words = gpn::cdiv(gpn::plan_rows(batch_size, batch) * cells, 64);
+    const unsigned grid_blocks = gpn::dev_grid(n_blocks, gpn::cdiv(plan_words, kScanBlock), batch.dev != nullptr, 1, 256);
     gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 16.0 * (double)N * 2 + 8.0 * (double)N);
-    GPN_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_words * sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(down_mark_kernel, dim3(gridN), dim3(kThreads), 0, stream, indices, N, (int)batch_size, o0, o1, o2, bitmap, tap);
+    if (batch.dev) {
+      hipLaunchKernelGGL(bitmap_clear_kernel, dim3(gpn::dev_grid(gpn::cdiv((int64_t)n_words, kThreads), gpn::cdiv(plan_words, kThreads), true)),
+                         dim3(kThreads), 0, stream, bitmap, (int64_t)n_words, cells, batch.dev);
+      GPN_CHECK_LAUNCH();
+    } else {
+      GPN_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_words * sizeof(unsigned long long), stream));
+    }
+    hipLaunchKernelGGL(down_mark_kernel, dim3(gridN), dim3(kThreads), 0, stream, indices, N, (int)batch_size, o0, o1, o2, bitmap, tap,
+                       rows.dev);
     GPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bitmap_scan_blocks_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, bitmap, (int64_t)n_words, prefix,
-                       block_sum);
+    hipLaunchKernelGGL(bitmap_scan_blocks_kernel, dim3(grid_blocks), dim3(256), 0, stream, bitmap, (int64_t)n_words, prefix,
+                       block_sum, cells, batch.dev);
     GPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bitmap_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, block_sum, n_blocks, num_out);
+    hipLaunchKernelGGL(bitmap_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, block_sum, n_blocks, num_out, (int64_t)n_words,
+                       cells, batch.dev);
     GPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(down_rank_kernel, dim3(gridN), dim3(kThreads), 0, stream, indices, N, (int)batch_size, o0, o1, o2, bitmap,
-                       prefix, block_sum, out_indices, fine_to_coarse);
+                       prefix, block_sum, out_indices, fine_to_coarse, rows.dev);
     GPN_CHECK_LAUNCH();
     return GPN_OK;
+  }
+  if (rows.dev || batch.dev) {
+    gpn::set_error("gpn_rulebook_down_dev: the coarse grid does not fit the bitmap form (workspace of gpn_rulebook_down_dev_ws_bytes?)");
+    return GPN_ERR_WS;
   }
   gpn::WsCarver w(ws, ws_bytes);
   uint64_t* keys = w.take<uint64_t>((size_t)N);
@@ -752,12 +894,36 @@ extern "C" size_t gpn_rulebook_down_lists_ws_bytes(int64_t N, int64_t n_out) {
   return w.used;
 }
 
+static int rulebook_down_lists_impl(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N, const gpn::DevRows& rows,
+                                    int64_t n_out, const gpn::DevRows& rows_out, int32_t* fwd_nbr, int32_t* fwd_src, int32_t* fwd_dst,
+                                    int32_t* fwd_tile_off, int32_t* bwd_nbr, int32_t* bwd_src, int32_t* bwd_dst,
+                                    int32_t* bwd_tile_off, int64_t* num_pairs, void* ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N,
                                        int64_t n_out, int32_t* fwd_nbr, int32_t* fwd_src, int32_t* fwd_dst,
                                        int32_t* fwd_tile_off, int32_t* bwd_nbr, int32_t* bwd_src, int32_t* bwd_dst,
                                        int32_t* bwd_tile_off, int64_t* num_pairs, void* ws, size_t ws_bytes,
                                        gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return rulebook_down_lists_impl(fine_to_coarse, tap, N, gpn::DevRows(), n_out, gpn::DevRows(), fwd_nbr, fwd_src, fwd_dst,
+                                  fwd_tile_off, bwd_nbr, bwd_src, bwd_dst, bwd_tile_off, num_pairs, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+// fine and coarse row counts on the device (N, n_out: the bounds; tables laid out for the live counts)
+extern "C" int gpn_rulebook_down_lists_dev(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N, const int64_t* n_dev,
+                                           int64_t n_plan, int64_t n_out, const int64_t* n_out_dev, int64_t n_out_plan,
+                                           int32_t* fwd_nbr, int32_t* fwd_src, int32_t* fwd_dst, int32_t* fwd_tile_off,
+                                           int32_t* bwd_nbr, int32_t* bwd_src, int32_t* bwd_dst, int32_t* bwd_tile_off,
+                                           int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(n_dev && n_out_dev && N >= 1 && n_out >= 1);
+  return rulebook_down_lists_impl(fine_to_coarse, tap, N, gpn::DevRows{n_dev, n_plan}, n_out, gpn::DevRows{n_out_dev, n_out_plan},
+                                  fwd_nbr, fwd_src, fwd_dst, fwd_tile_off, bwd_nbr, bwd_src, bwd_dst, bwd_tile_off, num_pairs, ws,
+                                  ws_bytes, (hipStream_t)stream_);
+}
+
+static int rulebook_down_lists_impl(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N, const gpn::DevRows& rows,
+                                    int64_t n_out, const gpn::DevRows& rows_out, int32_t* fwd_nbr, int32_t* fwd_src, int32_t* fwd_dst,
+                                    int32_t* fwd_tile_off, int32_t* bwd_nbr, int32_t* bwd_src, int32_t* bwd_dst,
+                                    int32_t* bwd_tile_off, int64_t* num_pairs, void* ws, size_t ws_bytes, hipStream_t stream) {
   GPN_CHECK_ARG(N >= 0 && n_out >= 0 && n_out <= N && fwd_tile_off && bwd_tile_off);
   const int64_t nt_f = gpn::cdiv(n_out, GPN_TILE_ROWS), nt_b = gpn::cdiv(N, GPN_TILE_ROWS);
   if (N == 0 || n_out == 0) {
@@ -777,18 +943,21 @@ extern "C" int gpn_rulebook_down_lists(const int32_t* fine_to_coarse, const int3
   void* prim_tmp = w.take<char>(prim_bytes);
   GPN_CHECK_WS(w);
   gpn::ProfScope prof(GPN_K_RULEBOOK, stream, 0.0, 8.0 * (double)N + 16.0 * (double)N);
+  const bool dev = rows.dev != nullptr;
+  const int64_t Np = gpn::plan_rows(N, rows), Nop = gpn::plan_rows(n_out, rows_out);
   {  // both tables to -1 in one launch (they are separate caller-owned outputs: two memsets otherwise)
     const int64_t nf = 8 * n_out + 1, nb = 8 * N + 1;
-    hipLaunchKernelGGL(fill_two_i32_kernel, dim3((int)gpn::cdiv(nf + nb, kThreads)), dim3(kThreads), 0, stream, tf, nf, tb, nb, -1);
+    hipLaunchKernelGGL(fill_two_i32_kernel, dim3(gpn::dev_grid(gpn::cdiv(nf + nb, kThreads), gpn::cdiv(8 * (Np + Nop) + 2, kThreads), dev)),
+                       dim3(kThreads), 0, stream, tf, nf, tb, nb, -1, 8, rows_out.dev, 8, rows.dev);
     GPN_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(down_scatter_tables_kernel, dim3((int)gpn::cdiv(N, kThreads)), dim3(kThreads), 0, stream,
-                     fine_to_coarse, tap, N, n_out, tf, tb);
+  hipLaunchKernelGGL(down_scatter_tables_kernel, dim3(gpn::dev_grid(gpn::cdiv(N, kThreads), gpn::cdiv(Np, kThreads), dev)), dim3(kThreads), 0,
+                     stream, fine_to_coarse, tap, N, n_out, tf, tb, rows.dev, rows_out.dev);
   GPN_CHECK_LAUNCH();
   int rc = lists_from_table(tf, pos, 8, n_out, fwd_src, fwd_dst, fwd_tile_off, num_pairs, prim_tmp, prim_bytes,
-                            stream);
+                            stream, rows_out);
   if (rc != GPN_OK) return rc;
-  return lists_from_table(tb, pos, 8, N, bwd_src, bwd_dst, bwd_tile_off, nullptr, prim_tmp, prim_bytes, stream);
+  return lists_from_table(tb, pos, 8, N, bwd_src, bwd_dst, bwd_tile_off, nullptr, prim_tmp, prim_bytes, stream, rows);
 }
 
 
@@ -851,7 +1020,19 @@ extern "C" int gpn_rulebook_identity(int64_t n, int32_t* rows, int32_t* tile_off
   GPN_CHECK_ARG(n >= 0 && n < (int64_t)0x7fffffff && rows && tile_off && nbr && num_pairs);
   const int64_t n_tiles = gpn::cdiv(n, (int64_t)GPN_TILE_ROWS);
   hipLaunchKernelGGL(identity_rulebook_kernel, dim3((unsigned)gpn::cdiv(n + 1, (int64_t)kThreads)), dim3(kThreads), 0, stream, n,
-                     n_tiles, rows, tile_off, nbr, num_pairs);
+                     n_tiles, rows, tile_off, nbr, num_pairs, (const int64_t*)nullptr);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+// the same for a device-counted row count (n = the bound of the buffers)
+extern "C" int gpn_rulebook_identity_dev(int64_t n, const int64_t* n_dev, int64_t n_plan, int32_t* rows, int32_t* tile_off,
+                                         int32_t* nbr, int64_t* num_pairs, gpn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GPN_CHECK_ARG(n >= 1 && n < (int64_t)0x7fffffff && n_dev && rows && tile_off && nbr && num_pairs);
+  const int64_t np = gpn::plan_rows(n, gpn::DevRows{n_dev, n_plan});
+  hipLaunchKernelGGL(identity_rulebook_kernel, dim3(gpn::dev_grid(gpn::cdiv(n + 1, (int64_t)kThreads), gpn::cdiv(np + 1, (int64_t)kThreads), true)),
+                     dim3(kThreads), 0, stream, n, gpn::cdiv(n, (int64_t)GPN_TILE_ROWS), rows, tile_off, nbr, num_pairs, n_dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

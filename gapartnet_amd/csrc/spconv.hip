@@ -54,7 +54,9 @@ struct LdsPitch {  // floats per LDS row for W payload floats: pitch % 64 in {16
 
 template <int CT, int NT>
 __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
-    const gpn::WgradSets sets, int64_t n_tiles, int cin, int S, int cigs) {
+    const gpn::WgradSets sets, int64_t n_tiles, int cin, int S, int cigs, const int64_t* __restrict__ n_dst_dev) {
+  // (device-counted rows, gpn::DevRows: the offset table's leading dimension is that of the LIVE row count)
+  if (n_dst_dev) n_tiles = (gpn::live_rows(n_dst_dev, n_tiles * GPN_TILE_ROWS) + GPN_TILE_ROWS - 1) / GPN_TILE_ROWS;
   constexpr int T = 64;  // pairs per tile
   constexpr int COUT = NT * 16;
   constexpr int PA = LdsPitch<CT * 16>::value, PB = LdsPitch<COUT>::value;
@@ -305,21 +307,22 @@ int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
 }
 
 template <int CT, int NT>
-int launch_wgrad(const gpn::WgradSets& sets, int K, int64_t n_dst, int cin, int S, hipStream_t stream) {
+int launch_wgrad(const gpn::WgradSets& sets, int K, int64_t n_dst, int cin, int S, hipStream_t stream, const int64_t* n_dev) {
   const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
   const int ct_tiles = cin / 16;
   const int cig = (ct_tiles + CT - 1) / CT;
   hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), dim3(K, S, sets.n * cig), dim3(256), 0, stream, sets, n_tiles, cin, S,
-                     cig);
+                     cig, n_dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
 template <int CT>
-int dispatch_wgrad_nt(int nt, const gpn::WgradSets& sets, int K, int64_t n_dst, int cin, int S, hipStream_t stream) {
+int dispatch_wgrad_nt(int nt, const gpn::WgradSets& sets, int K, int64_t n_dst, int cin, int S, hipStream_t stream,
+                      const int64_t* n_dev) {
   switch (nt) {
 #define GPN_CASE(N) \
-  case N: return launch_wgrad<CT, N>(sets, K, n_dst, cin, S, stream);
+  case N: return launch_wgrad<CT, N>(sets, K, n_dst, cin, S, stream, n_dev);
     GPN_CASE(1) GPN_CASE(2) GPN_CASE(3) GPN_CASE(4) GPN_CASE(5) GPN_CASE(6) GPN_CASE(7) GPN_CASE(8)
 #undef GPN_CASE
     default:
@@ -332,11 +335,16 @@ int dispatch_wgrad_nt(int nt, const gpn::WgradSets& sets, int K, int64_t n_dst, 
 // U float4 elements per thread, the U index loads issued together and then the U row loads together: two memory round
 // trips per U elements (one element per thread ran at half the bandwidth of a copy of the same size - every wave was a
 // serial idx -> row chain and the launch needed two rounds of waves); 32-bit element arithmetic
+// (n_dev != nullptr, gpn::DevRows: the row count is a device counter; the launch then walks its elements in rounds of
+// U x (threads of the grid) - one round when the grid was sized from the count)
 template <int U>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx,
-                                                          uint32_t total4, uint32_t C4, float* __restrict__ out) {
+                                                          uint32_t total4, uint32_t C4, float* __restrict__ out,
+                                                          const int64_t* __restrict__ n_dev) {
+  if (n_dev) total4 = (uint32_t)gpn::live_rows(n_dev, total4 / C4) * C4;
   const uint32_t T = gridDim.x * blockDim.x;
-  const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t base = 0; base < total4; base += (uint32_t)U * T) {
+  const uint32_t t0 = base + blockIdx.x * blockDim.x + threadIdx.x;
   int32_t r[U];
   uint32_t c[U];
 #pragma unroll
@@ -357,36 +365,40 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     const uint32_t t = t0 + (uint32_t)k * T;
     if (t < total4) reinterpret_cast<f32x4*>(out)[t] = v[k];
   }
+  }
 }
 __global__ void gather_rows_scalar_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx,
-                                          int64_t n, int C, float* __restrict__ out) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * C) return;
-  const int64_t i = t / C;
-  const int c = (int)(t - i * C);
-  const int32_t r = idx[i];
-  out[t] = r >= 0 ? table[(int64_t)r * C + c] : 0.f;
+                                          int64_t n, int C, float* __restrict__ out, const int64_t* __restrict__ n_dev) {
+  n = gpn::live_rows(n_dev, n);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / C;
+    const int c = (int)(t - i * C);
+    const int32_t r = idx[i];
+    out[t] = r >= 0 ? table[(int64_t)r * C + c] : 0.f;
+  }
 }
 // dtable[r][c] = ordered sum over the points of row r
 __global__ void scatter_rows_csr_kernel(const float* __restrict__ dout, const int32_t* __restrict__ order,
                                         const int32_t* __restrict__ starts, int64_t n_rows, int C,
-                                        float* __restrict__ dtable) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_rows * C) return;
-  const int64_t r = t / C;
-  const int c = (int)(t - r * C);
-  float acc = 0.f;
-  for (int32_t j = starts[r]; j < starts[r + 1]; ++j) acc += dout[(int64_t)order[j] * C + c];
-  dtable[t] = acc;
+                                        float* __restrict__ dtable, const int64_t* __restrict__ n_dev) {
+  n_rows = gpn::live_rows(n_dev, n_rows);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_rows * C; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / C;
+    const int c = (int)(t - r * C);
+    float acc = 0.f;
+    for (int32_t j = starts[r]; j < starts[r + 1]; ++j) acc += dout[(int64_t)order[j] * C + c];
+    dtable[t] = acc;
+  }
 }
 // float4 form (C % 4 == 0): same order of additions per channel; the first two points of a row are fetched together
 // (rows hold 1.1 points on average: the common case is one order -> row chain, not a loop)
 __global__ __launch_bounds__(256) void scatter_rows_csr_v4_kernel(const float* __restrict__ dout,
                                                                    const int32_t* __restrict__ order,
                                                                    const int32_t* __restrict__ starts, uint32_t total4,
-                                                                   uint32_t C4, float* __restrict__ dtable) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total4) return;
+                                                                   uint32_t C4, float* __restrict__ dtable,
+                                                                   const int64_t* __restrict__ n_dev) {
+  if (n_dev) total4 = (uint32_t)gpn::live_rows(n_dev, total4 / C4) * C4;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += gridDim.x * blockDim.x) {
   const uint32_t r = t / C4, c = t - r * C4;
   const int32_t b = starts[r], e = starts[r + 1];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -401,6 +413,7 @@ __global__ __launch_bounds__(256) void scatter_rows_csr_v4_kernel(const float* _
     for (int32_t j = b + 2; j < e; ++j) acc = acc + reinterpret_cast<const f32x4*>(dout)[(uint64_t)(uint32_t)order[j] * C4 + c];
   }
   reinterpret_cast<f32x4*>(dtable)[t] = acc;
+  }
 }
 
 }  // namespace
@@ -428,17 +441,18 @@ namespace gpn {
 int wgrad_slices(int K, int cin, int cout, int64_t n_dst) { return wgrad_splits(K, cin, cout, n_dst); }
 
 // the contraction of sets.n layers of ONE shape (K, n_dst, cin, cout) into their partial[S][K][cin][cout] buffers
-int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream) {
+int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream,
+                   const int64_t* n_dst_dev) {
   GPN_CHECK_ARG(sets.n >= 1 && sets.n <= kWgradSets);
   const int ct_tiles = cin / 16;
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int nt = cout / 16;
   gpn::ProfScope prof(GPN_K_SPCONV_WGRAD, stream, 0.0, 0.0);
   switch (CT) {
-    case 1: return dispatch_wgrad_nt<1>(nt, sets, K, n_dst, cin, S, stream);
-    case 2: return dispatch_wgrad_nt<2>(nt, sets, K, n_dst, cin, S, stream);
-    case 3: return dispatch_wgrad_nt<3>(nt, sets, K, n_dst, cin, S, stream);
-    default: return dispatch_wgrad_nt<4>(nt, sets, K, n_dst, cin, S, stream);
+    case 1: return dispatch_wgrad_nt<1>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);
+    case 2: return dispatch_wgrad_nt<2>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);
+    case 3: return dispatch_wgrad_nt<3>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);
+    default: return dispatch_wgrad_nt<4>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);
   }
 }
 
@@ -497,40 +511,63 @@ extern "C" int gpn_spconv_wgrad(const float* in, const float* dout, const int32_
   return gpn::wgrad_reduce_many(&job, 1, stream);
 }
 
-extern "C" int gpn_gather_rows(const float* table, const int32_t* idx, int64_t n, int C, float* out,
-                               gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int gather_rows_impl(const float* table, const int32_t* idx, int64_t n, const gpn::DevRows& rows, int C, float* out,
+                            hipStream_t stream) {
   GPN_CHECK_ARG(n >= 0 && C >= 1);
   if (n == 0) return GPN_OK;
   GPN_CHECK_ARG(table && idx && out);
+  const int64_t np = gpn::plan_rows(n, rows);
+  const bool dev = rows.dev != nullptr;
   if (C % 4 == 0 && n * (C / 4) < (int64_t)0x7fffffff) {
-    const int64_t total4 = n * (C / 4);
-    if (total4 >= 4 * 256 * 256)  // enough elements to keep every CU busy with 4 per thread
-      hipLaunchKernelGGL(gather_rows_kernel<4>, dim3((int)gpn::cdiv(total4, 4 * 256)), dim3(256), 0, stream, table, idx,
-                         (uint32_t)total4, (uint32_t)(C / 4), out);
+    const int64_t total4 = n * (C / 4), plan4 = np * (C / 4);
+    if (plan4 >= 4 * 256 * 256)  // enough elements to keep every CU busy with 4 per thread
+      hipLaunchKernelGGL(gather_rows_kernel<4>, dim3(gpn::dev_grid(gpn::cdiv(total4, 4 * 256), gpn::cdiv(plan4, 4 * 256), dev)), dim3(256), 0,
+                         stream, table, idx, (uint32_t)total4, (uint32_t)(C / 4), out, rows.dev);
     else
-      hipLaunchKernelGGL(gather_rows_kernel<1>, dim3((int)gpn::cdiv(total4, 256)), dim3(256), 0, stream, table, idx,
-                         (uint32_t)total4, (uint32_t)(C / 4), out);
+      hipLaunchKernelGGL(gather_rows_kernel<1>, dim3(gpn::dev_grid(gpn::cdiv(total4, 256), gpn::cdiv(plan4, 256), dev)), dim3(256), 0, stream,
+                         table, idx, (uint32_t)total4, (uint32_t)(C / 4), out, rows.dev);
   } else {
-    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((int)gpn::cdiv(n * C, 256)), dim3(256), 0, stream, table,
-                       idx, n, C, out);
+    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3(gpn::dev_grid(gpn::cdiv(n * C, 256), gpn::cdiv(np * C, 256), dev)), dim3(256), 0, stream,
+                       table, idx, n, C, out, rows.dev);
   }
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+extern "C" int gpn_gather_rows(const float* table, const int32_t* idx, int64_t n, int C, float* out,
+                               gpn_stream_t stream_) {
+  return gather_rows_impl(table, idx, n, gpn::DevRows(), C, out, (hipStream_t)stream_);
+}
+// row count on the device: n = the bound of idx / out, *n_dev the live count, n_plan the host's estimate (grid size only)
+extern "C" int gpn_gather_rows_dev(const float* table, const int32_t* idx, int64_t n, const int64_t* n_dev, int64_t n_plan, int C,
+                                   float* out, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(n_dev != nullptr);
+  return gather_rows_impl(table, idx, n, gpn::DevRows{n_dev, n_plan}, C, out, (hipStream_t)stream_);
+}
+
+static int scatter_rows_csr_impl(const float* dout, const int32_t* order, const int32_t* starts, int64_t n_rows,
+                                 const gpn::DevRows& rows, int C, float* dtable, hipStream_t stream) {
+  GPN_CHECK_ARG(n_rows >= 0 && C >= 1);
+  if (n_rows == 0) return GPN_OK;
+  GPN_CHECK_ARG(starts && dtable);  // dout / order may be NULL when no point exists (every starts[r] is then 0)
+  const int64_t np = gpn::plan_rows(n_rows, rows);
+  const bool dev = rows.dev != nullptr;
+  if (C % 4 == 0 && n_rows * (C / 4) < (int64_t)0x7fffffff)
+    hipLaunchKernelGGL(scatter_rows_csr_v4_kernel, dim3(gpn::dev_grid(gpn::cdiv(n_rows * (C / 4), 256), gpn::cdiv(np * (C / 4), 256), dev)),
+                       dim3(256), 0, stream, dout, order, starts, (uint32_t)(n_rows * (C / 4)), (uint32_t)(C / 4), dtable, rows.dev);
+  else
+    hipLaunchKernelGGL(scatter_rows_csr_kernel, dim3(gpn::dev_grid(gpn::cdiv(n_rows * C, 256), gpn::cdiv(np * C, 256), dev)), dim3(256), 0,
+                       stream, dout, order, starts, n_rows, C, dtable, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
 
 extern "C" int gpn_scatter_rows_csr(const float* dout, const int32_t* order, const int32_t* starts,
                                     int64_t n_rows, int C, float* dtable, gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  GPN_CHECK_ARG(n_rows >= 0 && C >= 1);
-  if (n_rows == 0) return GPN_OK;
-  GPN_CHECK_ARG(starts && dtable);  // dout / order may be NULL when no point exists (every starts[r] is then 0)
-  if (C % 4 == 0 && n_rows * (C / 4) < (int64_t)0x7fffffff)
-    hipLaunchKernelGGL(scatter_rows_csr_v4_kernel, dim3((int)gpn::cdiv(n_rows * (C / 4), 256)), dim3(256), 0, stream, dout,
-                       order, starts, (uint32_t)(n_rows * (C / 4)), (uint32_t)(C / 4), dtable);
-  else
-    hipLaunchKernelGGL(scatter_rows_csr_kernel, dim3((int)gpn::cdiv(n_rows * C, 256)), dim3(256), 0, stream, dout,
-                       order, starts, n_rows, C, dtable);
-  GPN_CHECK_LAUNCH();
-  return GPN_OK;
+  return scatter_rows_csr_impl(dout, order, starts, n_rows, gpn::DevRows(), C, dtable, (hipStream_t)stream_);
+}
+extern "C" int gpn_scatter_rows_csr_dev(const float* dout, const int32_t* order, const int32_t* starts, int64_t n_rows,
+                                        const int64_t* n_dev, int64_t n_plan, int C, float* dtable, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(n_dev != nullptr);
+  return scatter_rows_csr_impl(dout, order, starts, n_rows, gpn::DevRows{n_dev, n_plan}, C, dtable, (hipStream_t)stream_);
 }

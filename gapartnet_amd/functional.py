@@ -102,11 +102,18 @@ class _LinearFn(torch.autograd.Function):
     with three operator calls (forward, dgrad, wgrad) and no autograd-visible pad / slice ops."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, rows=None):
         ops = backend.raw()
         x = x.contiguous()
         cout, cin = weight.shape
         ctx.native = hasattr(ops, "linear_fwd") and ops.linear_supported(cin, cout)
+        ctx.rows = rows
+        if rows is not None:
+            assert ctx.native, "a device-counted row count needs the dense-head kernels (csrc/linear.hip)"
+            w = weight.detach().contiguous()
+            ctx.save_for_backward(x, w)
+            ctx.has_bias = bias is not None
+            return ops.linear_fwd(x, w, bias.detach() if bias is not None else None, rows=rows)
         if ctx.native:
             w = weight.detach().contiguous()
             ctx.save_for_backward(x, w)
@@ -128,9 +135,12 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         ops = backend.raw()
         x, w = ctx.saved_tensors
+        if ctx.rows is not None:
+            return ops.linear_bwd(x, w, dy.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                  ctx.has_bias and ctx.needs_input_grad[2], rows=ctx.rows) + (None,)
         if ctx.native:
             return ops.linear_bwd(x, w, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                  ctx.has_bias and ctx.needs_input_grad[2])
+                                  ctx.has_bias and ctx.needs_input_grad[2]) + (None,)
         cout, cout_p = ctx.cout, w.shape[0]
         dy_p = dy.contiguous() if cout_p == cout else F.pad(dy, (0, cout_p - cout))
         dx = ops.conv_dgrad(dy_p, w, ctx.rb, ctx.rb, False, "oki") if ctx.needs_input_grad[0] else None
@@ -138,15 +148,17 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = ops.conv_wgrad(x, dy_p, ctx.rb, "oki").view(cout_p, x.shape[1])[:cout]
         db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, rows=None) -> torch.Tensor:
     """``F.linear`` for the per-point / per-voxel heads (model.py:160-175: Linear(16, n) on 10^5 rows).  These are
     K = 1 cases of the fused conv kernel family (forward, dgrad, wgrad): at [160k, 16] x [16, 3..27] the library GEMMs
     the framework dispatches to run at 0.2-0.4 TFLOP/s (fwd+bwd 260-380 us per layer vs 200-250 here).
     Falls back to F.linear for shapes the kernels do not cover."""
     ops = backend.raw()
+    if rows is not None:  # hip_ops.DevCount: x.shape[0] is a bound, the live row count a device counter
+        return _LinearFn.apply(x, weight, bias, rows)
     if ops.name != "hip" or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32 or x.shape[0] == 0:
         return F.linear(x, weight, bias)
     if hasattr(ops, "linear_supported") and ops.linear_supported(x.shape[1], weight.shape[0]):
@@ -160,24 +172,30 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 class _GatherRowsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, idx, csr):
+    def forward(ctx, table, idx, csr, rows, table_rows):
         ops = backend.raw()
         ctx.save_for_backward(idx)
         ctx.csr = csr
         ctx.n_rows = table.shape[0]
+        ctx.table_rows = table_rows
+        if rows is not None:
+            return ops.gather_rows(table.contiguous(), idx, rows=rows)
         return ops.gather_rows(table.contiguous(), idx)
 
     @staticmethod
     def backward(ctx, dout):
         ops = backend.raw()
         (idx,) = ctx.saved_tensors
-        return ops.scatter_rows(dout.contiguous(), idx, ctx.n_rows, ctx.csr), None, None
+        if ctx.table_rows is not None:
+            return ops.scatter_rows(dout.contiguous(), idx, ctx.n_rows, ctx.csr, rows=ctx.table_rows), None, None, None, None
+        return ops.scatter_rows(dout.contiguous(), idx, ctx.n_rows, ctx.csr), None, None, None, None
 
 
-def gather_rows(table: torch.Tensor, idx: torch.Tensor, csr=None) -> torch.Tensor:
+def gather_rows(table: torch.Tensor, idx: torch.Tensor, csr=None, rows=None, table_rows=None) -> torch.Tensor:
     """table[idx] with idx<0 -> zero row (reference: ``voxel_features.features[pc_voxel_id]``, model.py:153,359,394).
-    ``csr`` = (order, starts) of points grouped by row, if the caller already has it (voxelize returns it)."""
-    return _GatherRowsFn.apply(table, idx, csr)
+    ``csr`` = (order, starts) of points grouped by row, if the caller already has it (voxelize returns it).
+    ``rows`` / ``table_rows`` (hip_ops.DevCount): the live lengths of ``idx`` / of ``table`` are device counters."""
+    return _GatherRowsFn.apply(table, idx, csr, rows, table_rows)
 
 
 class _VoxelMeanFn(torch.autograd.Function):
@@ -220,23 +238,26 @@ class _ProposalVoxelMeanFn(torch.autograd.Function):
     the (at most two) proposals it belongs to.  The index structure comes from ``hip_ops.proposals_build``."""
 
     @staticmethod
-    def forward(ctx, feats, point_indices, point_order, voxel_point_start, member_slot, pc_voxel_id, n_voxels):
+    def forward(ctx, feats, point_indices, point_order, voxel_point_start, member_slot, pc_voxel_id, n_voxels, rows):
         ops = backend.raw()
         ctx.save_for_backward(member_slot, pc_voxel_id, voxel_point_start)
         ctx.n_points = feats.shape[0]
+        if rows is not None:
+            return ops.proposals_voxel_mean(feats.contiguous(), point_indices, point_order, voxel_point_start, n_voxels, rows=rows)
         return ops.proposals_voxel_mean(feats.contiguous(), point_indices, point_order, voxel_point_start, n_voxels)
 
     @staticmethod
     def backward(ctx, dout):
         ops = backend.raw()
         member_slot, pc_voxel_id, voxel_point_start = ctx.saved_tensors
+        # (one thread per ORIGINAL point walks its at most two memberships: no data-dependent extent)
         return (ops.proposals_voxel_mean_bwd(dout.contiguous(), member_slot, pc_voxel_id, voxel_point_start, ctx.n_points),
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
-def proposal_voxel_mean(feats, built) -> torch.Tensor:
+def proposal_voxel_mean(feats, built, rows=None) -> torch.Tensor:
     return _ProposalVoxelMeanFn.apply(feats, built["point_indices"], built["point_order"], built["voxel_point_start"],
-                                      built["member_slot"], built["pc_voxel_id"], built["V"])
+                                      built["member_slot"], built["pc_voxel_id"], built["V"], rows)
 
 
 class _ScoreLossFn(torch.autograd.Function):
@@ -244,9 +265,13 @@ class _ScoreLossFn(torch.autograd.Function):
     one multiplication.  -> (loss 0-dim, score_preds [P] without a gradient)"""
 
     @staticmethod
-    def forward(ctx, logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh):
-        loss, preds, d_logits = backend.raw().score_loss(logits.contiguous(), cls_source, proposal_offsets, ious, fg_thresh,
-                                                         bg_thresh)
+    def forward(ctx, logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh, rows):
+        if rows is not None:
+            loss, preds, d_logits = backend.raw().score_loss(logits.contiguous(), cls_source, proposal_offsets, ious, fg_thresh,
+                                                             bg_thresh, rows=rows)
+        else:
+            loss, preds, d_logits = backend.raw().score_loss(logits.contiguous(), cls_source, proposal_offsets, ious, fg_thresh,
+                                                             bg_thresh)
         ctx.save_for_backward(d_logits)
         ctx.mark_non_differentiable(preds)
         return loss.reshape(()), preds
@@ -254,7 +279,7 @@ class _ScoreLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss, _grad_preds):
         (d_logits,) = ctx.saved_tensors
-        return d_logits * grad_loss, None, None, None, None, None
+        return d_logits * grad_loss, None, None, None, None, None, None
 
 
 def score_loss_available(logits: torch.Tensor) -> bool:
@@ -262,33 +287,40 @@ def score_loss_available(logits: torch.Tensor) -> bool:
             and hasattr(backend.raw(), "score_loss"))
 
 
-def score_loss(logits, cls_source, proposal_offsets, ious, fg_thresh: float = 0.75, bg_thresh: float = 0.25):
-    return _ScoreLossFn.apply(logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh)
+def score_loss(logits, cls_source, proposal_offsets, ious, fg_thresh: float = 0.75, bg_thresh: float = 0.25, rows=None):
+    return _ScoreLossFn.apply(logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh, rows)
 
 
 class _NpcsLossFn(torch.autograd.Function):
     """symmetry-aware NPCS loss of all proposals (model.py:398-462): two launches forward, one backward"""
 
     @staticmethod
-    def forward(ctx, logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, proposal_indices, sym):
+    def forward(ctx, logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, proposal_indices, sym, p_rows, m_rows):
         ops = backend.raw()
         logits, gt_npcs = logits.contiguous(), gt_npcs.contiguous()
         sem_preds, sem_labels = sem_preds.to(torch.int32).contiguous(), sem_labels.to(torch.int64).contiguous()
-        loss, scratch = ops.npcs_loss_fwd(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, sym)
+        if p_rows is not None:
+            loss, scratch = ops.npcs_loss_fwd(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, sym, rows=p_rows)
+        else:
+            loss, scratch = ops.npcs_loss_fwd(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, sym)
         ctx.save_for_backward(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, scratch)
-        ctx.sym, ctx.P = sym, proposal_offsets.shape[0] - 1
+        ctx.sym, ctx.P, ctx.m_rows = sym, proposal_offsets.shape[0] - 1, m_rows
         return loss[0]
 
     @staticmethod
     def backward(ctx, grad_loss):
         ops = backend.raw()
         logits, gt_npcs, sem_preds, sem_labels, proposal_indices, scratch = ctx.saved_tensors
-        d_logits = ops.npcs_loss_bwd(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, ctx.P, ctx.sym, scratch, grad_loss)
-        return d_logits, None, None, None, None, None, None
+        if ctx.m_rows is not None:
+            d_logits = ops.npcs_loss_bwd(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, ctx.P, ctx.sym, scratch, grad_loss,
+                                         m_rows=ctx.m_rows)
+        else:
+            d_logits = ops.npcs_loss_bwd(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, ctx.P, ctx.sym, scratch, grad_loss)
+        return d_logits, None, None, None, None, None, None, None, None
 
 
-def npcs_loss(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, proposal_indices, sym) -> torch.Tensor:
-    return _NpcsLossFn.apply(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, proposal_indices, sym)
+def npcs_loss(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, proposal_indices, sym, p_rows=None, m_rows=None) -> torch.Tensor:
+    return _NpcsLossFn.apply(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, proposal_indices, sym, p_rows, m_rows)
 
 
 class _PointLossesFn(torch.autograd.Function):
@@ -327,11 +359,14 @@ def point_losses(logits, offsets, labels, gt_offsets, instance_labels, ignore_in
 
 class _SegmentedMaxpoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, values, begin, end):
+    def forward(ctx, values, begin, end, rows, m_rows):
         ops = backend.raw()
-        pooled, argmax = ops.segmented_maxpool_fwd(values.contiguous(), begin, end)
+        if rows is not None:
+            pooled, argmax = ops.segmented_maxpool_fwd(values.contiguous(), begin, end, rows=rows)
+        else:
+            pooled, argmax = ops.segmented_maxpool_fwd(values.contiguous(), begin, end)
         ctx.save_for_backward(argmax)
-        ctx.M = values.shape[0]
+        ctx.M, ctx.rows, ctx.m_rows = values.shape[0], rows, m_rows
         ctx.mark_non_differentiable(argmax)
         return pooled, argmax
 
@@ -339,11 +374,14 @@ class _SegmentedMaxpoolFn(torch.autograd.Function):
     def backward(ctx, dpooled, _dargmax):
         ops = backend.raw()
         (argmax,) = ctx.saved_tensors
-        return ops.segmented_maxpool_bwd(dpooled.contiguous(), argmax, ctx.M), None, None
+        if ctx.rows is not None:
+            return ops.segmented_maxpool_bwd(dpooled.contiguous(), argmax, ctx.M, rows=ctx.rows, m_rows=ctx.m_rows), None, None, None, None
+        return ops.segmented_maxpool_bwd(dpooled.contiguous(), argmax, ctx.M), None, None, None, None
 
 
-def segmented_maxpool(values, begin, end):
-    return _SegmentedMaxpoolFn.apply(values, begin, end)
+def segmented_maxpool(values, begin, end, rows=None, m_rows=None):
+    """``rows`` / ``m_rows`` (hip_ops.DevCount): the number of segments / of value rows are device counters"""
+    return _SegmentedMaxpoolFn.apply(values, begin, end, rows, m_rows)
 
 
 class _BnActFn(torch.autograd.Function):

@@ -82,6 +82,25 @@ class Rulebook:
         return int(self.num_pairs.item())
 
 
+class DevCount:
+    """A row count that is still on the device (include/gpn.h section DEV): ``t`` = int64 [1] device tensor (usually a view
+    into the counts array of the launch that produced it), ``plan`` = the host's estimate of its value (0 = none; it sizes
+    grids and picks kernel variants, results never depend on it).  Tensors that go with it are allocated for a BOUND."""
+    __slots__ = ("t", "plan")
+
+    def __init__(self, t: torch.Tensor, plan: int = 0):
+        assert t.dtype == torch.int64 and t.numel() == 1 and t.is_cuda
+        self.t, self.plan = t, max(int(plan), 0)
+
+    @property
+    def ptr(self):
+        return _C.ctypes.c_void_p(self.t.data_ptr())
+
+    def args(self):
+        """(device pointer, plan) as ctypes arguments"""
+        return _C.ctypes.c_void_p(self.t.data_ptr()), _C.ctypes.c_int64(self.plan)
+
+
 # ---------------------------------------------------------------------------------------------------- V
 def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_size, grid_dims, want_csr=False,
              want_stats=False):
@@ -151,7 +170,9 @@ def voxelize_scenes(points, feats, seg_offsets, voxel_size, n_levels=0):
 
 
 # ---------------------------------------------------------------------------------------------------- K
-def rulebook_subm3(indices, spatial_shape) -> Rulebook:
+def rulebook_subm3(indices, spatial_shape, rows: Optional[DevCount] = None) -> Rulebook:
+    """``rows``: the live row count of ``indices`` is a device counter (indices.shape[0] = its bound): every buffer is sized for
+    the bound, the tables are laid out for the live count, no tile order"""
     dev = _dev(indices)
     indices = _c(indices, torch.int32)
     N = indices.shape[0]
@@ -163,6 +184,10 @@ def rulebook_subm3(indices, spatial_shape) -> Rulebook:
     L = _C.lib()
     ws = _ws(L.gpn_rulebook_subm3_ws_bytes(i64(N)), dev)
     nbr = torch.empty((27 * N + 1,), dtype=torch.int32, device=dev)
+    if rows is not None:
+        check(L.gpn_rulebook_subm3_dev(ptr(indices), i64(N), *rows.args(), host_i32x3(spatial_shape), ptr(nbr), ptr(src), ptr(dst),
+                                       ptr(toff), ptr(npairs), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_subm3_dev")
+        return Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr)
     check(L.gpn_rulebook_subm3(ptr(indices), i64(N), host_i32x3(spatial_shape), ptr(nbr), ptr(src), ptr(dst), ptr(toff),
                                ptr(npairs), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_subm3")
     return _with_tile_order(Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr))
@@ -199,12 +224,17 @@ def tile_order(nbr, K, n):
 _CHECK_LEVEL_COUNTS = _os.environ.get("GPN_CHECK_LEVEL_COUNTS") == "1"
 
 
-def rulebook_identity(n, device) -> Rulebook:
-    """the K = 1 rulebook over ``n`` rows (SubMConv3d(k=1), linear layers on the conv kernels) in one launch"""
+def rulebook_identity(n, device, rows_dev: Optional[DevCount] = None) -> Rulebook:
+    """the K = 1 rulebook over ``n`` rows (SubMConv3d(k=1), linear layers on the conv kernels) in one launch; ``rows_dev``: n is
+    a bound, the live count a device counter"""
     rows = torch.empty((max(n, 1),), dtype=torch.int32, device=device)[:n]
     tile_off = torch.empty((1, n_tiles(n) + 1), dtype=torch.int32, device=device)
     nbr = torch.empty((n + 1,), dtype=torch.int32, device=device)
     npairs = torch.empty((1,), dtype=torch.int64, device=device)
+    if rows_dev is not None:
+        check(_C.lib().gpn_rulebook_identity_dev(i64(n), *rows_dev.args(), ptr(rows), ptr(tile_off), ptr(nbr), ptr(npairs), _stream()),
+              "gpn_rulebook_identity_dev")
+        return Rulebook(rows, rows, tile_off, 1, n, n, npairs[0], nbr)
     check(_C.lib().gpn_rulebook_identity(i64(n), ptr(rows if n > 0 else nbr), ptr(tile_off), ptr(nbr), ptr(npairs), _stream()),
           "gpn_rulebook_identity")
     return Rulebook(rows, rows, tile_off, 1, n, n, npairs[0], nbr)
@@ -260,6 +290,44 @@ def rulebook_down(indices, spatial_shape, batch_size, n_out=None):
     rb_fwd = Rulebook(fs, fd, ft, 8, N, No, npairs[0], fn)  # (dst = coarse: 1-8 children per row, the order buys nothing: 10.7 -> 10 us)
     rb_bwd = _with_tile_order(Rulebook(bs, bd, bt, 8, No, N, npairs[0], bn))  # dst = fine: one tap per row, 4.3x -> 1.0x slots
     return out_idx[:No], out_shape, rb_fwd, rb_bwd
+
+
+def rulebook_down_dev(indices, spatial_shape, batch_size, rows: DevCount, batch: Optional[DevCount], out_plan: int = 0):
+    """rulebook_down with the fine row count (and optionally the number of batch entries - the proposals of a step) on the
+    device: no host read.  ``indices.shape[0]`` / ``batch_size`` are bounds.  -> (out_indices [bound,4], out_shape, rb_fwd,
+    rb_bwd, coarse rows as a DevCount with plan ``out_plan``)"""
+    dev = _dev(indices)
+    indices = _c(indices, torch.int32)
+    N = indices.shape[0]
+    out_idx = torch.empty((N, 4), dtype=torch.int32, device=dev)
+    f2c = torch.empty((N,), dtype=torch.int32, device=dev)
+    tap = torch.empty((N,), dtype=torch.int32, device=dev)
+    nout = torch.empty((1,), dtype=torch.int64, device=dev)
+    L = _C.lib()
+    shape = host_i32x3(spatial_shape)
+    ws = _ws(L.gpn_rulebook_down_dev_ws_bytes(i64(N), i64(batch_size), shape), dev)
+    b_ptr, b_plan = batch.args() if batch is not None else (_C.ctypes.c_void_p(0), _C.ctypes.c_int64(0))
+    check(L.gpn_rulebook_down_dev(ptr(indices), i64(N), *rows.args(), i64(batch_size), b_ptr, b_plan, shape, ptr(out_idx), ptr(f2c),
+                                  ptr(tap), ptr(nout), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_down_dev")
+    out_rows = DevCount(nout, out_plan)
+    No = N  # bound of the coarse level
+    fs = torch.empty((N,), dtype=torch.int32, device=dev)
+    fd = torch.empty((N,), dtype=torch.int32, device=dev)
+    bs = torch.empty((N,), dtype=torch.int32, device=dev)
+    bd = torch.empty((N,), dtype=torch.int32, device=dev)
+    ft = torch.empty((8, n_tiles(No) + 1), dtype=torch.int32, device=dev)
+    bt = torch.empty((8, n_tiles(N) + 1), dtype=torch.int32, device=dev)
+    npairs = torch.empty((1,), dtype=torch.int64, device=dev)
+    ws = _ws(L.gpn_rulebook_down_lists_ws_bytes(i64(N), i64(No)), dev)
+    fn = torch.empty((8 * No + 1,), dtype=torch.int32, device=dev)
+    bn = torch.empty((8 * N + 1,), dtype=torch.int32, device=dev)
+    check(L.gpn_rulebook_down_lists_dev(ptr(f2c), ptr(tap), i64(N), *rows.args(), i64(No), *out_rows.args(), ptr(fn), ptr(fs), ptr(fd),
+                                        ptr(ft), ptr(bn), ptr(bs), ptr(bd), ptr(bt), ptr(npairs), ptr(ws), szt(ws.numel()), _stream()),
+          "gpn_rulebook_down_lists_dev")
+    out_shape = [int(s) // 2 for s in spatial_shape]
+    rb_fwd = Rulebook(fs, fd, ft, 8, N, No, npairs[0], fn)
+    rb_bwd = Rulebook(bs, bd, bt, 8, No, N, npairs[0], bn)
+    return out_idx, out_shape, rb_fwd, rb_bwd, out_rows
 
 
 # ---------------------------------------------------------------------------------------------------- C
@@ -474,10 +542,14 @@ def bn_bwd(x, y, dy, weight, mean, invstd, relu, training, has_res):
 
 
 # ---------------------------------------------------------------------------------------------------- G
-def gather_rows(table, idx):
+def gather_rows(table, idx, rows: Optional[DevCount] = None):
     dev = _dev(table, idx)
     table, idx = _c(table, torch.float32), _c(idx, torch.int32)
     out = torch.empty((idx.shape[0], table.shape[1]), dtype=torch.float32, device=dev)
+    if rows is not None:  # the live length of idx is a device counter (rows of `out` past it stay unwritten)
+        check(_C.lib().gpn_gather_rows_dev(ptr(table), ptr(idx), i64(idx.shape[0]), *rows.args(), i32(table.shape[1]), ptr(out),
+                                           _stream()), "gpn_gather_rows_dev")
+        return out
     check(_C.lib().gpn_gather_rows(ptr(table), ptr(idx), i64(idx.shape[0]), i32(table.shape[1]), ptr(out), _stream()),
           "gpn_gather_rows")
     return out
@@ -494,12 +566,18 @@ def rows_csr(idx, n_rows):
     return order.to(torch.int32), starts
 
 
-def scatter_rows(dout, idx, n_rows, csr=None):
-    """transpose of gather_rows: dtable[r] = ordered sum of dout[i] over idx[i] == r."""
+def scatter_rows(dout, idx, n_rows, csr=None, rows: Optional[DevCount] = None):
+    """transpose of gather_rows: dtable[r] = ordered sum of dout[i] over idx[i] == r.  ``rows``: the live number of table rows
+    is a device counter (n_rows = its bound; needs ``csr``)."""
     dev = _dev(dout, idx)
     dout = _c(dout, torch.float32)
     order, starts = csr if csr is not None else rows_csr(idx, n_rows)
     out = torch.empty((n_rows, dout.shape[1]), dtype=torch.float32, device=dev)
+    if rows is not None:
+        assert csr is not None, "a device-counted scatter needs the caller's CSR"
+        check(_C.lib().gpn_scatter_rows_csr_dev(ptr(dout), ptr(_c(order, torch.int32)), ptr(_c(starts, torch.int32)), i64(n_rows),
+                                                *rows.args(), i32(dout.shape[1]), ptr(out), _stream()), "gpn_scatter_rows_csr_dev")
+        return out
     check(_C.lib().gpn_scatter_rows_csr(ptr(dout), ptr(_c(order, torch.int32)), ptr(_c(starts, torch.int32)),
                                         i64(n_rows), i32(dout.shape[1]), ptr(out), _stream()),
           "gpn_scatter_rows_csr")
@@ -556,32 +634,45 @@ def segmented_reduce(values, begin, end, mode):
     return out
 
 
-def segmented_maxpool_fwd(values, begin, end):
+def segmented_maxpool_fwd(values, begin, end, rows: Optional[DevCount] = None):
     dev = _dev(values, begin, end)
     values, begin, end = _c(values, torch.float32), _c(begin, torch.int32), _c(end, torch.int32)
     P, C = begin.shape[0], values.shape[1]
     pooled = torch.empty((P, C), dtype=torch.float32, device=dev)
     arg = torch.empty((P, C), dtype=torch.int32, device=dev)
+    if rows is not None:  # the number of segments is a device counter (P = its bound)
+        check(_C.lib().gpn_segmented_maxpool_fwd_dev(ptr(values), ptr(begin), ptr(end), i64(P), *rows.args(), i32(C), ptr(pooled),
+                                                     ptr(arg), _stream()), "gpn_segmented_maxpool_fwd_dev")
+        return pooled, arg
     check(_C.lib().gpn_segmented_maxpool_fwd(ptr(values), ptr(begin), ptr(end), i64(P), i32(C), ptr(pooled), ptr(arg),
                                              _stream()), "gpn_segmented_maxpool_fwd")
     return pooled, arg
 
 
-def segmented_maxpool_bwd(dpooled, argmax, M):
+def segmented_maxpool_bwd(dpooled, argmax, M, rows: Optional[DevCount] = None, m_rows: Optional[DevCount] = None):
     dev = _dev(dpooled, argmax)
     dpooled, argmax = _c(dpooled, torch.float32), _c(argmax, torch.int32)
     P, C = dpooled.shape
     dv = torch.empty((M, C), dtype=torch.float32, device=dev)
+    if rows is not None:
+        check(_C.lib().gpn_segmented_maxpool_bwd_dev(ptr(dpooled), ptr(argmax), i64(P), *rows.args(), i32(C), i64(M), *m_rows.args(),
+                                                     ptr(dv), _stream()), "gpn_segmented_maxpool_bwd_dev")
+        return dv
     check(_C.lib().gpn_segmented_maxpool_bwd(ptr(dpooled), ptr(argmax), i64(P), i32(C), i64(M), ptr(dv), _stream()),
           "gpn_segmented_maxpool_bwd")
     return dv
 
 
-def instance_iou(proposal_offsets, instance_labels, batch_indices, num_points_per_instance):
+def instance_iou(proposal_offsets, instance_labels, batch_indices, num_points_per_instance, rows: Optional[DevCount] = None):
     dev = _dev(proposal_offsets, instance_labels, batch_indices, num_points_per_instance)
     po, il = _c(proposal_offsets, torch.int32), _c(instance_labels, torch.int32)
     bi, npi = _c(batch_indices, torch.int32), _c(num_points_per_instance, torch.int32)
     P, (B, I) = po.shape[0] - 1, npi.shape
+    if rows is not None:  # the proposal count is a device counter (P = its bound; rows past it stay unwritten)
+        out = torch.empty((P, I), dtype=torch.float32, device=dev)
+        check(_C.lib().gpn_instance_iou_dev(ptr(po), ptr(il), ptr(bi), ptr(npi), i64(P), *rows.args(), i64(B), i32(I), ptr(out),
+                                            _stream()), "gpn_instance_iou_dev")
+        return out
     out = torch.zeros((P, I), dtype=torch.float32, device=dev)
     check(_C.lib().gpn_instance_iou(ptr(po), ptr(il), ptr(bi), ptr(npi), i64(P), i64(B), i32(I), ptr(out), _stream()),
           "gpn_instance_iou")
@@ -716,7 +807,7 @@ def pn2_three_interpolate_grad(grad_out, idx, weight, m):
 
 # ---------------------------------------------------------------------------------------------------- PR
 def proposals_build(points_xyz, offset_preds, sem_preds, instance_labels, batch_indices, batch_size, radius, K1, K2,
-                    min_points, fullscale, max_scale, jitter):
+                    min_points, fullscale, max_scale, jitter, read_counts: bool = True):
     """Section PR of include/gpn.h: the whole proposal stage (model.py:228-346 of the reference) in one library call and ONE
     host read.  ``points_xyz`` = [N,3] view of the [N,6] point matrix (row stride passed through).  -> dict of tensors
     sliced to their actual sizes, or None when no proposal survives."""
@@ -753,10 +844,19 @@ def proposals_build(points_xyz, offset_preds, sem_preds, instance_labels, batch_
                                 ptr(point_indices), ptr(proposal_indices), ptr(batch_p), ptr(xyz_p), ptr(sem_p), ptr(inst_p),
                                 ptr(sizes), ptr(offsets), ptr(member_slot), ptr(coords4), ptr(pid), ptr(order), ptr(vstart),
                                 ptr(ws), szt(ws.numel()), _stream()), "gpn_proposals_build")
+    if not read_counts:
+        # no host read: every output at its bound, the counts stay on the device (DevCount views of `counts`; section DEV of
+        # include/gpn.h).  P_ub + 1 offsets, T2 = 2 N per-point rows, T2 voxel rows.
+        return dict(counts=counts, Q_dev=counts[0:1], M_dev=counts[1:2], P_dev=counts[2:3], V_dev=counts[3:4],
+                    coarse_dev=counts[6:7], P=P_ub, M=T2, V=T2, valid_mask=valid_mask, valid_indices=valid_indices,
+                    sorted_indices=sorted_indices, point_indices=point_indices, proposal_indices=proposal_indices,
+                    batch_indices=batch_p, pt_xyz=xyz_p, sem_preds=sem_p, instance_labels=inst_p if instance_labels is not None else None,
+                    sizes=sizes[:P_ub], proposal_offsets=offsets, member_slot=member_slot, voxel_coords=coords4, pc_voxel_id=pid,
+                    point_order=order, voxel_point_start=vstart)
     Q, M, P, V, dropped, _, coarse = counts.tolist()[:7]  # the stage's single device -> host read
     if M == 0:
         return None
-    return dict(Q=Q, M=M, P=P, V=V, dropped=dropped, coarse=coarse, valid_mask=valid_mask, valid_indices=valid_indices[:Q],
+    return dict(counts_host=(Q, M, P, V, dropped, coarse), Q=Q, M=M, P=P, V=V, dropped=dropped, coarse=coarse, valid_mask=valid_mask, valid_indices=valid_indices[:Q],
                 sorted_indices=sorted_indices[:M], point_indices=point_indices[:M], proposal_indices=proposal_indices[:M],
                 batch_indices=batch_p[:M], pt_xyz=xyz_p[:M], sem_preds=sem_p[:M],
                 instance_labels=inst_p[:M] if instance_labels is not None else None, sizes=sizes[:P],
@@ -764,10 +864,26 @@ def proposals_build(points_xyz, offset_preds, sem_preds, instance_labels, batch_
                 point_order=order[:M], voxel_point_start=vstart[:V + 1])
 
 
-def proposals_voxel_mean(feats, point_indices, point_order, voxel_point_start, V):
+def proposals_targets(sem_labels, gt_npcs, point_indices, rows: DevCount):
+    """sem_labels [N] i64 / gt_npcs [N,3] f32 (either may be None) at the proposal points -> ([M] i64 or None, [M,3] f32 or
+    None), M = point_indices.shape[0] = the bound; rows past the device count stay unwritten"""
+    dev = _dev(point_indices)
+    M = point_indices.shape[0]
+    sem_out = torch.empty((M,), dtype=torch.int64, device=dev) if sem_labels is not None else None
+    npcs_out = torch.empty((M, 3), dtype=torch.float32, device=dev) if gt_npcs is not None else None
+    check(_C.lib().gpn_proposals_targets_dev(ptr(_c(sem_labels, torch.int64)), ptr(_c(gt_npcs, torch.float32)), ptr(point_indices),
+                                             i64(M), *rows.args(), ptr(sem_out), ptr(npcs_out), _stream()), "gpn_proposals_targets_dev")
+    return sem_out, npcs_out
+
+
+def proposals_voxel_mean(feats, point_indices, point_order, voxel_point_start, V, rows: Optional[DevCount] = None):
     dev = _dev(feats)
     feats = _c(feats, torch.float32)
     out = torch.empty((V, feats.shape[1]), dtype=torch.float32, device=dev)
+    if rows is not None:
+        check(_C.lib().gpn_proposals_voxel_mean_dev(ptr(feats), ptr(point_indices), ptr(point_order), ptr(voxel_point_start), i64(V),
+                                                    *rows.args(), i32(feats.shape[1]), ptr(out), _stream()), "gpn_proposals_voxel_mean_dev")
+        return out
     check(_C.lib().gpn_proposals_voxel_mean(ptr(feats), ptr(point_indices), ptr(point_order), ptr(voxel_point_start), i64(V),
                                             i32(feats.shape[1]), ptr(out), _stream()), "gpn_proposals_voxel_mean")
     return out
@@ -788,7 +904,7 @@ def _npcs_args(sym):
     return i32a(sym["first"]), i32a(sym["count"]), i32a(sym["group"]), i32(len(sym["first"]))
 
 
-def npcs_loss_fwd(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, sym):
+def npcs_loss_fwd(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, sym, rows: Optional[DevCount] = None):
     """-> (loss [1] f32, scratch for the backward).  ``sym`` = dict(sym_of_class i64 [classes], mats f32 [n,3,3] (device),
     first / count / group: python lists per symmetry type)."""
     dev = _dev(logits, gt_npcs)
@@ -799,16 +915,28 @@ def npcs_loss_fwd(logits, gt_npcs, sem_preds, sem_labels, proposal_offsets, sym)
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     scratch = torch.empty((9 * P + 4,), dtype=torch.float32, device=dev)
     first, count, group, n = _npcs_args(sym)
+    if rows is not None:  # the proposal count is a device counter (P = its bound)
+        check(_C.lib().gpn_npcs_loss_fwd_dev(ptr(logits), i32(logits.shape[1]), ptr(gt_npcs), ptr(sem_preds), ptr(sem_labels),
+                                             ptr(proposal_offsets), i64(P), *rows.args(), ptr(sym["sym_of_class"]), ptr(sym["mats"]),
+                                             first, count, group, n, ptr(loss), ptr(scratch), _stream()), "gpn_npcs_loss_fwd_dev")
+        return loss, scratch
     check(_C.lib().gpn_npcs_loss_fwd(ptr(logits), i32(logits.shape[1]), ptr(gt_npcs), ptr(sem_preds), ptr(sem_labels),
                                      ptr(proposal_offsets), i64(P), ptr(sym["sym_of_class"]), ptr(sym["mats"]), first, count,
                                      group, n, ptr(loss), ptr(scratch), _stream()), "gpn_npcs_loss_fwd")
     return loss, scratch
 
 
-def npcs_loss_bwd(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, P, sym, scratch, grad_loss):
+def npcs_loss_bwd(logits, gt_npcs, sem_preds, sem_labels, proposal_indices, P, sym, scratch, grad_loss,
+                  m_rows: Optional[DevCount] = None):
     dev = _dev(logits)
     d_logits = torch.empty_like(logits)
     first, count, group, n = _npcs_args(sym)
+    if m_rows is not None:  # the point count is a device counter (rows of d_logits past it stay unwritten)
+        check(_C.lib().gpn_npcs_loss_bwd_dev(ptr(logits), i32(logits.shape[1]), ptr(gt_npcs), ptr(sem_preds), ptr(sem_labels),
+                                             ptr(_c(proposal_indices, torch.int64)), i64(logits.shape[0]), *m_rows.args(), i64(P),
+                                             ptr(sym["sym_of_class"]), ptr(sym["mats"]), first, count, group, n, ptr(scratch),
+                                             ptr(_c(grad_loss.reshape(1), torch.float32)), ptr(d_logits), _stream()), "gpn_npcs_loss_bwd_dev")
+        return d_logits
     check(_C.lib().gpn_npcs_loss_bwd(ptr(logits), i32(logits.shape[1]), ptr(gt_npcs), ptr(sem_preds), ptr(sem_labels),
                                      ptr(_c(proposal_indices, torch.int64)), i64(logits.shape[0]), i64(P), ptr(sym["sym_of_class"]),
                                      ptr(sym["mats"]), first, count, group, n, ptr(scratch),
@@ -821,19 +949,23 @@ def linear_supported(cin: int, cout: int) -> bool:
     return bool(_C.lib().gpn_linear_supported(i32(cin), i32(cout)))
 
 
-def linear_fwd(x, weight, bias):
+def linear_fwd(x, weight, bias, rows: Optional[DevCount] = None):
     """y = x @ weight.T + bias in one launch (csrc/linear.hip); weight [cout, cin] as torch.nn.Linear holds it"""
     dev = _dev(x, weight)
     x, weight = _c(x, torch.float32), _c(weight, torch.float32)
     N, cin = x.shape
     cout = weight.shape[0]
     y = torch.empty((N, cout), dtype=torch.float32, device=dev)
+    if rows is not None:  # the row count is a device counter (N = its bound)
+        check(_C.lib().gpn_linear_fwd_dev(ptr(x), ptr(weight), ptr(_c(bias, torch.float32) if bias is not None else None), i64(N),
+                                          *rows.args(), i32(cin), i32(cout), ptr(y), _stream()), "gpn_linear_fwd_dev")
+        return y
     check(_C.lib().gpn_linear_fwd(ptr(x), ptr(weight), ptr(_c(bias, torch.float32) if bias is not None else None), i64(N),
                                   i32(cin), i32(cout), ptr(y), _stream()), "gpn_linear_fwd")
     return y
 
 
-def linear_bwd(x, weight, dy, need_dx: bool, need_dw: bool, need_db: bool):
+def linear_bwd(x, weight, dy, need_dx: bool, need_dw: bool, need_db: bool, rows: Optional[DevCount] = None):
     """-> (dx or None, dW or None, db or None): three launches at most (dx; partial dW / db per 512 rows; their ordered sum)"""
     dev = _dev(x, dy)
     x, weight, dy = _c(x, torch.float32), _c(weight, torch.float32), _c(dy, torch.float32)
@@ -844,12 +976,16 @@ def linear_bwd(x, weight, dy, need_dx: bool, need_dw: bool, need_db: bool):
     db = torch.empty((cout,), dtype=torch.float32, device=dev) if need_db else None
     L = _C.lib()
     ws = _ws(L.gpn_linear_bwd_ws_bytes(i64(N), i32(cin), i32(cout)), dev) if (need_dw or need_db) else None
+    if rows is not None:
+        check(L.gpn_linear_bwd_dev(ptr(x), ptr(weight), ptr(dy), i64(N), *rows.args(), i32(cin), i32(cout), ptr(dx), ptr(dw), ptr(db),
+                                   ptr(ws), szt(ws.numel() if ws is not None else 0), _stream()), "gpn_linear_bwd_dev")
+        return dx, dw, db
     check(L.gpn_linear_bwd(ptr(x), ptr(weight), ptr(dy), i64(N), i32(cin), i32(cout), ptr(dx), ptr(dw), ptr(db), ptr(ws),
                            szt(ws.numel() if ws is not None else 0), _stream()), "gpn_linear_bwd")
     return dx, dw, db
 
 
-def score_loss(logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh):
+def score_loss(logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh, rows: Optional[DevCount] = None):
     """-> (loss [1] f32, score_preds [P] f32, d_logits [P, C1] f32) in one launch (gpn_score_loss)"""
     dev = _dev(logits, ious)
     logits, ious = _c(logits, torch.float32), _c(ious, torch.float32)
@@ -861,6 +997,11 @@ def score_loss(logits, cls_source, proposal_offsets, ious, fg_thresh, bg_thresh)
     preds = torch.empty((P,), dtype=torch.float32, device=dev)
     d_logits = torch.empty_like(logits)
     is64 = cls_source.dtype == torch.int64
+    if rows is not None:  # the proposal count is a device counter (P = its bound; rows past it stay unwritten and unread)
+        check(_C.lib().gpn_score_loss_dev(ptr(logits), i32(C1), ptr(cls_source if is64 else None), ptr(None if is64 else cls_source),
+                                          ptr(po), ptr(ious), i32(ious.shape[1]), i64(P), rows.ptr, f32(fg_thresh), f32(bg_thresh),
+                                          ptr(loss), ptr(preds), ptr(d_logits), _stream()), "gpn_score_loss_dev")
+        return loss, preds, d_logits
     check(_C.lib().gpn_score_loss(ptr(logits), i32(C1), ptr(cls_source if is64 else None), ptr(None if is64 else cls_source),
                                   ptr(po), ptr(ious), i32(ious.shape[1]), i64(P), f32(fg_thresh), f32(bg_thresh), ptr(loss),
                                   ptr(preds), ptr(d_logits), _stream()), "gpn_score_loss")

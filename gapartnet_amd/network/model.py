@@ -94,6 +94,14 @@ class GAPartNet(LightningModule):
         self.revoxelize_jitter = None  # tests inject the two uniform 3-vectors of segmented_voxelize here
         self.record_npcs_preds = False  # True: keep proposals.npcs_preds / gt_npcs in training steps too (costs a host read)
         self.use_fused_proposals = True  # csrc/proposals.hip on the GPU; False = the torch formulation of the same stage
+        # Training steps issue the proposal stage and everything behind it WITHOUT reading its sizes back (include/gpn.h section
+        # DEV): buffers at their bounds, counts on the device, the previous step's counts (copied to pinned memory, taken over
+        # without waiting) as the plan that sizes grids.  The first step of a run - no plan yet - and evaluation steps read the
+        # counts as before.  GPN_PROPOSALS_SYNC=1 (or the attribute) restores the blocking read for every step.
+        self.sync_free_proposals = os.environ.get("GPN_PROPOSALS_SYNC", "0") != "1"
+        self._prop_plan = None       # [Q, M, P, V, dropped, runs, coarse] of the latest step whose counts have arrived
+        self._prop_pending = []      # (pinned int64 [8], event) of counts still on their way
+        self._prop_pinned = []       # pinned buffers ready for reuse
 
         self.ball_query_radius = instance_seg_cfg["ball_query_radius"]
         self.max_num_points_per_query = instance_seg_cfg["max_num_points_per_query"]
@@ -273,14 +281,25 @@ class GAPartNet(LightningModule):
             rng_before = (gen, gen.get_state())
             jitter = (torch.rand(3, dtype=torch.float32, device=pt_xyz.device),
                       torch.rand(3, dtype=torch.float32, device=pt_xyz.device))
+        sync_free = self.training and self.sync_free_proposals and not self.record_npcs_preds and torch.is_grad_enabled()
+        if sync_free:
+            self._take_over_proposal_counts()
+            sync_free = self._prop_plan is not None
         built = ops.proposals_build(pt_xyz, offset_preds, sem_preds, instance_labels, batch_indices, batch_size,
                                     self.ball_query_radius, self.max_num_points_per_query,
                                     self.max_num_points_per_query_shift, self.min_num_points_per_proposal,
-                                    float(self.score_fullscale), float(self.score_scale), jitter)
+                                    float(self.score_fullscale), float(self.score_scale), jitter, read_counts=not sync_free)
+        if sync_free:
+            return self._proposals_without_a_read(pt_features, built)
         if built is None:
+            if self.training and self.sync_free_proposals:
+                self._prop_plan = [0] * 7  # (a step without proposals is a plan too: the next one need not wait for its counts)
             if rng_before is not None:
                 rng_before[0].set_state(rng_before[1])
             return None, None, None
+        if self.training and self.sync_free_proposals:
+            Q, M, P, V, dropped, coarse = built["counts_host"]
+            self._prop_plan = [Q, M, P, V, dropped, 0, coarse]
         if built["dropped"] != 0:
             raise RuntimeError("re-voxelisation dropped points: a proposal left its score_fullscale^3 grid "
                                "(the reference stops in pdb here, model.py:328-330)")
@@ -295,6 +314,47 @@ class GAPartNet(LightningModule):
                               proposal_offsets=built["proposal_offsets"], proposal_indices=built["proposal_indices"],
                               num_points_per_proposal=built["sizes"], sem_preds=built["sem_preds"],
                               instance_labels=built["instance_labels"])
+        return voxel_tensor, built["pc_voxel_id"], proposals
+
+    def _take_over_proposal_counts(self, wait: bool = False):
+        """counts of earlier steps whose copy to pinned memory has completed become the plan (never waits unless asked to)"""
+        pend = self._prop_pending
+        while pend and (wait or pend[0][1].query()):
+            host, ev = pend.pop(0)
+            if wait:
+                ev.synchronize()
+            counts = host.tolist()
+            self._prop_pinned.append(host)
+            if counts[4] != 0:
+                raise RuntimeError("re-voxelisation dropped points in an earlier training step: a proposal left its "
+                                   "score_fullscale^3 grid (the reference stops in pdb there, model.py:328-330)")
+            self._prop_plan = counts[:7]
+
+    def _proposals_without_a_read(self, pt_features, built):
+        """the outputs of gpn_proposals_build as they are - every tensor at its bound, the counts as device counters - for a
+        training step that never learns the sizes on the host (include/gpn.h section DEV)"""
+        from ..hip_ops import DevCount
+        counts = built["counts"]
+        host = self._prop_pinned.pop() if self._prop_pinned else torch.empty((8,), dtype=torch.int64).pin_memory()
+        host.copy_(counts, non_blocking=True)  # arrives some time during this step; read by a later one
+        ev = torch.cuda.Event()
+        ev.record()
+        self._prop_pending.append((host, ev))
+        plan = self._prop_plan
+        dev = dict(M=DevCount(built["M_dev"], max(plan[1], 1)), P=DevCount(built["P_dev"], max(plan[2], 1)),
+                   V=DevCount(built["V_dev"], max(plan[3], 1)))
+        voxel_features = GF.proposal_voxel_mean(pt_features, built, rows=dev["V"])
+        voxel_tensor = spconv.SparseConvTensor(voxel_features, built["voxel_coords"],
+                                               spatial_shape=[self.score_fullscale] * 3, batch_size=built["P"])
+        voxel_tensor.rows_dev, voxel_tensor.batch_dev = dev["V"], dev["P"]
+        voxel_tensor.level_plans = [max(plan[6], 1)]
+        voxel_tensor.point_csr = (built["point_order"], built["voxel_point_start"])
+        proposals = Instances(valid_mask=built["valid_mask"], valid_indices=built["valid_indices"],
+                              sorted_indices=built["sorted_indices"], point_indices=built["point_indices"],
+                              pt_xyz=built["pt_xyz"], batch_indices=built["batch_indices"],
+                              proposal_offsets=built["proposal_offsets"], proposal_indices=built["proposal_indices"],
+                              num_points_per_proposal=built["sizes"], sem_preds=built["sem_preds"],
+                              instance_labels=built["instance_labels"], dev_counts=dev)
         return voxel_tensor, built["pc_voxel_id"], proposals
 
     # ScoreNet and NPCS-Net read the same proposal grid and have the same structure: with both switched on, their U-Nets run
@@ -317,6 +377,11 @@ class GAPartNet(LightningModule):
         offsets = proposals.proposal_offsets
         if feats is None:
             feats = self.score_unet(voxel_tensor)
+        dev = proposals.dev_counts
+        if dev is not None:  # sizes on the device (no host read this step): same operators, extents as device counters
+            feats = GF.gather_rows(feats.features, pc_voxel_id, voxel_tensor.point_csr, rows=dev["M"], table_rows=dev["V"])
+            pooled, _ = GF.segmented_maxpool(feats, offsets[:-1], offsets[1:], rows=dev["P"], m_rows=dev["M"])
+            return GF.linear(pooled, self.score_head.weight, self.score_head.bias, rows=dev["P"])
         feats = GF.gather_rows(feats.features, pc_voxel_id, getattr(voxel_tensor, "point_csr", None))
         pooled, _ = segmented_maxpool(feats, offsets[:-1], offsets[1:])
         return GF.linear(pooled, self.score_head.weight, self.score_head.bias)
@@ -331,9 +396,12 @@ class GAPartNet(LightningModule):
         return F.binary_cross_entropy_with_logits(score_logits, gt_scores)
 
     def forward_proposal_npcs(self, voxel_tensor: spconv.SparseConvTensor, pc_voxel_id: torch.Tensor,
-                              feats: Optional[spconv.SparseConvTensor] = None) -> torch.Tensor:
+                              feats: Optional[spconv.SparseConvTensor] = None, dev: Optional[dict] = None) -> torch.Tensor:
         if feats is None:
             feats = self.npcs_unet(voxel_tensor)
+        if dev is not None:
+            logits = GF.linear(feats.features, self.npcs_head.weight, self.npcs_head.bias, rows=dev["V"])
+            return GF.gather_rows(logits, pc_voxel_id, voxel_tensor.point_csr, rows=dev["M"], table_rows=dev["V"])
         logits = GF.linear(feats.features, self.npcs_head.weight, self.npcs_head.bias)
         return GF.gather_rows(logits, pc_voxel_id, getattr(voxel_tensor, "point_csr", None))
 
@@ -341,9 +409,11 @@ class GAPartNet(LightningModule):
         """symmetry-aware NPCS loss on points whose predicted part class is right and that carry a non-zero NPCS
         target (model.py:398-462); the per-class 3-vector is selected by the predicted class."""
         sem_preds, sem_labels = proposals.sem_preds, proposals.sem_labels
-        valid = (sem_preds == sem_labels) & (gt_npcs != 0).any(dim=-1)
+        # (with the sizes on the device the rows past the live count are undefined: no host-side mask then)
+        valid = (sem_preds == sem_labels) & (gt_npcs != 0).any(dim=-1) if proposals.dev_counts is None else None
         ops = backend.raw()
         fused = npcs_logits.is_cuda and hasattr(ops, "npcs_loss_fwd") and npcs_logits.shape[0] > 0
+        dev_counts = proposals.dev_counts
         proposals.npcs_valid_mask = valid
         valid_idx = None
         if fused and self.training and not self.record_npcs_preds:
@@ -378,6 +448,9 @@ class GAPartNet(LightningModule):
                            mats=torch.cat(mats).to(device=dev, dtype=torch.float32).contiguous(), first=first, count=count,
                            group=group)
                 self._npcs_sym = sym
+            if dev_counts is not None:
+                return GF.npcs_loss(npcs_logits, gt_npcs, sem_preds, sem_labels, proposals.proposal_offsets,
+                                    proposals.proposal_indices, sym, p_rows=dev_counts["P"], m_rows=dev_counts["M"])
             return GF.npcs_loss(npcs_logits, gt_npcs, sem_preds, sem_labels, proposals.proposal_offsets,
                                 proposals.proposal_indices, sym)
 
@@ -467,7 +540,11 @@ class GAPartNet(LightningModule):
                 pt_xyz=pt_xyz, batch_indices=data_batch.batch_indices, pt_features=pc_feature, sem_preds=sem_preds,
                 offset_preds=offsets_preds, instance_labels=instance_labels, batch_size=batch_size)
             if proposals is not None:
-                if sem_labels is not None:
+                if proposals.dev_counts is not None:  # the reference's sem_labels[rows] / gt_npcs[rows] for a device-counted row count
+                    want_npcs = gt_npcs is not None and self.current_epoch >= self.start_npcs
+                    proposals.sem_labels, proposals.gt_npcs = backend.raw().proposals_targets(
+                        sem_labels, gt_npcs if want_npcs else None, proposals.point_indices, proposals.dev_counts["M"])
+                elif sem_labels is not None:
                     proposals.sem_labels = sem_labels[self._proposal_rows(proposals)]
                 proposals.instance_sem_labels = data_batch.instance_sem_labels
 
@@ -483,7 +560,16 @@ class GAPartNet(LightningModule):
             cls_source = proposals.sem_labels if proposals.sem_labels is not None else proposals.sem_preds
             if num_points_per_instance is None:
                 raise RuntimeError("batch carries no num_points_per_instance (reference: pdb, model.py:567)")
-            if GF.score_loss_available(score_logits):
+            if proposals.dev_counts is not None:
+                P_dev = proposals.dev_counts["P"]
+                with torch.no_grad():
+                    ious = backend.raw().instance_iou(proposals.proposal_offsets, proposals.instance_labels, proposals.batch_indices,
+                                                      num_points_per_instance, rows=P_dev)
+                proposals.ious = ious
+                proposals.num_points_per_instance = num_points_per_instance
+                loss_prop_score, proposals.score_preds = GF.score_loss(score_logits, cls_source, proposals.proposal_offsets, ious,
+                                                                       0.75, 0.25, rows=P_dev)
+            elif GF.score_loss_available(score_logits):
                 # class selection, soft IoU targets, BCE and the sigmoid scores in one launch (csrc/losses.hip); the torch
                 # formulation below is what runs over other operator backends and what the kernel is tested against
                 ious = batch_instance_seg_iou(proposals.proposal_offsets, proposals.instance_labels, proposals.batch_indices,
@@ -501,9 +587,9 @@ class GAPartNet(LightningModule):
 
         loss_prop_npcs = 0.0
         if self.current_epoch >= self.start_npcs and voxel_tensor is not None:
-            npcs_logits = self.forward_proposal_npcs(voxel_tensor, pc_voxel_id, npcs_feats)
+            npcs_logits = self.forward_proposal_npcs(voxel_tensor, pc_voxel_id, npcs_feats, proposals.dev_counts)
             if gt_npcs is not None:
-                gt_npcs = gt_npcs[self._proposal_rows(proposals)]
+                gt_npcs = proposals.gt_npcs if proposals.dev_counts is not None else gt_npcs[self._proposal_rows(proposals)]
                 loss_prop_npcs = self.loss_proposal_npcs(npcs_logits, gt_npcs, proposals)
 
         loss = loss_sem_seg + loss_offset_dist + loss_offset_dir + loss_prop_score + loss_prop_npcs

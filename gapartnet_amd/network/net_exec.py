@@ -25,7 +25,8 @@ from .. import functional as GF
 from ..spconv import pytorch as spconv
 
 # numpy mirrors of the C structs in include/gpn.h (sizes are checked against the header in tests/test_cabi.py)
-SLOT_DT = np.dtype([("data", "<u8"), ("grad", "<u8"), ("rows", "<i8"), ("channels", "<i4"), ("grad_state", "<i4")])
+SLOT_DT = np.dtype([("data", "<u8"), ("grad", "<u8"), ("rows", "<i8"), ("channels", "<i4"), ("grad_state", "<i4"),
+                    ("rows_dev", "<u8"), ("rows_plan", "<i8")])
 RB_DT = np.dtype([("nbr", "<u8"), ("nbr_t", "<u8"), ("nbr_p", "<u8"), ("perm", "<u8"), ("nbr_t_p", "<u8"), ("perm_t", "<u8"),
                   ("pair_src", "<u8"), ("pair_dst", "<u8"), ("tile_off", "<u8"),
                   ("n_src", "<i8"), ("n_dst", "<i8"), ("K", "<i4"), ("reverse_taps", "<i4")])
@@ -200,6 +201,58 @@ class NetProgram:
         return tuple(id(m) for m in unet.modules())
 
     # ------------------------------------------------------------------ per-call state
+    def rulebooks_dev(self, x):
+        """``rulebooks`` for a tensor whose row count is a device counter (``x.rows_dev``, hip_ops.DevCount; include/gpn.h
+        section DEV): no host read anywhere - every level's buffers at the bound of level 0, the coarse levels' row counts
+        device counters of their own (plans from ``x.level_plans``).  -> (rows = the bounds, table, objs, levels, per-level
+        DevCounts)"""
+        ops = backend.raw()
+        dev_counts = [x.rows_dev]
+        levels = [(x.indices, list(x.spatial_shape))]
+        plans = list(getattr(x, "level_plans", None) or [])
+        subm, down = [], []
+        for lvl in range(self.n_levels):
+            idx, shape = levels[lvl]
+            skey, dkey = self.level_keys[lvl]
+            rb = x.indice_dict.get(skey)
+            if rb is None:
+                rb = ops.rulebook_subm3(idx, shape, rows=dev_counts[lvl])
+                x.indice_dict[skey] = rb
+            subm.append(rb)
+            if lvl + 1 < self.n_levels:
+                rec = x.indice_dict.get(dkey)
+                if rec is None:
+                    out_idx, out_shape, rb_fwd, rb_bwd, out_rows = ops.rulebook_down_dev(
+                        idx, shape, x.batch_size, dev_counts[lvl], getattr(x, "batch_dev", None),
+                        out_plan=plans[lvl] if lvl < len(plans) else 0)
+                    rec = spconv._DownRecord(idx, shape, out_idx, out_shape, rb_fwd, rb_bwd)
+                    rec.out_rows = out_rows
+                    x.indice_dict[dkey] = rec
+                down.append(rec)
+                levels.append((rec.out_indices, rec.out_shape))
+                dev_counts.append(rec.out_rows)
+        rows = np.asarray([lv[0].shape[0] for lv in levels], np.int64)
+        table = np.zeros(len(self.rb_keys), RB_DT)
+        objs = []
+        for i, (kind, lvl) in enumerate(self.rb_keys):
+            if kind == "subm":
+                rb, rb_t, rev = subm[lvl], subm[lvl], 1
+            elif kind == "down":
+                rb, rb_t, rev = down[lvl].rb_fwd, down[lvl].rb_bwd, 0
+            elif kind == "inv":
+                rb, rb_t, rev = down[lvl].rb_bwd, down[lvl].rb_fwd, 0
+            else:
+                ikey = f"__identity_dev_{lvl}__"
+                rb = x.indice_dict.get(ikey)
+                if rb is None:
+                    rb = ops.rulebook_identity(int(rows[lvl]), x.features.device, rows_dev=dev_counts[lvl])
+                    x.indice_dict[ikey] = rb
+                rb_t, rev = rb, 0
+            table[i] = (rb.nbr.data_ptr(), rb_t.nbr.data_ptr(), 0, 0, 0, 0, rb.pair_src.data_ptr(), rb.pair_dst.data_ptr(),
+                        rb.tile_off.data_ptr(), rb.n_src, rb.n_dst, rb.K, rev)
+            objs.append((rb, rb_t))
+        return rows, table, objs, levels, dev_counts
+
     def rulebooks(self, x):
         """fetch / build the rulebook of every level through the tensor's indice_dict (same keys as the modules)"""
         ops = backend.raw()
@@ -440,8 +493,9 @@ def _call_pair(fn_name, prog, slots_a, slots_b, rb_table, conv_a, conv_b, bn_a, 
         raise _C.GpnError(f"{fn_name} failed: {L.gpn_last_error().decode('utf-8', 'replace')}")
 
 
-def _forward_tables(features, prog: NetProgram, rows):
-    """activation arena, slot / weight / BatchNorm tables of one forward pass of ``prog`` over ``features``"""
+def _forward_tables(features, prog: NetProgram, rows, lvl_dev=None):
+    """activation arena, slot / weight / BatchNorm tables of one forward pass of ``prog`` over ``features``; ``lvl_dev``: per
+    level a hip_ops.DevCount when the row counts are device counters (``rows`` then holds the bounds)"""
     params = prog.params()
     dev = features.device
     n_slots = len(prog.slot_level)
@@ -456,6 +510,9 @@ def _forward_tables(features, prog: NetProgram, rows):
     slots["data"][0] = features.data_ptr()
     slots["rows"] = slot_rows
     slots["channels"] = prog.slot_channels_np
+    if lvl_dev is not None:
+        slots["rows_dev"] = np.asarray([c.t.data_ptr() for c in lvl_dev], np.uint64)[prog.slot_level_np]
+        slots["rows_plan"] = np.asarray([c.plan for c in lvl_dev], np.int64)[prog.slot_level_np]
     total_c = int(prog.bn_off[-1])
     stats = torch.empty((2, total_c), dtype=torch.float32, device=dev)
     conv_table, bn_table = prog.static_tables(params)
@@ -474,9 +531,9 @@ def _log_forward(prog, rb_objs):
 
 
 def _forward_impl(ctx, features, prog: NetProgram, rt, training):
-    rows, rb_table, rb_objs = rt
+    rows, rb_table, rb_objs, lvl_dev = rt
     features = features.contiguous()
-    out, state = _forward_tables(features, prog, rows)
+    out, state = _forward_tables(features, prog, rows, lvl_dev)
     _call("gpn_net_forward", prog, state[3], rb_table, state[4], state[5], (1 if training else 0,), features.device)
     _log_forward(prog, rb_objs)
     ctx.prog, ctx.rt, ctx.training = prog, rt, training
@@ -526,7 +583,7 @@ def _log_backward(prog, rb_objs, need_in):
 def _backward_impl(ctx, dout, fresh: bool, need_in: bool):
     """runs gpn_net_backward; -> (din or None, flat parameter-gradient buffer, its per-parameter views, params)"""
     prog = ctx.prog
-    rows, rb_table, rb_objs = ctx.rt
+    rows, rb_table, rb_objs, _lvl_dev = ctx.rt
     features, params = ctx.state[0], ctx.state[-1]
     dout = dout.contiguous()
     garena, slots, conv_table, bn_table, pgrad, views = _backward_tables(prog, ctx.state, dout, fresh)
@@ -589,10 +646,10 @@ class _NetPairFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, features, anchor, prog_a: NetProgram, prog_b: NetProgram, rt, training):
-        rows, rb_table, rb_objs = rt
+        rows, rb_table, rb_objs, lvl_dev = rt
         features = features.contiguous()
-        out_a, state_a = _forward_tables(features, prog_a, rows)
-        out_b, state_b = _forward_tables(features, prog_b, rows)
+        out_a, state_a = _forward_tables(features, prog_a, rows, lvl_dev)
+        out_b, state_b = _forward_tables(features, prog_b, rows, lvl_dev)
         _call_pair("gpn_net_forward_pair", prog_a, state_a[3], state_b[3], rb_table, state_a[4], state_b[4], state_a[5],
                    state_b[5], (1 if training else 0,), features.device)
         _log_forward(prog_a, rb_objs)
@@ -604,7 +661,7 @@ class _NetPairFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout_a, dout_b):
-        rows, rb_table, rb_objs = ctx.rt
+        rows, rb_table, rb_objs, _lvl_dev = ctx.rt
         need_in = bool(ctx.needs_input_grad[0])
         features = ctx.states[0][0]
         dev = features.device
@@ -678,6 +735,26 @@ def invalidate(unet):
     unet.__dict__.pop("_net_program", None)
 
 
+def _count_batches(buffers, x):
+    """num_batches_tracked += 1 of a training-mode pass; with a device-counted row count only if any row exists (the reference
+    does not run the network at all for a step without proposals: its counters stay)"""
+    rows_dev = getattr(x, "rows_dev", None)
+    if rows_dev is None:
+        torch._foreach_add_(buffers, 1)
+    else:
+        # (list-list form: the tensor-scalar overload of _foreach_add_ reads its scalar on the host - a blocking sync)
+        inc = (rows_dev.t[0] > 0).to(torch.int64)
+        torch._foreach_add_(buffers, [inc] * len(buffers))
+
+
+def _out_tensor(out, idx, shape, x, rows_dev):
+    t = spconv.SparseConvTensor(out, idx, shape, x.batch_size, x.indice_dict)
+    if rows_dev is not None:
+        t.rows_dev = rows_dev
+        t.batch_dev = getattr(x, "batch_dev", None)
+    return t
+
+
 def run(unet, x):
     """SparseUNet.forward through the native executor; returns None when the per-layer path must be used."""
     prog = program_for(unet)
@@ -692,20 +769,24 @@ def run(unet, x):
         x = prog.python_stem_conv(x)
         if known is not None:
             x.level_counts = known  # same voxel set: the coarse levels' row counts that came with the voxelisation's read
-    rows, rb_table, rb_objs, levels = prog.rulebooks(x)
+    lvl_dev = None
+    if getattr(x, "rows_dev", None) is not None:
+        rows, rb_table, rb_objs, levels, lvl_dev = prog.rulebooks_dev(x)
+    else:
+        rows, rb_table, rb_objs, levels = prog.rulebooks(x)
     if int(rows.min()) < 1 or x.features.shape[1] != prog.slot_channels[0]:
         return None
     if training:
         with torch.no_grad():
-            torch._foreach_add_(prog.buffers("num_batches_tracked"), 1)
+            _count_batches(prog.buffers("num_batches_tracked"), x)
     params = prog.params()
     if _AUTOGRAD_PARAMS or any(_has_hooks(p) for p in params):
-        out = _NetFnAutograd.apply(x.features, prog, (rows, rb_table, rb_objs), training, *params)
+        out = _NetFnAutograd.apply(x.features, prog, (rows, rb_table, rb_objs, lvl_dev), training, *params)
     else:
-        out = _NetFn.apply(x.features, prog._anchor, prog, (rows, rb_table, rb_objs), training)
+        out = _NetFn.apply(x.features, prog._anchor, prog, (rows, rb_table, rb_objs, lvl_dev), training)
     lvl = prog.slot_level[prog.out_slot]
     idx, shape = levels[lvl]
-    return spconv.SparseConvTensor(out, idx, shape, x.batch_size, x.indice_dict)
+    return _out_tensor(out, idx, shape, x, lvl_dev[lvl] if lvl_dev is not None else None)
 
 
 def run_pair(unet_a, unet_b, x):
@@ -728,14 +809,18 @@ def run_pair(unet_a, unet_b, x):
     params = prog_a.params() + prog_b.params()
     if any(_has_hooks(p) for p in params):
         return None
-    rows, rb_table, rb_objs, levels = prog_a.rulebooks(x)
+    lvl_dev = None
+    if getattr(x, "rows_dev", None) is not None:
+        rows, rb_table, rb_objs, levels, lvl_dev = prog_a.rulebooks_dev(x)
+    else:
+        rows, rb_table, rb_objs, levels = prog_a.rulebooks(x)
     if int(rows.min()) < 1 or x.features.shape[1] != prog_a.slot_channels[0]:
         return None
     if training:
         with torch.no_grad():
-            torch._foreach_add_(prog_a.buffers("num_batches_tracked") + prog_b.buffers("num_batches_tracked"), 1)
-    out_a, out_b = _NetPairFn.apply(x.features, prog_a._anchor, prog_a, prog_b, (rows, rb_table, rb_objs), training)
+            _count_batches(prog_a.buffers("num_batches_tracked") + prog_b.buffers("num_batches_tracked"), x)
+    out_a, out_b = _NetPairFn.apply(x.features, prog_a._anchor, prog_a, prog_b, (rows, rb_table, rb_objs, lvl_dev), training)
     lvl = prog_a.slot_level[prog_a.out_slot]
     idx, shape = levels[lvl]
-    return (spconv.SparseConvTensor(out_a, idx, shape, x.batch_size, x.indice_dict),
-            spconv.SparseConvTensor(out_b, idx, shape, x.batch_size, x.indice_dict))
+    d = lvl_dev[lvl] if lvl_dev is not None else None
+    return _out_tensor(out_a, idx, shape, x, d), _out_tensor(out_b, idx, shape, x, d)

@@ -44,6 +44,12 @@ class SparseConvTensor:
         self.spatial_shape = [int(s) for s in spatial_shape]
         self.batch_size = int(batch_size)
         self.indice_dict = indice_dict if indice_dict is not None else {}
+        # not part of spconv's API: a tensor whose live row count (and number of batch entries) is still on the device
+        # (hip_ops.DevCount; include/gpn.h section DEV) - features / indices then have the rows of a BOUND, batch_size is a
+        # bound, and level_plans carries the host's estimates of the coarse levels' row counts.  None: ordinary tensor.
+        self.rows_dev = None
+        self.batch_dev = None
+        self.level_plans = None
 
     @property
     def features(self) -> torch.Tensor:
@@ -54,7 +60,9 @@ class SparseConvTensor:
         raise ValueError("assign features through replace_feature(), as spconv >= 2.1 requires")
 
     def replace_feature(self, feature: torch.Tensor) -> "SparseConvTensor":
-        return SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size, self.indice_dict)
+        out = SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size, self.indice_dict)
+        out.rows_dev, out.batch_dev, out.level_plans = self.rows_dev, self.batch_dev, self.level_plans
+        return out
 
     def find_indice_pair(self, key):
         return None if key is None else self.indice_dict.get(key)

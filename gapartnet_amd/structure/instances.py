@@ -34,6 +34,9 @@ class Instances:
     cls_preds: Optional[torch.Tensor] = None
     cls_labels: Optional[torch.Tensor] = None
     name: Optional[str] = None
+    # not a reference field: {"M", "P", "V"} -> hip_ops.DevCount when the proposal stage ran without a host read - every tensor
+    # above then has the rows of a bound and only the first *count rows are defined (training steps only)
+    dev_counts: Optional[dict] = None
 
 
 @dataclass

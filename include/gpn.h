@@ -263,6 +263,15 @@ typedef struct gpn_net_slot {
   int64_t rows;
   int32_t channels;
   int32_t grad_state;
+  /* Row counts that are still on the device (round 4: a pass issued without a host read of its sizes).  rows_dev != NULL:
+   * `rows` is the BOUND the buffers (and the rulebook tables) are allocated for and *rows_dev the live row count, written by an
+   * earlier launch on the same stream; every kernel of the pass reads it and walks its rows with a grid stride, so no result
+   * depends on the host's knowledge.  rows_plan (> 0) is the host's ESTIMATE of that count (e.g. the previous step's): it only
+   * sizes grids and picks kernel variants.  Tables of such a pass use the LIVE count as their leading dimension (nbr is
+   * [K][*rows_dev], tile_off [K][ceil(*rows_dev / 32) + 1]) - exactly the layout of an exactly-sized pass, in larger buffers.
+   * rows_dev == NULL: `rows` is the exact count (rows_plan ignored). */
+  const int64_t* rows_dev;
+  int64_t rows_plan;
 } gpn_net_slot_t;
 typedef struct gpn_net_rulebook {
   const int32_t* nbr;   /* [K][n_dst]  forward table */
@@ -551,6 +560,63 @@ int gpn_pose_fit(const double* xyz, const double* npcs, const int64_t* offsets, 
                  int H, double stop_thrsh, uint8_t* valid, double* scale, double* rotation, double* translation,
                  double* transform, double* bbox, uint8_t* inlier_mask, int64_t* best_iteration, double* residual, void* ws,
                  size_t ws_bytes, gpn_stream_t stream);
+
+/* ================================================================================================
+ * DEV - entry points whose extents are DEVICE COUNTERS (round 4: the proposal stage of a training step without a host read;
+ * reference glue: network/model.py:228-346, 348-462 - there every stage boundary is a device->host read of a size).
+ * Convention of every *_dev entry point: an extent argument (N, P, M, V ...) is the BOUND its buffers are allocated for;
+ * `<x>_dev` points at an int64 on the device holding the live value (written by an earlier launch on the stream, e.g.
+ * gpn_proposals_build's counts) and `<x>_plan` is the host's estimate of it (<= 0: none) that only sizes the grid.  Kernels read
+ * the counter and walk their work with a grid stride, so results never depend on the estimate; tables are laid out for the LIVE
+ * count (see gpn_net_slot_t).  Each computes exactly what its exactly-sized twin computes on the first *<x>_dev rows.
+ * ================================================================================================ */
+int gpn_rulebook_subm3_dev(const int32_t* indices, int64_t N, const int64_t* n_dev, int64_t n_plan,
+                           const int32_t* spatial_shape_host, int32_t* nbr, int32_t* pair_src, int32_t* pair_dst,
+                           int32_t* tile_off, int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream);
+size_t gpn_rulebook_down_dev_ws_bytes(int64_t N, int64_t batch_size, const int32_t* spatial_shape_host);
+int gpn_rulebook_down_dev(const int32_t* indices, int64_t N, const int64_t* n_dev, int64_t n_plan, int64_t batch_size,
+                          const int64_t* batch_dev, int64_t batch_plan, const int32_t* spatial_shape_host, int32_t* out_indices,
+                          int32_t* fine_to_coarse, int32_t* tap, int64_t* num_out, void* ws, size_t ws_bytes, gpn_stream_t stream);
+int gpn_rulebook_down_lists_dev(const int32_t* fine_to_coarse, const int32_t* tap, int64_t N, const int64_t* n_dev, int64_t n_plan,
+                                int64_t n_out, const int64_t* n_out_dev, int64_t n_out_plan, int32_t* fwd_nbr, int32_t* fwd_src,
+                                int32_t* fwd_dst, int32_t* fwd_tile_off, int32_t* bwd_nbr, int32_t* bwd_src, int32_t* bwd_dst,
+                                int32_t* bwd_tile_off, int64_t* num_pairs, void* ws, size_t ws_bytes, gpn_stream_t stream);
+int gpn_rulebook_identity_dev(int64_t n, const int64_t* n_dev, int64_t n_plan, int32_t* rows, int32_t* tile_off, int32_t* nbr,
+                              int64_t* num_pairs, gpn_stream_t stream);
+int gpn_gather_rows_dev(const float* table, const int32_t* idx, int64_t n, const int64_t* n_dev, int64_t n_plan, int C, float* out,
+                        gpn_stream_t stream);
+int gpn_scatter_rows_csr_dev(const float* dout, const int32_t* order, const int32_t* starts, int64_t n_rows, const int64_t* n_dev,
+                             int64_t n_plan, int C, float* dtable, gpn_stream_t stream);
+int gpn_proposals_voxel_mean_dev(const float* feats, const int64_t* point_indices, const int32_t* point_order,
+                                 const int32_t* voxel_point_start, int64_t V, const int64_t* v_dev, int64_t v_plan, int C, float* out,
+                                 gpn_stream_t stream);
+/* sem_labels [N] i64 / gt_npcs [N,3] f32 (either may be NULL) at the proposal points: the reference's sem_labels[rows],
+ * gt_npcs[rows] (model.py:556-571) for the first *m_dev of M rows */
+int gpn_proposals_targets_dev(const int64_t* sem_labels, const float* gt_npcs, const int64_t* point_indices, int64_t M,
+                              const int64_t* m_dev, int64_t m_plan, int64_t* sem_out, float* npcs_out, gpn_stream_t stream);
+int gpn_linear_fwd_dev(const float* x, const float* W, const float* b, int64_t N, const int64_t* n_dev, int64_t n_plan, int cin,
+                       int cout, float* y, gpn_stream_t stream);
+int gpn_linear_bwd_dev(const float* x, const float* W, const float* dy, int64_t N, const int64_t* n_dev, int64_t n_plan, int cin,
+                       int cout, float* dx, float* dW, float* db, void* ws, size_t ws_bytes, gpn_stream_t stream);
+int gpn_segmented_maxpool_fwd_dev(const float* values, const int32_t* begin, const int32_t* end, int64_t P, const int64_t* p_dev,
+                                  int64_t p_plan, int C, float* pooled, int32_t* argmax, gpn_stream_t stream);
+int gpn_segmented_maxpool_bwd_dev(const float* dpooled, const int32_t* argmax, int64_t P, const int64_t* p_dev, int64_t p_plan, int C,
+                                  int64_t M, const int64_t* m_dev, int64_t m_plan, float* dvalues, gpn_stream_t stream);
+int gpn_instance_iou_dev(const int32_t* proposal_offsets, const int32_t* instance_labels, const int32_t* batch_indices,
+                         const int32_t* num_points_per_instance, int64_t P, const int64_t* p_dev, int64_t p_plan, int64_t B, int I,
+                         float* ious, gpn_stream_t stream);
+int gpn_score_loss_dev(const float* logits, int C1, const int64_t* cls_i64, const int32_t* cls_i32, const int32_t* offsets,
+                       const float* ious, int I, int64_t P, const int64_t* p_dev, float fg_thresh, float bg_thresh, float* loss,
+                       float* score_preds, float* d_logits, gpn_stream_t stream);
+int gpn_npcs_loss_fwd_dev(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds, const int64_t* sem_labels,
+                          const int32_t* proposal_offsets, int64_t P, const int64_t* p_dev, int64_t p_plan,
+                          const int64_t* sym_of_class, const float* mats, const int32_t* type_first, const int32_t* type_count,
+                          const int32_t* type_group, int n_types, float* loss, void* scratch, gpn_stream_t stream);
+int gpn_npcs_loss_bwd_dev(const float* logits, int n_cls3, const float* gt_npcs, const int32_t* sem_preds, const int64_t* sem_labels,
+                          const int64_t* proposal_indices, int64_t M, const int64_t* m_dev, int64_t m_plan, int64_t P,
+                          const int64_t* sym_of_class, const float* mats, const int32_t* type_first, const int32_t* type_count,
+                          const int32_t* type_group, int n_types, const void* scratch, const float* grad_loss, float* d_logits,
+                          gpn_stream_t stream);
 
 #ifdef __cplusplus
 }

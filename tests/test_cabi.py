@@ -92,7 +92,7 @@ def test_executor_struct_layouts_match_the_header(tmp_path):
     from gapartnet_amd.network import net_exec as NX
     src = tmp_path / "sizes.c"
     fields = {
-        "gpn_net_slot_t": (NX.SLOT_DT, ["data", "grad", "rows", "channels", "grad_state"]),
+        "gpn_net_slot_t": (NX.SLOT_DT, ["data", "grad", "rows", "channels", "grad_state", "rows_dev", "rows_plan"]),
         "gpn_net_rulebook_t": (NX.RB_DT, ["nbr", "nbr_t", "nbr_p", "perm", "nbr_t_p", "perm_t", "pair_src", "pair_dst",
                                           "tile_off", "n_src", "n_dst", "K", "reverse_taps"]),
         "gpn_net_conv_t": (NX.CONV_DT, ["W", "dW", "cin", "cout"]),
