@@ -15,9 +15,17 @@ from typing import Iterable, Optional
 
 import torch
 
-from ..structure.point_cloud import PointCloud, PointCloudBatch
+from ..structure.point_cloud import PointCloud, PointCloudBatch, finish_voxels
 
 
+import os
+
+# GPN_PREFETCH_DEFER=1: the voxelisation of batch i + 2 is queued one step before its sizes are read, so that the read never
+# waits (hip_ops.voxelize_scenes_begin / _finish).  Measured (round 4, four interleaved same-box pairs): the wait of 0.54 ms per
+# step is gone from the host (tools/host_wait.py: 0 ms) and the step is SLOWER, 8.10 -> 8.44 ms, every pair - the host is the
+# critical resource of the step now and the wait was the moment the GPU caught up with it; the earlier start of the batch
+# preparation kernels beside the backbone costs more than the wait did.  Default off; kept as a switch.
+_DEFER_VOXELS = os.environ.get("GPN_PREFETCH_DEFER", "0") == "1"
 _LEAF_TYPES = (str, bytes, int, float, bool, type(None))
 
 
@@ -59,7 +67,9 @@ class DevicePrefetcher:
         self.stream = torch.cuda.Stream(device=device)
         self._consumer_mark = None
 
-    def _prepare(self, raw):
+    def _begin(self, raw):
+        """first half of a batch's preparation, on the side stream: collate and QUEUE the voxelisation - its sizes are not read
+        here.  -> (batch still without its voxel part, or the finished batch when nothing could be deferred)"""
         if raw is None:
             return None
         with torch.cuda.stream(self.stream):
@@ -67,19 +77,30 @@ class DevicePrefetcher:
                 # Everything this stream allocates from here on may reuse blocks of batches the training stream has
                 # finished with: wait for the point of the training stream up to which that is true (see __iter__).
                 self.stream.wait_event(self._consumer_mark)
-            backbone = getattr(self.model, "backbone", None)
             if isinstance(raw, PointCloudBatch):
-                batch = raw
-            else:
-                pcs = [pc.to(self.device) if hasattr(pc, "to") else pc for pc in raw]
-                raw_scenes = pcs[0].num_instances is None and pcs[0].instance_labels is not None
-                levels = 0  # the backbone's coarse levels: their row counts come back with the voxelisation's one host read
-                if backbone is not None and getattr(backbone, "use_native_executor", False):
-                    from ..network import net_exec
-                    prog = net_exec.program_for(backbone)
-                    levels = prog.n_levels - 1 if prog is not None and prog.n_levels > 2 else 0
-                batch = PointCloud.collate(pcs, voxel_size=self.model.voxel_size,
-                                           augmentation=self.augmentation if raw_scenes else None, pyramid_levels=levels)
+                return raw
+            backbone = getattr(self.model, "backbone", None)
+            pcs = [pc.to(self.device) if hasattr(pc, "to") else pc for pc in raw]
+            raw_scenes = pcs[0].num_instances is None and pcs[0].instance_labels is not None
+            levels = 0  # the backbone's coarse levels: their row counts come back with the voxelisation's one host read
+            if backbone is not None and getattr(backbone, "use_native_executor", False):
+                from ..network import net_exec
+                prog = net_exec.program_for(backbone)
+                levels = prog.n_levels - 1 if prog is not None and prog.n_levels > 2 else 0
+            return PointCloud.collate(pcs, voxel_size=self.model.voxel_size,
+                                      augmentation=self.augmentation if raw_scenes else None, pyramid_levels=levels,
+                                      defer_voxels=_DEFER_VOXELS)
+
+    def _finish(self, batch):
+        """second half, one step later: the read of the voxelisation's sizes (its kernels ran long ago: no wait), the voxel
+        tensor, the backbone's rulebooks.  -> (batch, event the consumer waits for)"""
+        if batch is None:
+            return None
+        with torch.cuda.stream(self.stream):
+            if self._consumer_mark is not None:
+                self.stream.wait_event(self._consumer_mark)
+            batch = finish_voxels(batch)
+            backbone = getattr(self.model, "backbone", None)
             if backbone is not None and getattr(backbone, "use_native_executor", False) and batch.voxel_tensor is not None:
                 from ..network import net_exec
                 prog = net_exec.program_for(backbone)
@@ -91,11 +112,12 @@ class DevicePrefetcher:
 
     def _prepare_pending(self):
         """called by the model in the middle of its step (GAPartNet._prefetch_hook): after the backbone and the point heads
-        have been launched and before the clustering code reads back from the device - the host would otherwise sit in
-        that read while the GPU works through the backbone"""
+        have been launched and before the clustering code.  Finishes the NEXT batch (whose voxelisation was queued a step ago)
+        and queues the voxelisation of the one after it."""
         if self._has_pending:
             self._has_pending = False
-            self._ahead = self._prepare(self._pending)
+            self._ahead = self._finish(self._begun)
+            self._begun = self._begin(self._pending)
             self._pending = None
 
     def _mark_consumer(self):
@@ -106,13 +128,14 @@ class DevicePrefetcher:
 
     def __iter__(self):
         it = iter(self.batches)
-        # Invariant of the ordering scheme below: a batch may be used by the training stream until the next-but-one batch is
-        # handed out.  A (re-)started iteration has no such history: the last batches of a previous pass over this object
-        # (or anything else the consumer still has in flight) may still be read by kernels enqueued AFTER the last mark,
-        # and their blocks are free for the side stream to reuse once `_held` was dropped - so the first preparation
-        # waits for the training stream as it stands now.
+        # Invariant of the ordering scheme below: a batch may be used by the training stream until the third batch after it is
+        # handed out (two are in preparation at any time: one finished, one with its voxelisation queued).  A (re-)started
+        # iteration has no such history: the last batches of a previous pass over this object (or anything else the consumer
+        # still has in flight) may still be read by kernels enqueued AFTER the last mark, and their blocks are free for the side
+        # stream to reuse once `_held` was dropped - so the first preparation waits for the training stream as it stands now.
         self._mark_consumer()
-        self._ahead = self._prepare(next(it, None))
+        self._ahead = self._finish(self._begin(next(it, None)))
+        self._begun = self._begin(next(it, None))
         self._pending, self._has_pending = None, False
         hook_owner = self.model if hasattr(self.model, "_prefetch_hook") else None
         try:
@@ -144,5 +167,6 @@ class DevicePrefetcher:
             except Exception:  # interpreter teardown: no device left to order against
                 self._consumer_mark = None
             self._held = (None, None)
+            self._begun = None
             if hook_owner is not None:
                 hook_owner.__dict__["_prefetch_hook"] = None  # plain attribute; safe at interpreter teardown too

@@ -142,11 +142,13 @@ def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_siz
     return out
 
 
-def voxelize_scenes(points, feats, seg_offsets, voxel_size, n_levels=0):
-    """Scene-batch voxelisation with the reference's per-scene ranges and NO host read before or between the launches
-    (gpn_voxelize_scenes).  -> (voxel_feats [V,C], indices [V,4] i32 = (scene,x,y,z), pc_voxel_id [M] i32, point_order [M],
-    voxel_point_start [V+1], max_coord [3 ints], dropped, level_counts [n_levels ints]) after ONE host read, or None when
-    a cell index did not fit the packed keys (>= 1024 cells along an axis: the caller takes voxelize() instead)."""
+_PINNED_STATS = []  # pinned int64 buffers of finished voxelize_scenes_begin / _finish pairs, for reuse
+
+
+def voxelize_scenes_begin(points, feats, seg_offsets, voxel_size, n_levels=0):
+    """first half of ``voxelize_scenes``: every launch of gpn_voxelize_scenes plus an asynchronous copy of its statistics to
+    pinned memory - NO host read.  ``voxelize_scenes_finish(handle)`` is the second half; issued a step later (the device
+    prefetcher does: dataset/prefetch.py) it finds the statistics there and does not wait."""
     dev = _dev(points, feats, seg_offsets)
     points, feats = _c(points, torch.float32), _c(feats, torch.float32)
     seg_offsets = _c(seg_offsets, torch.int64)
@@ -162,11 +164,38 @@ def voxelize_scenes(points, feats, seg_offsets, voxel_size, n_levels=0):
     check(L.gpn_voxelize_scenes(ptr(points), ptr(feats), ptr(seg_offsets), i64(M), i32(C), i64(S), host_f32x3(voxel_size),
                                 i32(n_levels), ptr(vf), ptr(idx4), ptr(pid), ptr(order), ptr(vstart), ptr(stats), ptr(ws),
                                 szt(ws.numel()), _stream()), "gpn_voxelize_scenes")
-    st = stats.tolist()  # the one host read of batch preparation
+    host = None
+    for i, buf in enumerate(_PINNED_STATS):
+        if buf.numel() == stats.numel():
+            host = _PINNED_STATS.pop(i)
+            break
+    if host is None:
+        host = torch.empty((stats.numel(),), dtype=torch.int64).pin_memory()
+    host.copy_(stats, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    return dict(vf=vf, idx4=idx4, pid=pid, order=order, vstart=vstart, stats=stats, host=host, done=done, n_levels=n_levels)
+
+
+def voxelize_scenes_finish(handle):
+    """second half: the one host read of batch preparation (of pinned memory, after the copy's event) and the slicing"""
+    handle["done"].synchronize()
+    st = handle["host"].tolist()
+    if len(_PINNED_STATS) < 8:
+        _PINNED_STATS.append(handle["host"])
     if st[5] != 0:
         return None
-    V = st[0]
-    return vf[:V], idx4[:V], pid, order, vstart[:V + 1], st[1:4], st[4], st[8:8 + n_levels]
+    V, n_levels = st[0], handle["n_levels"]
+    return (handle["vf"][:V], handle["idx4"][:V], handle["pid"], handle["order"], handle["vstart"][:V + 1], st[1:4], st[4],
+            st[8:8 + n_levels])
+
+
+def voxelize_scenes(points, feats, seg_offsets, voxel_size, n_levels=0):
+    """Scene-batch voxelisation with the reference's per-scene ranges and NO host read before or between the launches
+    (gpn_voxelize_scenes).  -> (voxel_feats [V,C], indices [V,4] i32 = (scene,x,y,z), pc_voxel_id [M] i32, point_order [M],
+    voxel_point_start [V+1], max_coord [3 ints], dropped, level_counts [n_levels ints]) after ONE host read, or None when
+    a cell index did not fit the packed keys (>= 1024 cells along an axis: the caller takes voxelize() instead)."""
+    return voxelize_scenes_finish(voxelize_scenes_begin(points, feats, seg_offsets, voxel_size, n_levels))
 
 
 # ---------------------------------------------------------------------------------------------------- K
