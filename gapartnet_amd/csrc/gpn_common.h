@@ -161,11 +161,6 @@ bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout);
 int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
                         int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream,
                         const DevRows& rows = DevRows());
-// the pair-compacted kernel (spconv_pairs.hip): conv over the (tap, dst)-ordered pair lists, accumulators in LDS
-bool spconv_pairs_supported(int K, int64_t n_dst, int cin, int cout);
-int spconv_pairs_launch(const float* in, const float* packed, const int32_t* pair_src, const int32_t* pair_dst,
-                        const int32_t* tile_off, int K, int64_t n_dst, int cin, int cout, int accumulate, const ConvStats& stats,
-                        float* out, hipStream_t stream);
 // weight-gradient contraction and its (batched) slice sums (spconv.hip); used by gpn_spconv_wgrad and the network executor
 constexpr int kWgradReduceJobs = 24;
 constexpr int kWgradSets = 4;

@@ -228,7 +228,9 @@ import os as _os
 # 4.3x the MFMA row-slots of its useful pairs, sorted by mask inside 16384-row blocks 2.1x (levels 1 / 2: 2.2x / 2.0x ->
 # 1.4x; stride-2 convs 4.4x -> 1.3x, inverse convs 4.3x -> 1.0x; tools/conv_tiles_bench.py).  The order costs a block-local sort (one workgroup per 16384 rows)
 # and a permuted table per rulebook; levels below 4096 tiles run on the direct kernel and keep voxel order.
-TILE_ORDER_MIN_ROWS = int(_os.environ.get("GPN_TILE_ORDER_MIN_ROWS", 65536))  # = the levels the masked-tile kernel takes
+# (round 4: also level 2 of the bench - 25k rows, direct / split kernel through `perm`: 8.17 / 8.23 / 8.14 -> 8.10 / 8.10 / 8.09 ms
+# per step in three interleaved same-box runs, profiles/r04_findings.md; 4096 gave nothing more)
+TILE_ORDER_MIN_ROWS = int(_os.environ.get("GPN_TILE_ORDER_MIN_ROWS", 16384))
 TILE_ORDER_BLOCK = int(_os.environ.get("GPN_TILE_ORDER_BLOCK", 16384))
 
 

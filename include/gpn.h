@@ -561,16 +561,6 @@ int gpn_pose_fit(const double* xyz, const double* npcs, const int64_t* offsets, 
                  double* transform, double* bbox, uint8_t* inlier_mask, int64_t* best_iteration, double* residual, void* ws,
                  size_t ws_bytes, gpn_stream_t stream);
 
-/* the conv over the rulebook's pair lists (csrc/spconv_pairs.hip, round 4): a wave owns 32-128 destination rows, walks the
- * pairs of every tap in chunks of 16 (MFMA row = pair) and adds the products to LDS accumulators in tap order - bit-equal to
- * gpn_spconv_fwd.  pair_src / pair_dst / tile_off as gpn_rulebook_subm3 / gpn_rulebook_down_lists write them. */
-int gpn_spconv_fwd_pairs(const float* in, const float* packed_w, const int32_t* pair_src, const int32_t* pair_dst,
-                         const int32_t* tile_off, int K, int64_t n_dst, int cin, int cout, float* out, gpn_stream_t stream);
-/* its knobs: mode 0 off / 1 on inside the network executor, rows per wave (32 / 64 / 128), column tiles per wave (0 = up to
- * 4), smallest / largest layer in rows; a negative argument keeps a setting (env GPN_CONV_PAIRS, GPN_PAIRS_ROWS, GPN_PAIRS_COLS,
- * GPN_PAIRS_MIN_ROWS, GPN_PAIRS_MAX_ROWS) */
-int gpn_spconv_pairs_config(int mode, int rows_per_wave, int cols_per_wave, int64_t min_rows, int64_t max_rows);
-
 /* ================================================================================================
  * DEV - entry points whose extents are DEVICE COUNTERS (round 4: the proposal stage of a training step without a host read;
  * reference glue: network/model.py:228-346, 348-462 - there every stage boundary is a device->host read of a size).
