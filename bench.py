@@ -300,6 +300,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
+    cpu0 = time.process_time()  # CPU seconds of every thread of this process (main, weight-gradient helper, runtime threads)
     for i in range(args.steps):
         step(next(feed), i)
     torch.cuda.synchronize(device)
@@ -307,6 +308,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    host_cpu_ms = (time.process_time() - cpu0) / args.steps * 1e3
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -395,6 +397,11 @@ def main():
                                    f"voxel 0.01, random-init weights", "global_batch": world * args.batch,
                        "points_per_scene": args.points, "parallelism": f"dp{world}"},
             "roofline": roof,
+            # what a rank asks of the host: CPU milliseconds per step summed over its threads (rank 0's), and the cores it may
+            # run on - at N ranks per node the node needs about N x cpu_ms_per_step / ms_per_step cores for this rate
+            "host": {"cpu_ms_per_step": host_cpu_ms, "cores_in_use": host_cpu_ms / (elapsed / args.steps * 1e3),
+                     "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                     "usable_cores": usable_cores()},
         }
         if step.grad_sync is not None:  # how the gradient exchange ran: buckets all-reduced in place / via one cat / skipped
             out["grad_exchange"] = dict(step.grad_sync.stats, backend=step.grad_sync.backend)

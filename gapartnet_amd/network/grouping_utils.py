@@ -240,10 +240,13 @@ def filter_invalid_proposals(proposals: Instances, score_threshold: float, min_n
 
 
 @torch.no_grad()
-def proposal_intersections(sorted_indices: torch.Tensor, proposal_indices: torch.Tensor, num_proposals: int) -> torch.Tensor:
+def proposal_intersections(sorted_indices: torch.Tensor, proposal_indices: torch.Tensor, num_proposals: int,
+                           max_sets: Optional[int] = None) -> torch.Tensor:
     """[P,P] float32 number of shared points between proposals (diagonal = sizes).  Equivalent to the reference's
     dense ``csr @ csr.T`` (grouping_utils.py:231-239) but built from the sorted (point, proposal) incidence list, so
-    memory is O(P^2 + M) instead of O(P * M)."""
+    memory is O(P^2 + M) instead of O(P * M).  ``max_sets``: an upper bound on the proposals a point can be in, when the
+    caller knows one (dual-set clustering: 2) - the walk over neighbour distances then has a fixed length and no host read;
+    None: walk until no point repeats at that distance (one read per distance)."""
     dev = sorted_indices.device
     inter = torch.zeros((num_proposals, num_proposals), dtype=torch.float32, device=dev)
     sizes = torch.bincount(proposal_indices, minlength=num_proposals).to(torch.float32)
@@ -252,6 +255,13 @@ def proposal_intersections(sorted_indices: torch.Tensor, proposal_indices: torch
         return inter
     pt, order = torch.sort(sorted_indices.to(torch.int64), stable=True)
     prop = proposal_indices[order]
+    if max_sets is not None:
+        for d in range(1, min(int(max_sets), pt.shape[0])):
+            w = (pt[d:] == pt[:-d]).to(torch.float32)  # weight 0 where the two entries are different points: nothing selected
+            a, b = prop[:-d], prop[d:]
+            inter.index_put_((a, b), w, accumulate=True)
+            inter.index_put_((b, a), w, accumulate=True)
+        return inter
     d = 1
     while d < pt.shape[0]:
         same = pt[d:] == pt[:-d]
@@ -265,10 +275,10 @@ def proposal_intersections(sorted_indices: torch.Tensor, proposal_indices: torch
     return inter
 
 
-def apply_nms(proposals: Instances, iou_threshold: float = 0.3) -> Instances:
-    """greedy NMS on point-set IoU between proposals (grouping_utils.py:221-298)."""
+def apply_nms(proposals: Instances, iou_threshold: float = 0.3, max_sets: Optional[int] = None) -> Instances:
+    """greedy NMS on point-set IoU between proposals (grouping_utils.py:221-298).  ``max_sets``: see proposal_intersections."""
     P = proposals.score_preds.shape[0]
-    inter = proposal_intersections(proposals.sorted_indices, proposals.proposal_indices, P)
+    inter = proposal_intersections(proposals.sorted_indices, proposals.proposal_indices, P, max_sets)
     sizes = proposals.num_points_per_proposal.to(torch.float32)
     union = sizes[:, None] + sizes[None, :] - inter
     ious = inter / (union + 1e-8)

@@ -611,7 +611,8 @@ class GAPartNet(LightningModule):
     def _post_process(self, proposals: Instances) -> Instances:
         proposals = filter_invalid_proposals(proposals, score_threshold=self.val_score_threshold,
                                              min_num_points_per_proposal=self.val_min_num_points_per_proposal)
-        proposals = apply_nms(proposals, self.val_nms_iou_threshold)
+        # (a point is in at most one cluster of each of the two sets: model.py:256-283)
+        proposals = apply_nms(proposals, self.val_nms_iou_threshold, max_sets=2)
         proposals.pt_sem_classes = proposals.sem_preds[proposals.proposal_offsets[:-1].long()]
         return proposals
 

@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Throughput of the evaluation path (BASELINE.json config 2: full pipeline, 20k-point scenes, bs 4, eval mode): validation steps
+(backbone -> point heads -> dual-set clustering -> ScoreNet / NPCS-Net -> score filter -> NMS) over the three loaders of the data
+module, and the epoch end (AP at ten IoU thresholds + mIoU on the device).  Reference: network/model.py:667-692, 694-857.
+release.ckpt is absent: name-keyed seeded weights with non-trivial BatchNorm statistics (tests/golden/recipe.py), so that the
+network predicts more than one class and proposals exist.
+
+    python tools/eval_bench.py [--batch 4] [--points 20000] [--steps 12]        # one JSON line
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=12, help="validation steps per loader and epoch")
+    ap.add_argument("--epochs", type=int, default=3)
+    args = ap.parse_args()
+    from gapartnet_amd.smoke import make_batch, make_model
+    from tests.golden import recipe
+    dev = torch.device("cuda:0")
+    model = make_model((0, 0)).eval()
+    model.load_state_dict(recipe.name_keyed_state(model))
+    model = model.to(dev)
+    logged = {}
+    model._log_sink = lambda name, value, bs, sync: logged.__setitem__(name, value)
+    pools = [[[pc.to(dev) for pc in make_batch(args.batch, args.points, seed0=2000 + 1000 * l + 10 * j)] for j in range(2)]
+             for l in range(3)]
+    step_ms, end_ms, kept = [], [], 0
+    with torch.no_grad():
+        for epoch in range(args.epochs + 1):  # epoch 0 warms up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for l in range(3):
+                for i in range(args.steps):
+                    out = model.validation_step(pools[l][i % 2], i, l)
+                    if out[2] is not None:
+                        kept = int(out[2].score_preds.shape[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model.on_validation_epoch_end()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if epoch > 0:
+                step_ms.append((t1 - t0) / (3 * args.steps) * 1e3)
+                end_ms.append((t2 - t1) * 1e3)
+    step_ms.sort(); end_ms.sort()
+    ms = step_ms[len(step_ms) // 2]
+    print(json.dumps({"metric": "point-clouds/sec (20k pts, validation step, eval mode)", "value": args.batch / ms * 1e3,
+                      "ms_per_validation_step": ms, "epoch_end_ms": end_ms[len(end_ms) // 2],
+                      "steps_per_epoch": 3 * args.steps, "batch": args.batch, "points": args.points,
+                      "proposals_kept_last_step": kept, "mAP_logged": float(logged.get("val/mAP", float("nan"))),
+                      "config": "BASELINE config 2 shape (full pipeline eval, bs 4 x 20k), seeded weights (release.ckpt absent)"}))
+
+
+if __name__ == "__main__":
+    main()
