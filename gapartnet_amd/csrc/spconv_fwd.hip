@@ -288,7 +288,7 @@ int dispatch_cw(const FwdPlan& p, const float* in, const float* packed, const in
 #ifndef GPN_DIRECT_D
 #define GPN_DIRECT_D 4
 #endif
-template <int KT, int CB>
+template <int KT, int CB, bool DEV>  // DEV: the row count is a device counter (gpn::DevRows), units walked with a grid stride
 __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                                                 const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
                                                                 int64_t units, size_t packed_bytes,
@@ -304,19 +304,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;  // prefetch depth in stages
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  if (n_dev) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
+  if constexpr (DEV) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
     n_dst = gpn::live_rows(n_dev, n_dst);
     units = ((n_dst + 15) >> 4) * nt_total;
   }
-  // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous eighth of the
-  // tiles, so that the source rows its waves gather (spatial neighbours = nearby rows) are fetched into ONE L2 instead of
-  // all eight (time per launch unchanged; fetched bytes per launch, averaged over the bench's conv launches: 16.2 -> 8.9 MB).
-  // An XCD's workgroups walk its eighth with a grid stride (one round unless a device-counted launch outgrew its plan).
-  const int64_t per8 = (((units + 3) >> 2) + 7) >> 3;
-  for (int64_t wj = blockIdx.x >> 3; wj < per8; wj += gridDim.x >> 3) {
-  const int64_t wg = (int64_t)(blockIdx.x & 7) * per8 + wj;
-  const int64_t unit = wg * 4 + wave;
-  if (unit >= units) continue;  // whole wave; no barrier in this kernel
+  // (the unit's code as a lambda with ONE call site per instantiation: the exactly-sized form keeps its straight-line shape and
+  // register count, the DEV form wraps it in a grid-stride loop - see spconv_tiles.hip)
+  auto run_unit = [&](const int64_t unit) {
   const int64_t tile = unit / nt_total;
   const int nt = (int)(unit - tile * nt_total);
   const int cin = CB * 16, cout = nt_total * 16;
@@ -451,7 +445,22 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   }
   if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
   else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
-  }  // units of this workgroup
+  };
+  // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous eighth of the
+  // tiles, so that the source rows its waves gather (spatial neighbours = nearby rows) are fetched into ONE L2 instead of
+  // all eight (time per launch unchanged; fetched bytes per launch, averaged over the bench's conv launches: 16.2 -> 8.9 MB)
+  if constexpr (!DEV) {
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t unit = wg * 4 + wave;
+    if (unit >= units) return;  // whole wave; no barrier in this kernel
+    run_unit(unit);
+  } else {  // an XCD's workgroups walk its eighth with a grid stride (one round unless the launch outgrew its plan)
+    const int64_t per8 = (((units + 3) >> 2) + 7) >> 3;
+    for (int64_t wj = blockIdx.x >> 3; wj < per8; wj += gridDim.x >> 3) {
+      const int64_t unit = ((int64_t)(blockIdx.x & 7) * per8 + wj) * 4 + wave;
+      if (unit < units) run_unit(unit);
+    }
+  }
 }
 
 // Tap-split form of the direct kernel for layers with FEW (tile, column tile) units (round 3).  A level of a few thousand
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
 // SP-th of the taps with the same register rings, leave their accumulators in LDS, and the unit's first wave adds them in
 // wave order and stores (plus the BatchNorm sums): SP x the waves, chains 1 / SP as long, one launch, fixed summation order
 // (per wave: taps ascending, two-level as in the direct kernel; then (((p0 + p1) + p2) + p3)) => deterministic.
-template <int KT, int CB, int SP>
+template <int KT, int CB, int SP, bool DEV>
 __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                                                const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
                                                                int64_t units, size_t packed_bytes,
@@ -480,13 +489,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  if (n_dev) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
+  if constexpr (DEV) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
     n_dst = gpn::live_rows(n_dev, n_dst);
     units = ((n_dst + 15) >> 4) * nt_total;
   }
-  const int64_t per8 = (((units + UPW - 1) / UPW) + 7) >> 3;  // workgroups of an XCD that have a unit (grid-stride walk below)
-  for (int64_t wj = blockIdx.x >> 3; wj < per8; wj += gridDim.x >> 3) {
-  const int64_t wg = (int64_t)(blockIdx.x & 7) * per8 + wj;
+  // (one workgroup's units as a lambda with ONE call site per instantiation, see the direct kernel; `more` = another round
+  // follows, uniform per workgroup)
+  auto run_wg = [&](const int64_t wg, const bool more) {
   const int64_t unit = wg * UPW + wave / SP;
   const int part = wave % SP;
   const int tap0 = part * TP;
@@ -613,8 +622,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
   else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
   }
-  if (wj + (int64_t)(gridDim.x >> 3) < per8) __syncthreads();  // another round: `red` is rewritten (uniform per workgroup)
-  }  // units of this workgroup
+  if (more) __syncthreads();  // another round: `red` is rewritten
+  };
+  if constexpr (!DEV) {
+    run_wg((int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3), false);
+  } else {
+    const int64_t per8 = (((units + UPW - 1) / UPW) + 7) >> 3;  // workgroups of an XCD that have a unit
+    for (int64_t wj = blockIdx.x >> 3; wj < per8; wj += gridDim.x >> 3)
+      run_wg((int64_t)(blockIdx.x & 7) * per8 + wj, wj + (int64_t)(gridDim.x >> 3) < per8);
+  }
 }
 
 // units below which a layer takes the 4-way / 2-way tap-split form (0 = never).  tools/conv_split_sweep.py
@@ -638,9 +654,13 @@ int launch_split(const float* in, const float* packed, const int32_t* nbr, const
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
   const int64_t plan_units = gpn::cdiv(gpn::plan_rows(n_dst, rows), 16) * nt_total;
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
-  hipLaunchKernelGGL((spconv_fwd_split_kernel<KT, CB, SP>),
-                     dim3(gpn::dev_grid(gpn::cdiv(units, 4 / SP), gpn::cdiv(plan_units, 4 / SP), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1), dim3(256), 0,
-                     stream, in, packed, nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out, rows.dev);
+  const dim3 grid(gpn::dev_grid(gpn::cdiv(units, 4 / SP), gpn::cdiv(plan_units, 4 / SP), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1);
+  if (rows.dev)
+    hipLaunchKernelGGL((spconv_fwd_split_kernel<KT, CB, SP, true>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
+                       packed_bytes, perm, accumulate, stats, out, rows.dev);
+  else
+    hipLaunchKernelGGL((spconv_fwd_split_kernel<KT, CB, SP, false>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
+                       packed_bytes, perm, accumulate, stats, out, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -657,9 +677,13 @@ int launch_direct(const float* in, const float* packed, const int32_t* nbr, cons
       return launch_split<KT, CB, 2>(in, packed, nbr, perm, n_dst, nt_total, accumulate, stats, out, stream, rows);
   }
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
-  hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB>),
-                     dim3(gpn::dev_grid(gpn::cdiv(units, 4), gpn::cdiv(plan_units, 4), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1), dim3(256), 0, stream, in, packed,
-                     nbr, n_dst, nt_total, units, packed_bytes, perm, accumulate, stats, out, rows.dev);
+  const dim3 grid(gpn::dev_grid(gpn::cdiv(units, 4), gpn::cdiv(plan_units, 4), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1);
+  if (rows.dev)
+    hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB, true>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
+                       packed_bytes, perm, accumulate, stats, out, rows.dev);
+  else
+    hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB, false>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
+                       packed_bytes, perm, accumulate, stats, out, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

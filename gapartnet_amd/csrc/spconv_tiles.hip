@@ -49,7 +49,7 @@ constexpr int cfg_group(int CB, int R, int NT) {  // taps per iteration of the m
   return U < 1 ? 1 : (U > 4 ? 4 : U);
 }
 
-template <int CB, int NT, int R>
+template <int CB, int NT, int R, bool DEV>  // DEV: the row count is a device counter (gpn::DevRows), units walked with a grid stride
 __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                                            const int32_t* __restrict__ nbr, const int32_t* __restrict__ perm,
                                                            int K, int64_t n_dst, int n_tiles, int n_units, int nt_total,
@@ -70,19 +70,15 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  if (n_dev) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
+  if constexpr (DEV) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
     n_dst = gpn::live_rows(n_dev, n_dst);
     n_tiles = (int)((n_dst + 15) >> 4);
     n_units = ((n_tiles + R - 1) / R) * col_groups;
   }
-  // workgroups are dealt round-robin to the 8 XCDs: every XCD takes one contiguous eighth of the units (the rows its waves
-  // gather are fetched into ONE L2).  The workgroups of an XCD walk that eighth with a grid stride: one round when the grid was
-  // sized from the row count (per8 == gridDim.x / 8), more when a device-counted launch holds more rows than planned
-  const int per8 = (((n_units + 3) >> 2) + 7) >> 3;
-  for (int wj = (int)(blockIdx.x >> 3); wj < per8; wj += (int)(gridDim.x >> 3)) {
-  const int wg = (int)(blockIdx.x & 7) * per8 + wj;
-  const int unit = __builtin_amdgcn_readfirstlane(wg * 4 + wave);
-  if (unit >= n_units) continue;  // whole wave; no barrier in this kernel
+  // one unit = R row tiles x NT column tiles of one wave.  (A generic lambda called from ONE place per instantiation: wrapped
+  // in the grid-stride loop of the DEV form the same code took 128 instead of 62 VGPRs - half the waves per SIMD, +19 % per
+  // launch at the 80k-row level - so the exactly-sized form keeps its straight-line shape.)
+  auto run_unit = [&](const int unit) {
   const int rg = unit / col_groups;
   const int nt0 = (unit - rg * col_groups) * NT;
   const int tile0 = rg * R;
@@ -272,7 +268,21 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
       }
     }
   }
-  }  // units of this workgroup
+  };
+  // workgroups are dealt round-robin to the 8 XCDs: every XCD takes one contiguous eighth of the units (the rows its waves
+  // gather are fetched into ONE L2)
+  if constexpr (!DEV) {
+    const int wg = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int unit = __builtin_amdgcn_readfirstlane(wg * 4 + wave);
+    if (unit >= n_units) return;  // whole wave; no barrier in this kernel
+    run_unit(unit);
+  } else {  // the workgroups of an XCD walk its eighth with a grid stride: one round unless the launch outgrew its plan
+    const int per8 = (((n_units + 3) >> 2) + 7) >> 3;
+    for (int wj = (int)(blockIdx.x >> 3); wj < per8; wj += (int)(gridDim.x >> 3)) {
+      const int unit = __builtin_amdgcn_readfirstlane(((int)(blockIdx.x & 7) * per8 + wj) * 4 + wave);
+      if (unit < n_units) run_unit(unit);
+    }
+  }
 }
 
 std::atomic<int64_t> g_min_tiles{[] {
@@ -306,8 +316,12 @@ int launch_tiles(const float* in, const float* packed, const int32_t* nbr, const
   const int64_t plan_units = gpn::cdiv(gpn::cdiv(gpn::plan_rows(n_dst, rows), 16), R) * col_groups;
   const size_t packed_bytes = (size_t)K * CB * nt_total * 1024;
   const dim3 grid(gpn::dev_grid(gpn::cdiv(n_units, 4), gpn::cdiv(plan_units, 4), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1);
-  hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
-                     n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev);
+  if (rows.dev)
+    hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R, true>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
+                       n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev);
+  else
+    hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R, false>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
+                       n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
