@@ -34,6 +34,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "bn_stats.h"
 #include "gpn_common.h"
@@ -43,13 +44,42 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxTaps = 27;
 
-constexpr int cfg_group(int CB, int R, int NT) {  // taps per iteration of the main loop: ~32 MFMAs
-  const int per_tap = CB * R * NT * 4;
-  const int U = (32 + per_tap - 1) / per_tap;
-  return U < 1 ? 1 : (U > 4 ? 4 : U);
+// compile-time measurement switches (tools/probes/tiles_ablation.sh; 0 in the product): 1 = no row gathers, 2 = no weight loads,
+// 4 = no MFMAs (an element-wise stand-in keeps the loads alive), 8 = no BatchNorm sums in the epilogue
+#ifndef GPN_TILES_ABL
+#define GPN_TILES_ABL 0
+#endif
+#ifndef GPN_TILES_OPERAND_REGS
+#define GPN_TILES_OPERAND_REGS 32
+#endif
+
+// GPN_TILES_TRACE (tools/probes/tiles_trace.py; off in the product): every wave records when it started, finished its prologue,
+// its tap loop and its epilogue (s_memrealtime, 100 MHz), its live taps and where it ran (HW_ID, XCC_ID)
+#ifndef GPN_TILES_TRACE
+#define GPN_TILES_TRACE 0
+#endif
+#if GPN_TILES_TRACE
+__device__ unsigned long long* g_tiles_trace = nullptr;  // [units][8]
+#endif
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+  static_for_impl(f, std::make_integer_sequence<int, N>());
 }
 
-template <int CB, int NT, int R, bool DEV>  // DEV: the row count is a device counter (gpn::DevRows), units walked with a grid stride
+constexpr int cfg_slots(int CB, int R, int NT) {  // operand slots of the tap loop's ring: what the register budget holds, 2 .. 6
+  const int regs_per_tap = CB * (R + NT) * 4;
+  const int S = GPN_TILES_OPERAND_REGS / regs_per_tap;
+  return S < 2 ? 2 : (S > 6 ? 6 : S);
+}
+
+// DEV = false: one unit per wave, the grid is exactly the launch (straight-line).  DEV = true: the row count is a device
+// counter (gpn::DevRows: n_dst is the buffers' bound, the grid a guess) and the waves walk the units of their XCD's eighth.
+template <int CB, int NT, int R, bool DEV>
 __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                                            const int32_t* __restrict__ nbr, const int32_t* __restrict__ perm,
                                                            int K, int64_t n_dst, int n_tiles, int n_units, int nt_total,
@@ -61,7 +91,6 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
     stats.slab = stats.twin.slab, stats.x = stats.twin.x, stats.y = stats.twin.y, stats.mean = stats.twin.mean,
     stats.invstd = stats.twin.invstd;
   }
-  constexpr int U = cfg_group(CB, R, NT);
   constexpr int RW = R * 16;        // rows of a wave
   constexpr int TPI = 64 / RW;      // taps covered by one table load of the prologue
   constexpr int NI = (kMaxTaps + TPI - 1) / TPI;
@@ -70,7 +99,7 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  if constexpr (DEV) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound, the grid a guess
+  if constexpr (DEV) {  // the row count is a device counter (gpn::DevRows): n_dst was the buffers' bound
     n_dst = gpn::live_rows(n_dev, n_dst);
     n_tiles = (int)((n_dst + 15) >> 4);
     n_units = ((n_tiles + R - 1) / R) * col_groups;
@@ -79,6 +108,9 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
   // in the grid-stride loop of the DEV form the same code took 128 instead of 62 VGPRs - half the waves per SIMD, +19 % per
   // launch at the 80k-row level - so the exactly-sized form keeps its straight-line shape.)
   auto run_unit = [&](const int unit) {
+#if GPN_TILES_TRACE
+  const unsigned long long tr0 = wall_clock64();
+#endif
   const int rg = unit / col_groups;
   const int nt0 = (unit - rg * col_groups) * NT;
   const int tile0 = rg * R;
@@ -161,6 +193,10 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
     if (live) slab[wave][slot][lr] = valid ? (uint32_t)raw[i] * (uint32_t)(cin * 4) : kOob;
   }
   int remaining = __builtin_popcount(um);
+#if GPN_TILES_TRACE
+  const unsigned long long tr_taps = (unsigned long long)remaining;
+  const unsigned long long tr1 = wall_clock64();
+#endif
 
   f32x4 acc[R][NT];
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -171,73 +207,105 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
 
   const uint32_t bvoff = (uint32_t)lane * 16u;
   const uint32_t g16 = (uint32_t)g * 16u;
-  int slot0 = 0;
-  auto pop = [&]() -> int {  // next live tap (ascending)
-    const int k = __builtin_ctz(um);
+  // ---- the tap loop: a ring of S operand slots, S - 1 taps requested ahead of the one in the MFMAs ------------------------
+  // Left to itself the scheduler sinks a tap's loads to just above their use (one tap in flight per wave; a SIMD's few waves -
+  // 5 at the 80k-row level - then keep the MFMA pipe ~half busy: tools/probes/tiles_trace.py), and it undoes a ring written as
+  // a loop over slots (round 3: fresh registers per request, vmcnt(0) and a block of copies per iteration).  Here the loop
+  // body is the S sub-steps written out - slot indices are compile-time constants, no copies - and a scheduling barrier
+  // after every request block keeps it above the MFMAs of the older slot; the waits come out as counted s_waitcnt.  Requests
+  // past the wave's last live tap read at out-of-range offsets (zeros, no memory access) and are never multiplied.
+  constexpr int S = cfg_slots(CB, R, NT);
+  f32x4 ra[S][CB][R], rb[S][CB][NT];
+  int to_issue = remaining, issued = 0;
+  auto issue = [&](auto slot_tag) {
+    constexpr int sl = decltype(slot_tag)::value;
+    const bool has = to_issue > 0;
+    const int k = has ? __builtin_ctz(um) : 0;
     um &= um - 1u;
-    return k;
-  };
-  // one group of UU live taps, straight-line: offsets from the slab, all operands of the UU x CB stages, their MFMAs
-  auto group = [&](auto uu_tag) {
-    constexpr int UU = decltype(uu_tag)::value;
-    uint32_t aoff[UU][R];
-    int kk[UU];
+    const int ls = issued < kMaxTaps ? issued : kMaxTaps;  // (the slab has kMaxTaps + 1 slots)
+    to_issue -= 1, issued += 1;
+    const uint32_t woff = has ? (uint32_t)(k * CB * nt_total + nt0) * 1024u : 0x7ffffc00u - (uint32_t)(CB * nt_total) * 1024u;
 #pragma unroll
-    for (int u = 0; u < UU; ++u) {
-      kk[u] = pop();
-#pragma unroll
-      for (int t = 0; t < R; ++t) aoff[u][t] = slab[wave][slot0 + u][t * 16 + i16] + g16;  // (kOob + g16 stays out of range)
-    }
-    slot0 += UU;
-#pragma unroll
-    for (int u = 0; u < UU; ++u) {
-      // two-level summation, as the direct kernel: a tap's CB * 16 products accumulate in `part` (one MFMA chain from zero),
-      // the taps' sums are added to `acc` - rounding error grows with sqrt(16 CB) + sqrt(K) terms instead of sqrt(16 CB K)
-      // (2e-7 instead of 6e-7 relative; BatchNorm on the small deep levels amplifies it ~1000x in backward: with one chain
-      // the golden-pipeline gradient bound of 1e-3 x max|g| is missed by 3 %)
-      f32x4 part[R][NT];
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) part[t][nt] = zero;
+    for (int t = 0; t < R; ++t) {
+      const uint32_t ao = (has ? slab[wave][ls][t * 16 + i16] : kOob) + g16;  // (kOob + g16 stays out of range)
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
-        f32x4 a[R], b[NT];
+        if constexpr ((GPN_TILES_ABL & 1) != 0) {
+          const float f = __builtin_bit_cast(float, ao + (uint32_t)cb);
+          ra[sl][cb][t] = f32x4{f, f, f, f};
+        } else {
+          ra[sl][cb][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)ao, cb * 64, 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if constexpr ((GPN_TILES_ABL & 2) != 0) {
+          const float f = (float)(k + cb + nt);
+          rb[sl][cb][nt] = f32x4{f, f, f, f};
+        } else {
+          rb[sl][cb][nt] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(bvoff + woff), (cb * nt_total + nt) * 1024, 0));
+        }
+      }
+  };
+  auto consume = [&](auto slot_tag) {
+    constexpr int sl = decltype(slot_tag)::value;
+    // two-level summation, as the direct kernel: a tap's CB * 16 products accumulate in `part` (one MFMA chain from zero),
+    // the taps' sums are added to `acc` - rounding error grows with sqrt(16 CB) + sqrt(K) terms instead of sqrt(16 CB K)
+    // (2e-7 instead of 6e-7 relative; BatchNorm on the small deep levels amplifies it ~1000x in backward: with one chain
+    // the golden-pipeline gradient bound of 1e-3 x max|g| is missed by 3 %)
+    f32x4 part[R][NT];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) part[t][nt] = zero;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      // column tiles interleaved: a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles, an independent one after 32
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
         for (int t = 0; t < R; ++t)
-          a[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)aoff[u][t], cb * 64, 0));
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          b[nt] = __builtin_bit_cast(
-              f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)bvoff, ((kk[u] * CB + cb) * nt_total + nt0 + nt) * 1024, 0));
-        // column tiles interleaved: a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles, an independent one after 32
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int t = 0; t < R; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              part[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b[nt][s], part[t][nt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[t][nt] += part[t][nt];
+          for (int nt = 0; nt < NT; ++nt) {
+            if constexpr ((GPN_TILES_ABL & 4) != 0) part[t][nt][s4] += ra[sl][cb][t][s4] * rb[sl][cb][nt][s4];
+            else part[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[sl][cb][t][s4], rb[sl][cb][nt][s4], part[t][nt], 0, 0, 0);
+          }
     }
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[t][nt] += part[t][nt];
   };
-  while (remaining >= U) {
-    remaining -= U;
-    group(std::integral_constant<int, U>());
+  // (compile-time loops over the slots)
+  auto for_slots = [&](auto&& f) { static_for<S>(f); };
+  for_slots([&](auto i) {
+    if constexpr (decltype(i)::value < S - 1) issue(i);
+  });
+  __builtin_amdgcn_sched_barrier(0);
+  while (remaining >= S) {
+    remaining -= S;
+    for_slots([&](auto i) {
+      constexpr int iv = decltype(i)::value;
+      issue(std::integral_constant<int, (iv + S - 1) % S>());
+      __builtin_amdgcn_sched_barrier(0);
+      consume(i);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
-  if constexpr (U > 1) {
-    while (remaining > 0) {  // fewer than U taps left, one at a time
-      remaining -= 1;
-      group(std::integral_constant<int, 1>());
-    }
-  }
+  for_slots([&](auto i) {  // the last remaining (< S) taps: requested already
+    if (decltype(i)::value < remaining) consume(i);
+  });
 
+#if GPN_TILES_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long tr2 = wall_clock64();
+#endif
   // ---- D[row = 4g + r][col = i16] of every (row tile, column tile) -> out; BatchNorm column sums of the tile (bn_stats.h) ----
-  const bool st_fwd = stats.slab != nullptr && stats.x == nullptr;
+  const bool st_fwd = (GPN_TILES_ABL & 8) == 0 && stats.slab != nullptr && stats.x == nullptr;
 #pragma unroll
   for (int t = 0; t < R; ++t) {
     const int tile = tile0 + t;
@@ -268,19 +336,48 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
       }
     }
   }
+#if GPN_TILES_TRACE
+  if (g_tiles_trace && blockIdx.y == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long tr3 = wall_clock64();
+    if (lane == 0) {
+      unsigned long long* t = g_tiles_trace + (size_t)unit * 8;
+      t[0] = tr0, t[1] = tr1, t[2] = tr2, t[3] = tr3, t[4] = tr_taps;
+      t[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+      t[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+      t[7] = (unsigned long long)blockIdx.x;
+    }
+  }
+#endif
   };
-  // workgroups are dealt round-robin to the 8 XCDs: every XCD takes one contiguous eighth of the units (the rows its waves
-  // gather are fetched into ONE L2)
   if constexpr (!DEV) {
+    // workgroups are dealt round-robin to the 8 XCDs: every XCD takes one contiguous eighth of the units (the rows its waves
+    // gather are fetched into ONE L2)
     const int wg = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     const int unit = __builtin_amdgcn_readfirstlane(wg * 4 + wave);
     if (unit >= n_units) return;  // whole wave; no barrier in this kernel
     run_unit(unit);
-  } else {  // the workgroups of an XCD walk its eighth with a grid stride: one round unless the launch outgrew its plan
-    const int per8 = (((n_units + 3) >> 2) + 7) >> 3;
-    for (int wj = (int)(blockIdx.x >> 3); wj < per8; wj += (int)(gridDim.x >> 3)) {
-      const int unit = __builtin_amdgcn_readfirstlane(((int)(blockIdx.x & 7) * per8 + wj) * 4 + wave);
-      if (unit < n_units) run_unit(unit);
+  } else {
+    // the workgroups of an XCD share one eighth of the row-tile range (its rows stay in one L2) and deal its units out
+    // boustrophedon: wave j of the XCD's J waves takes the units at positions j, 2J-1-j, 2J+j, ... of the eighth - one round
+    // unless the launch outgrew its plan.
+    // (Round 4 tried this walk for the exactly-sized launches too - a grid of 2 - 6 waves per SIMD, with the rulebook's tiles
+    // of an eighth sorted by descending live taps so that a SIMD's units are a stratified sample, and, before that, unit
+    // queues on atomic counters.  tools/probes/tiles_trace.py: with one unit per wave a launch lasts as long as its most
+    // loaded SIMD's MFMAs - 1.47x the mean at the 80k-row level - plus a prologue and an epilogue all waves go through
+    // together; the walk cut the imbalance to 1.3x but leaves 3 - 4 waves per SIMD in the tap loop instead of 5, and a
+    // level has only ~5 row tiles per SIMD to balance with: 35.5 - 38 us per launch instead of 38, 7.92 - 8.10 ms per
+    // step instead of 7.94.  A same-address atomic across XCDs takes ~13 ns: the queues ran 300 - 900 us.  Removed.)
+    static_assert(R == 1, "units are single row tiles");
+    const int tp8 = (n_tiles + 7) >> 3;
+    const int x = (int)(blockIdx.x & 7);
+    const int a = min(x * tp8, n_tiles), b = min(a + tp8, n_tiles);
+    const int units = (b - a) * col_groups;
+    const int J = (int)(gridDim.x >> 3) * 4, j = (int)(blockIdx.x >> 3) * 4 + wave;
+    for (int r = 0;; ++r) {
+      const int pos = __builtin_amdgcn_readfirstlane(r * J + ((r & 1) ? J - 1 - j : j));
+      if (pos >= units) break;  // (positions grow with r for every j)
+      run_unit(a * col_groups + pos);
     }
   }
 }
@@ -396,6 +493,13 @@ int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr
 }
 
 }  // namespace gpn
+
+#if GPN_TILES_TRACE
+extern "C" int gpn_probe_tiles_trace(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tiles_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // smallest layer (in 16-row tiles) the masked-tile kernel takes; smaller ones run on the direct / lock-step kernels of
 // spconv_fwd.hip.  min_tiles < 0 only queries.  Returns the previous value.  (Default 4096, env GPN_TILES_MIN_TILES; tests
