@@ -183,6 +183,10 @@ struct WgradReduceJob {
 int wgrad_slices(int K, int cin, int cout, int64_t n_dst);
 int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream,
                    const int64_t* n_dst_dev = nullptr);
+// the same contraction without LDS staging (spconv_wgrad.hip): rows from L2 straight into MFMA operands
+bool wgrad_rows_supported(int64_t n_rows_bound, int cin, int cout);
+int wgrad_rows_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream,
+                        const int64_t* n_dst_dev);
 WgradReduceJob wgrad_reduce_job(const float* partial, int S, int K, int cin, int cout, int flags, float* dW);
 int wgrad_reduce_many(const WgradReduceJob* jobs, int n, hipStream_t stream);
 // gpn_rulebook_level_counts with row count and level-0 extent on the device (rulebook.hip; used by gpn_voxelize_scenes)

@@ -54,7 +54,7 @@ struct LdsPitch {  // floats per LDS row for W payload floats: pitch % 64 in {16
 
 template <int CT, int NT>
 __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
-    const gpn::WgradSets sets, int64_t n_tiles, int cin, int S, int cigs, const int64_t* __restrict__ n_dst_dev) {
+    const gpn::WgradSets sets, int64_t n_tiles, int cin, int K, int S, int cigs, int n_z, int dealt, const int64_t* __restrict__ n_dst_dev) {
   // (device-counted rows, gpn::DevRows: the offset table's leading dimension is that of the LIVE row count)
   if (n_dst_dev) n_tiles = (gpn::live_rows(n_dst_dev, n_tiles * GPN_TILE_ROWS) + GPN_TILE_ROWS - 1) / GPN_TILE_ROWS;
   constexpr int T = 64;  // pairs per tile
@@ -67,17 +67,30 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
   float* sA = smem;
   float* sB = smem + T * PA;
 
-  const int k = blockIdx.x, s = blockIdx.y;
-  // gridDim.z = (layers in this launch) x (Cin groups): layers of one shape - the same layer of the two networks of a paired
+  // Work item (tap k, pair slice s, z = (layer of this launch, Cin group)).  A slice of a tap's pair list (ordered by
+  // destination row) covers about the same stretch of rows for every tap, so all taps and layers of a slice go to ONE XCD
+  // (workgroups are dealt round-robin to the 8 XCDs: XCD x takes the slices [x S/8, (x+1) S/8), k fastest): its rows are
+  // fetched into one L2 once and re-read there by the other taps.  With (k, s, z) = blockIdx every XCD streamed the whole
+  // level - 20 MB at the 80k-row level against 4 MB of L2 - once per tap, i.e. every gathered row came from the Infinity Cache.
+  int k, s, z;
+  if (dealt) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, s8 = S >> 3;  // (S is a multiple of 8 here)
+    const int kz = K * n_z;
+    s = x * s8 + j / kz;
+    const int rem = j - (j / kz) * kz;
+    z = rem / K, k = rem - z * K;
+  } else {
+    k = blockIdx.x, s = blockIdx.y, z = blockIdx.z;
+  }
+  // z = (layers in this launch) x (Cin groups): layers of one shape - the same layer of the two networks of a paired
   // pass, consecutive layers of a level - are contracted by one launch (uniform per workgroup: scalar loads of the set)
-  const int set = blockIdx.z / cigs, cig = blockIdx.z - set * cigs;
+  const int set = z / cigs, cig = z - set * cigs;
   const float* __restrict__ in = sets.s[set].in;
   const float* __restrict__ dout = sets.s[set].dout;
   const int32_t* __restrict__ pair_src = sets.s[set].pair_src;
   const int32_t* __restrict__ pair_dst = sets.s[set].pair_dst;
   const int32_t* __restrict__ tile_off = sets.s[set].tile_off;
   float* __restrict__ partial = sets.s[set].partial;
-  const int K = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   const int row = tid >> 2, q = tid & 3;  // gather role: pair `row` of the tile, 16-byte piece q of each 64-byte block
@@ -303,6 +316,7 @@ int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
   if (S > mem_cap) S = mem_cap;
   if (S < 1) S = 1;
   if (S > 512) S = 512;
+  if (S >= 8) S &= ~(int64_t)7;  // whole eighths: the slices of a launch are dealt to the 8 XCDs (spconv_wgrad_lds_kernel)
   return (int)S;
 }
 
@@ -311,8 +325,14 @@ int launch_wgrad(const gpn::WgradSets& sets, int K, int64_t n_dst, int cin, int 
   const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
   const int ct_tiles = cin / 16;
   const int cig = (ct_tiles + CT - 1) / CT;
-  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), dim3(K, S, sets.n * cig), dim3(256), 0, stream, sets, n_tiles, cin, S,
-                     cig, n_dev);
+  static const bool by_xcd = [] {  // GPN_WGRAD_XCD=0: (tap, slice, layer) = blockIdx (A/B switch)
+    const char* e = getenv("GPN_WGRAD_XCD");
+    return e ? atoi(e) != 0 : true;
+  }();
+  const int n_z = sets.n * cig;
+  const int dealt = (by_xcd && S >= 8 && S % 8 == 0) ? 1 : 0;
+  const dim3 grid = dealt ? dim3((unsigned)(K * S * n_z)) : dim3(K, S, n_z);
+  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), grid, dim3(256), 0, stream, sets, n_tiles, cin, K, S, cig, n_z, dealt, n_dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -448,6 +468,7 @@ int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cou
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int nt = cout / 16;
   gpn::ProfScope prof(GPN_K_SPCONV_WGRAD, stream, 0.0, 0.0);
+  if (gpn::wgrad_rows_supported(n_dst, cin, cout)) return gpn::wgrad_rows_contract(sets, K, n_dst, cin, cout, S, stream, n_dst_dev);
   switch (CT) {
     case 1: return dispatch_wgrad_nt<1>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);
     case 2: return dispatch_wgrad_nt<2>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);

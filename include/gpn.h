@@ -215,6 +215,11 @@ int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src
                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
                      int cout, int flags /* GPN_LAYOUT_OKI: write dW as [Cout][K][Cin] */, float* dW, void* ws,
                      size_t ws_bytes, gpn_stream_t stream);
+/* which contraction gpn_spconv_wgrad and the executor run: 2 = gathered rows straight into MFMA operands (csrc/spconv_wgrad.hip)
+ * for every shape, 1 = for layers with >= 64 channels on a side, 0 = the LDS-staged kernel (csrc/spconv.hip) everywhere
+ * (default: the faster one in the training step); mode < 0 only queries.  Returns the previous value (env GPN_WGRAD_ROWS).
+ * Both are deterministic; they differ in the order of the sum over pairs (last bits). */
+int gpn_spconv_wgrad_rows(int mode);
 
 /* BN — BatchNorm1d over a feature matrix [N, C] fused with the residual add and ReLU that follow it in every block of
  * the reference network (network/backbone.py:40-49 relu(bn(conv(x)) [+ shortcut]); norm_fn = BatchNorm1d(eps=1e-4,

@@ -1,6 +1,3 @@
 cd $GRAFT_REPO_ROOT
-b() { env "$@" python $SO bench.py --steps 60 --warmup 15 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$SO', round(d['ms_per_step'],3))"; }
-for r in 1 2 3 4; do
-SO=""; b A=1
-SO="tools/probes/with_so.py tools/probes/_build/libgpn_old.so"; b A=1
-done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2 | cut -c1-300
+timeout 300 python tools/wgrad_bench.py 2>&1 | grep -E "^L| level" | cut -c1-110 > gpurun_out/wgrad_bench.txt; cat gpurun_out/wgrad_bench.txt | head -30
