@@ -11,6 +11,8 @@ clustering code), i.e. exactly where the host would otherwise wait for the GPU.
 Yields ``PointCloudBatch`` objects (what ``GAPartNet.training_step`` accepts directly) whose ``voxel_tensor`` already
 carries the rulebook pyramid of the backbone in its ``indice_dict``.
 """
+import queue
+import threading
 from typing import Iterable, Optional
 
 import torch
@@ -26,6 +28,14 @@ import os
 # critical resource of the step now and the wait was the moment the GPU caught up with it; the earlier start of the batch
 # preparation kernels beside the backbone costs more than the wait did.  Default off; kept as a switch.
 _DEFER_VOXELS = os.environ.get("GPN_PREFETCH_DEFER", "0") == "1"
+# GPN_PREFETCH_THREAD=1: batch preparation is issued by a worker thread of the prefetcher instead of by the thread that runs the
+# training step (from its mid-step hook).  Round 4: the host's main thread needs as long for a step as the GPU does (DESIGN.md
+# 5.3), and ~1.3 ms of that is this preparation - 15 rulebook-builder calls, the voxeliser, tile orders, ~100 small allocations.
+# Measured (four interleaved same-box pairs): 7.79 / 7.82 / 7.82 / 7.97 ms per step without, 8.14 / 8.14 / 8.12 / 8.17 with the
+# worker, and 20.5 instead of 12.9 CPU-ms per step: the preparation is hundreds of short calls, each releasing and re-taking the
+# GIL, and the two threads spend their time handing it to each other.  Default off; the way to take this work off the main
+# thread is one library call per batch, not a second Python thread.
+_THREADED = os.environ.get("GPN_PREFETCH_THREAD", "0") == "1"
 _LEAF_TYPES = (str, bytes, int, float, bool, type(None))
 
 
@@ -56,9 +66,45 @@ def _tensors(root):
     return out
 
 
+class _Worker:
+    """one daemon thread that runs submitted callables in order on ``device``; ``result()`` returns (or re-raises) the oldest
+    outstanding one's outcome"""
+
+    def __init__(self, device: torch.device):
+        self._jobs, self._results = queue.SimpleQueue(), queue.SimpleQueue()
+        self._device = device
+        self._thread = threading.Thread(target=self._run, name="gpn-batch-preparation", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        torch.cuda.set_device(self._device)
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            try:
+                with torch.no_grad():
+                    self._results.put((job(), None))
+            except BaseException as exc:  # handed to the consumer thread, which re-raises it
+                self._results.put((None, exc))
+
+    def submit(self, job):
+        self._jobs.put(job)
+
+    def result(self):
+        value, exc = self._results.get()
+        if exc is not None:
+            raise exc
+        return value
+
+    def stop(self):
+        self._jobs.put(None)
+
+
 class DevicePrefetcher:
     """``for batch in DevicePrefetcher(loader, model, device)``: batches come out collated, voxelised and with the
-    backbone's rulebooks built, each prepared on a side stream while the previous one trains."""
+    backbone's rulebooks built, each prepared on a side stream (with GPN_PREFETCH_THREAD=1 by a worker thread) while the
+    previous one trains."""
 
     def __init__(self, batches: Iterable, model, device: torch.device, augmentation: Optional[dict] = None):
         assert device.type == "cuda", "batch preparation runs on the GPU (the product has no CPU path)"
@@ -66,6 +112,8 @@ class DevicePrefetcher:
         self.augmentation = augmentation  # for raw scenes (dataset device_pipeline=True): drawn per batch, applied on the GPU
         self.stream = torch.cuda.Stream(device=device)
         self._consumer_mark = None
+        self._worker = None       # created on first use (threaded mode)
+        self._outstanding = False  # a preparation job is running on the worker
 
     def _begin(self, raw):
         """first half of a batch's preparation, on the side stream: collate and QUEUE the voxelisation - its sizes are not read
@@ -116,9 +164,21 @@ class DevicePrefetcher:
         and queues the voxelisation of the one after it."""
         if self._has_pending:
             self._has_pending = False
-            self._ahead = self._finish(self._begun)
-            self._begun = self._begin(self._pending)
-            self._pending = None
+            begun, pending, self._pending = self._begun, self._pending, None
+            if _THREADED:
+                if self._worker is None:
+                    self._worker = _Worker(self.device)
+                self._outstanding = True
+                self._worker.submit(lambda: (self._finish(begun), self._begin(pending)))
+            else:
+                self._ahead = self._finish(begun)
+                self._begun = self._begin(pending)
+
+    def _collect(self):
+        """take over what the worker prepared since the last hand-out (waits for it if it is still at it)"""
+        if self._outstanding:
+            self._outstanding = False
+            self._ahead, self._begun = self._worker.result()
 
     def _mark_consumer(self):
         """order everything the side stream does from now on behind what the training stream has been given so far"""
@@ -159,7 +219,14 @@ class DevicePrefetcher:
                     hook_owner._prefetch_hook = self._prepare_pending
                 yield batch
                 self._prepare_pending()  # the consumer's step did not reach the hook (eval, early exit): prepare now
+                self._collect()
         finally:
+            if self._outstanding:  # (the consumer left mid-iteration: the job's batches are dropped with the rest)
+                self._outstanding = False
+                try:
+                    self._worker.result()
+                except BaseException:
+                    pass
             # the batches held back are released here: whatever the side stream allocates next (a later iteration of this
             # object) must come after every kernel the consumer enqueued on them
             try:
