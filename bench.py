@@ -116,8 +116,10 @@ def roofline_from_profile(device):
     names = {0: "spconv_fwd_kernel (fwd+dgrad launches)", 1: "spconv_wgrad_kernel", 6: "batchnorm passes"}
     # algorithmic flops/bytes per launch from the Python-side conv log (pair counts are device scalars: read now)
     per_kind = {"fwd": [0.0, 0.0, 0], "dgrad": [0.0, 0.0, 0], "wgrad": [0.0, 0.0, 0]}
-    for (num_pairs, cin, cout, n_src, n_dst, K, kind) in GF.CONV_LOG:
+    for (num_pairs, cin, cout, n_src, n_dst, K, kind, live) in GF.CONV_LOG:
         P = float(num_pairs.item())
+        if live is not None:  # device-counted rulebook: n_src / n_dst are the buffers' bounds
+            n_src, n_dst = int(live[0].t.item()), int(live[1].t.item())
         per_kind[kind][0] += 2.0 * P * cin * cout
         per_kind[kind][1] += 4.0 * n_src * cin + 4.0 * n_dst * cout + 8.0 * P + 4.0 * K * cin * cout
         per_kind[kind][2] += 1
@@ -165,13 +167,16 @@ def conv_levels(lib, overhead_us):
         rec = shapes.setdefault(key, dict(launches=0, ms_raw=0.0, flops=0.0, bytes=0.0, layers=0))
         rec["launches"] += 1
         rec["ms_raw"] += float(ms[i])
-    for (num_pairs, cin, cout, n_src, n_dst, K, kind) in GF.CONV_LOG:
+    for (num_pairs, cin, cout, n_src, n_dst, K, kind, live) in GF.CONV_LOG:
         if kind == "wgrad":
             continue
-        rec = shapes.get((K, n_dst, cin, cout))
+        rec = shapes.get((K, n_dst, cin, cout))  # (the launch tag carries the row count the library was called with)
         if rec is None:  # (a launch path without a tag: not expected)
             continue
         P = float(num_pairs.item())
+        if live is not None:  # device-counted rulebook: the tag's rows are the buffers' bound, the bytes those of the live rows
+            n_src, n_dst = int(live[0].t.item()), int(live[1].t.item())
+            rec["live_rows"] = n_dst
         rec["flops"] += 2.0 * P * cin * cout
         rec["bytes"] += 4.0 * n_src * cin + 4.0 * n_dst * cout + 8.0 * P + 4.0 * K * cin * cout
         rec["layers"] += 1
@@ -185,7 +190,8 @@ def conv_levels(lib, overhead_us):
         bound = "mfma" if intensity >= MACHINE_BALANCE else "hbm"
         peak = FP32_MFMA_PEAK_TFLOPS * 1e12 if bound == "mfma" else HBM_PEAK_GBS * 1e9
         work = r["flops"] if bound == "mfma" else r["bytes"]
-        rows.append(dict(taps=K, rows=n_rows, cin=cin, cout=cout, launches=r["launches"], layers=r["layers"],
+        rows.append(dict(taps=K, rows=r.get("live_rows", n_rows), **({"rows_bound": n_rows} if "live_rows" in r else {}),
+                         cin=cin, cout=cout, launches=r["launches"], layers=r["layers"],
                          us_per_launch_raw_events=r["ms_raw"] * 1e3 / r["launches"], flop_per_byte=intensity, bound=bound,
                          tflops_raw_events=r["flops"] / t_raw / 1e12, gbs_raw_events=r["bytes"] / t_raw / 1e9,
                          frac_raw_events=work / t_raw / peak, frac_minus_bracket=work / t_adj / peak,

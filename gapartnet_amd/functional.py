@@ -11,13 +11,15 @@ import torch.nn.functional as F
 
 from . import backend
 
-# optional log of conv launches for bench.py's roofline accounting: entries (num_pairs tensor, cin, cout, n_src, n_dst, K, kind)
+# optional log of conv launches for bench.py's roofline accounting: entries (num_pairs tensor, cin, cout, n_src, n_dst, K, kind,
+# live row counters (src, dst) of a device-counted rulebook or None - n_src / n_dst are then the buffers' bounds)
 CONV_LOG = None
 
 
 def _log(rb, cin, cout, kind):
     if CONV_LOG is not None:
-        CONV_LOG.append((rb.num_pairs, cin, cout, rb.n_src, rb.n_dst, rb.K, kind))
+        live = getattr(rb, "live_src", None), getattr(rb, "live_dst", None)
+        CONV_LOG.append((rb.num_pairs, cin, cout, rb.n_src, rb.n_dst, rb.K, kind, live if live[0] is not None else None))
 
 
 def _pad16(n):

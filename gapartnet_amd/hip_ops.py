@@ -77,6 +77,9 @@ class Rulebook:
     # mask inside 16384-row blocks, and the destination row of every tile position
     nbr_p: Optional[torch.Tensor] = None
     perm: Optional[torch.Tensor] = None
+    # device-counted rulebooks (section DEV): n_src / n_dst above are the buffers' bounds, these the live counts' counters
+    live_src: Optional["DevCount"] = None
+    live_dst: Optional["DevCount"] = None
 
     def pairs_host(self) -> int:
         return int(self.num_pairs.item())
@@ -216,7 +219,7 @@ def rulebook_subm3(indices, spatial_shape, rows: Optional[DevCount] = None) -> R
     if rows is not None:
         check(L.gpn_rulebook_subm3_dev(ptr(indices), i64(N), *rows.args(), host_i32x3(spatial_shape), ptr(nbr), ptr(src), ptr(dst),
                                        ptr(toff), ptr(npairs), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_subm3_dev")
-        return Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr)
+        return Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr, live_src=rows, live_dst=rows)
     check(L.gpn_rulebook_subm3(ptr(indices), i64(N), host_i32x3(spatial_shape), ptr(nbr), ptr(src), ptr(dst), ptr(toff),
                                ptr(npairs), ptr(ws), szt(ws.numel()), _stream()), "gpn_rulebook_subm3")
     return _with_tile_order(Rulebook(src, dst, toff, 27, N, N, npairs[0], nbr))
@@ -265,7 +268,7 @@ def rulebook_identity(n, device, rows_dev: Optional[DevCount] = None) -> Ruleboo
     if rows_dev is not None:
         check(_C.lib().gpn_rulebook_identity_dev(i64(n), *rows_dev.args(), ptr(rows), ptr(tile_off), ptr(nbr), ptr(npairs), _stream()),
               "gpn_rulebook_identity_dev")
-        return Rulebook(rows, rows, tile_off, 1, n, n, npairs[0], nbr)
+        return Rulebook(rows, rows, tile_off, 1, n, n, npairs[0], nbr, live_src=rows_dev, live_dst=rows_dev)
     check(_C.lib().gpn_rulebook_identity(i64(n), ptr(rows if n > 0 else nbr), ptr(tile_off), ptr(nbr), ptr(npairs), _stream()),
           "gpn_rulebook_identity")
     return Rulebook(rows, rows, tile_off, 1, n, n, npairs[0], nbr)
@@ -356,8 +359,8 @@ def rulebook_down_dev(indices, spatial_shape, batch_size, rows: DevCount, batch:
                                         ptr(ft), ptr(bn), ptr(bs), ptr(bd), ptr(bt), ptr(npairs), ptr(ws), szt(ws.numel()), _stream()),
           "gpn_rulebook_down_lists_dev")
     out_shape = [int(s) // 2 for s in spatial_shape]
-    rb_fwd = Rulebook(fs, fd, ft, 8, N, No, npairs[0], fn)
-    rb_bwd = Rulebook(bs, bd, bt, 8, No, N, npairs[0], bn)
+    rb_fwd = Rulebook(fs, fd, ft, 8, N, No, npairs[0], fn, live_src=rows, live_dst=out_rows)
+    rb_bwd = Rulebook(bs, bd, bt, 8, No, N, npairs[0], bn, live_src=out_rows, live_dst=rows)
     return out_idx, out_shape, rb_fwd, rb_bwd, out_rows
 
 

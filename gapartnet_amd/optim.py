@@ -20,6 +20,25 @@ _TABLE_DT = np.dtype([("param", np.uint64), ("grad", np.uint64), ("exp_avg", np.
                       ("numel", np.int64)])
 
 
+def _copy_many(dsts, srcs):
+    """dst[i].copy_(src[i]) for lists of tensors.  CUDA fp32 contiguous pairs of equal size go through ONE launch
+    (gpn_copy_many: the segment table is a kernel argument); torch._foreach_copy_ took its per-tensor path for the model's ~57
+    dense-head gradients - 57 hipMemcpyAsync of 3.6 us each on the training stream and 0.11 ms of host time per step."""
+    fast = [(d, s_) for d, s_ in zip(dsts, srcs)
+            if d.is_cuda and s_.is_cuda and d.dtype == torch.float32 and s_.dtype == torch.float32 and d.is_contiguous()
+            and s_.is_contiguous() and d.numel() == s_.numel() and d.device == s_.device]
+    if len(fast) != len(dsts) or not fast:
+        torch._foreach_copy_(dsts, srcs)
+        return
+    table = np.empty((len(fast), 3), np.int64)
+    table[:, 0] = [s_.data_ptr() for _, s_ in fast]
+    table[:, 1] = [d.data_ptr() for d, _ in fast]
+    table[:, 2] = [d.numel() for d, _ in fast]
+    dev = fast[0][0].device
+    stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+    _C.check(_C.lib().gpn_copy_many(ctypes.c_void_p(table.ctypes.data), ctypes.c_int(len(fast)), stream), "gpn_copy_many")
+
+
 class FusedAdam(torch.optim.Adam):
     _MAX_TABLE_SETS = 4  # device-table sets kept per parameter group (alternating proposal / no-proposal steps reuse theirs)
 
@@ -216,7 +235,7 @@ class FusedAdam(torch.optim.Adam):
             if own:
                 moved = [p for p in group["params"] if p in own and p.grad is not None]  # this group's only
                 if moved:
-                    torch._foreach_copy_([own[p] for p in moved], [p.grad for p in moved])
+                    _copy_many([own[p] for p in moved], [p.grad for p in moved])
             sets = self._cache.setdefault(gi, {})
             prev = self._snap.get(gi)
             if prev is not None and self._unchanged(group, prev[0][0], prev[2]):

@@ -547,6 +547,14 @@ typedef struct {
   void* exp_avg_sq;
   int64_t numel;
 } gpn_adam_tensor_t;
+/* n_segs fp32 segments dst[0..numel) = src[0..numel) (device memory) in one launch per 96 segments; segs_host is read during
+ * the call.  (Gradients that autograd allocates afresh every step -> the persistent buffers an Adam table points at.) */
+typedef struct {
+  const void* src;
+  void* dst;
+  int64_t numel;
+} gpn_copy_seg_t;
+int gpn_copy_many(const gpn_copy_seg_t* segs_host, int n_segs, gpn_stream_t stream);
 int gpn_adam_blocks(int64_t numel);
 int gpn_adam_step(const gpn_adam_tensor_t* table_dev, const int32_t* block_first_dev, int n_tensors, int n_blocks, double lr,
                   double beta1, double beta2, double eps, int64_t step, gpn_stream_t stream);

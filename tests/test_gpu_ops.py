@@ -920,3 +920,21 @@ def test_fps_big_cloud_shared_by_workgroups(H, cuda):
                                                   ctypes.c_void_p(idx.data_ptr()),
                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0 and np.array_equal(idx.cpu().numpy(), got)
+
+
+def test_copy_many_segments_in_one_launch(H, cuda):
+    """gpn_copy_many (section O): any number of fp32 segments - more than one launch's 96, empty ones, odd lengths - land
+    in their destinations; used by FusedAdam for the gradients autograd allocates afresh every step"""
+    from gapartnet_amd import optim
+    rng = np.random.default_rng(3)
+    sizes = [0, 1, 3, 64, 4097, 70000] + [int(n) for n in rng.integers(1, 3000, size=120)]
+    srcs = [torch.randn(n, device=cuda) for n in sizes]
+    dsts = [torch.full((n,), -7.0, device=cuda) for n in sizes]
+    optim._copy_many(dsts, srcs)
+    for d, s_ in zip(dsts, srcs):
+        assert torch.equal(d, s_)
+    # a pair the fast path cannot take (non-contiguous source) falls back to torch for the whole list
+    src2 = torch.randn(8, 6, device=cuda).t()
+    dst2 = torch.zeros(6, 8, device=cuda)
+    optim._copy_many([dst2, dsts[4]], [src2, srcs[5][:4097]])
+    assert torch.equal(dst2, src2) and torch.equal(dsts[4], srcs[5][:4097])
