@@ -18,6 +18,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxClasses = 32;
 constexpr int kMaxBlocks = 1024;
+constexpr int kPartials = 9;  // focal, dice, offset distance, offset direction, kept points, on-part points; hits, part points, part hits
 
 struct Stats {  // device-resident, written by the finalize kernel, read by backward
   double keep_count, on_count, points;
@@ -54,15 +55,27 @@ __device__ __forceinline__ float row_softmax(const float* __restrict__ z, int C,
 __global__ __launch_bounds__(kThreads) void point_losses_fwd_kernel(
     const float* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ offsets,
     const float* __restrict__ gt_offsets, const int32_t* __restrict__ inst, int64_t M, int C, int64_t ignore_index,
-    double* __restrict__ partial /* [blocks][6] */) {
+    double* __restrict__ partial /* [blocks][kPartials] */, int64_t* __restrict__ preds /* optional [M] */) {
   __shared__ double scratch[4];
-  double focal = 0.0, dice = 0.0, dist = 0.0, dir = 0.0, keep = 0.0, on = 0.0;
+  double focal = 0.0, dice = 0.0, dist = 0.0, dir = 0.0, keep = 0.0, on = 0.0, hit = 0.0, part = 0.0, part_hit = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < M; i += (int64_t)gridDim.x * kThreads) {
     const int64_t lab = labels[i];
     float p[kMaxClasses];
     const float* z = logits + i * C;
     const float lse = row_softmax(z, C, p);
     const bool has_class = lab >= 0 && lab < C;
+    if (preds) {  // the predicted class (torch.argmax: the first maximum) and the accuracy counts of model.py:535-541
+      int best = 0;
+      float bz = z[0];
+#pragma unroll
+      for (int c = 1; c < kMaxClasses; ++c)
+        if (c < C && z[c] > bz) bz = z[c], best = c;
+      preds[i] = best;
+      const bool ok = (int64_t)best == lab;
+      hit += ok ? 1.0 : 0.0;
+      part += lab > 0 ? 1.0 : 0.0;
+      part_hit += (ok && lab > 0) ? 1.0 : 0.0;
+    }
     if (lab != ignore_index) {
       keep += 1.0;
       const float u = (has_class ? z[lab] : 0.f) - lse;  // log p_t
@@ -88,25 +101,26 @@ __global__ __launch_bounds__(kThreads) void point_losses_fwd_kernel(
       dir += (double)(-((gx / ng) * (ox / no) + (gy / ng) * (oy / no) + (gz / ng) * (oz / no)));
     }
   }
-  double vals[6] = {focal, dice, dist, dir, keep, on};
+  double vals[kPartials] = {focal, dice, dist, dir, keep, on, hit, part, part_hit};
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < kPartials; ++k) {
     const double s = block_sum(vals[k], scratch);
-    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * 6 + k] = s;
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * kPartials + k] = s;
   }
 }
 
 __global__ void point_losses_finalize_kernel(const double* __restrict__ partial, int blocks, int64_t M,
-                                             float* __restrict__ losses /* [4] */, Stats* __restrict__ stats) {
+                                             float* __restrict__ losses /* [4] */, Stats* __restrict__ stats,
+                                             float* __restrict__ accu /* optional [2] */) {
   // one wave: lane l sums the partials of workgroups l, l + 64, ... in that order, then a fixed-order shuffle tree
   // (deterministic; a single thread walking all ~600 partials was a 58 us chain of dependent loads)
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
-  double s[6] = {0, 0, 0, 0, 0, 0};
+  double s[kPartials] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int b = threadIdx.x; b < blocks; b += 64)
-    for (int k = 0; k < 6; ++k) s[k] += partial[(int64_t)b * 6 + k];
+    for (int k = 0; k < kPartials; ++k) s[k] += partial[(int64_t)b * kPartials + k];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1)
-    for (int k = 0; k < 6; ++k) s[k] += __shfl_down(s[k], off, 64);
+    for (int k = 0; k < kPartials; ++k) s[k] += __shfl_down(s[k], off, 64);
   if (threadIdx.x != 0) return;
   losses[0] = s[4] > 0 ? (float)(s[0] / s[4]) : 0.f;  // focal: 0 for an all-ignored batch
   losses[1] = (float)(s[1] / (double)M);
@@ -115,6 +129,10 @@ __global__ void point_losses_finalize_kernel(const double* __restrict__ partial,
   stats->keep_count = s[4];
   stats->on_count = s[5];
   stats->points = (double)M;
+  if (accu) {  // (counts are exact in double; the quotients as torch forms them: both sides to fp32, one division)
+    accu[0] = __fdiv_rn((float)s[6], (float)M);     // (sem_preds == sem_labels).sum().float() / M
+    accu[1] = __fdiv_rn((float)s[8], (float)s[7]);  // ((sem_preds == sem_labels) & on_part).sum() / on_part.sum()
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void point_losses_bwd_kernel(
@@ -194,28 +212,46 @@ int fwd_blocks(int64_t M) {
 
 extern "C" size_t gpn_point_losses_ws_bytes(int64_t M) {
   (void)M;
-  return gpn::align_up(sizeof(Stats)) + gpn::align_up((size_t)kMaxBlocks * 6 * sizeof(double));
+  return gpn::align_up(sizeof(Stats)) + gpn::align_up((size_t)kMaxBlocks * kPartials * sizeof(double));
 }
 
 // losses [4] f32 = (focal, dice, offset distance, offset direction); stats_out = opaque 32-byte device block that the
 // backward call needs (counts of the selections)
+static int point_losses_fwd_impl(const float* logits, const int64_t* labels, const float* offsets, const float* gt_offsets,
+                                 const int32_t* instance_labels, int64_t M, int C, int64_t ignore_index, float* losses,
+                                 int64_t* preds, float* accu, void* stats_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  GPN_CHECK_ARG(M >= 1 && C >= 1 && C <= kMaxClasses);
+  GPN_CHECK_ARG(logits && labels && offsets && gt_offsets && instance_labels && losses && stats_out && ws);
+  GPN_CHECK_ARG((preds == nullptr) == (accu == nullptr));
+  GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * kPartials * sizeof(double));
+  const int blocks = fwd_blocks(M);
+  double* partial = static_cast<double*>(ws);
+  hipLaunchKernelGGL(point_losses_fwd_kernel, dim3(blocks), dim3(kThreads), 0, stream, logits, labels, offsets,
+                     gt_offsets, instance_labels, M, C, ignore_index, partial, preds);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(point_losses_finalize_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, M, losses,
+                     static_cast<Stats*>(stats_out), accu);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
 extern "C" int gpn_point_losses_fwd(const float* logits, const int64_t* labels, const float* offsets,
                                     const float* gt_offsets, const int32_t* instance_labels, int64_t M, int C,
                                     int64_t ignore_index, float* losses, void* stats_out, void* ws, size_t ws_bytes,
                                     gpn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  GPN_CHECK_ARG(M >= 1 && C >= 1 && C <= kMaxClasses);
-  GPN_CHECK_ARG(logits && labels && offsets && gt_offsets && instance_labels && losses && stats_out && ws);
-  GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 6 * sizeof(double));
-  const int blocks = fwd_blocks(M);
-  double* partial = static_cast<double*>(ws);
-  hipLaunchKernelGGL(point_losses_fwd_kernel, dim3(blocks), dim3(kThreads), 0, stream, logits, labels, offsets,
-                     gt_offsets, instance_labels, M, C, ignore_index, partial);
-  GPN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(point_losses_finalize_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, M, losses,
-                     static_cast<Stats*>(stats_out));
-  GPN_CHECK_LAUNCH();
-  return GPN_OK;
+  return point_losses_fwd_impl(logits, labels, offsets, gt_offsets, instance_labels, M, C, ignore_index, losses, nullptr, nullptr,
+                               stats_out, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+// the same pass also emits what the training step derives from the logits for its log and for the proposal stage: the
+// predicted class of every point (torch.argmax) and the two accuracies of network/model.py:535-541 - 11 torch launches less
+extern "C" int gpn_point_losses_fwd_metrics(const float* logits, const int64_t* labels, const float* offsets,
+                                            const float* gt_offsets, const int32_t* instance_labels, int64_t M, int C,
+                                            int64_t ignore_index, float* losses, int64_t* preds, float* accu, void* stats_out,
+                                            void* ws, size_t ws_bytes, gpn_stream_t stream_) {
+  GPN_CHECK_ARG(preds && accu);
+  return point_losses_fwd_impl(logits, labels, offsets, gt_offsets, instance_labels, M, C, ignore_index, losses, preds, accu,
+                               stats_out, ws, ws_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int gpn_point_losses_bwd(const float* logits, const int64_t* labels, const float* offsets,

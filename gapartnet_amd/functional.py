@@ -329,23 +329,29 @@ class _PointLossesFn(torch.autograd.Function):
     """kernel family P: focal + dice + offset-distance + offset-direction losses of all points in one pass"""
 
     @staticmethod
-    def forward(ctx, logits, offsets, labels, gt_offsets, instance_labels, ignore_index):
+    def forward(ctx, logits, offsets, labels, gt_offsets, instance_labels, ignore_index, metrics=False):
         ops = backend.raw()
         logits, offsets = logits.contiguous(), offsets.contiguous()
         labels, gt_offsets = labels.contiguous(), gt_offsets.contiguous()
         instance_labels = instance_labels.to(torch.int32).contiguous()
+        ctx.ignore_index = ignore_index
+        if metrics:
+            losses, stats, preds, accu = ops.point_losses_fwd(logits, labels, offsets, gt_offsets, instance_labels, ignore_index,
+                                                              metrics=True)
+            ctx.save_for_backward(logits, offsets, labels, gt_offsets, instance_labels, stats)
+            ctx.mark_non_differentiable(preds, accu)
+            return losses, preds, accu
         losses, stats = ops.point_losses_fwd(logits, labels, offsets, gt_offsets, instance_labels, ignore_index)
         ctx.save_for_backward(logits, offsets, labels, gt_offsets, instance_labels, stats)
-        ctx.ignore_index = ignore_index
         return losses
 
     @staticmethod
-    def backward(ctx, grad_losses):
+    def backward(ctx, grad_losses, *_unused):
         ops = backend.raw()
         logits, offsets, labels, gt_offsets, instance_labels, stats = ctx.saved_tensors
         d_logits, d_offsets = ops.point_losses_bwd(logits, labels, offsets, gt_offsets, instance_labels, ctx.ignore_index,
                                                    stats, grad_losses.contiguous())
-        return d_logits, d_offsets, None, None, None, None
+        return d_logits, d_offsets, None, None, None, None, None
 
 
 def point_losses_available(logits: torch.Tensor) -> bool:
@@ -357,6 +363,13 @@ def point_losses(logits, offsets, labels, gt_offsets, instance_labels, ignore_in
     """-> [4] = (focal loss, dice loss, offset L1 loss, offset direction loss) exactly as network/model.py:177-226 computes
     them from ~70 torch ops (focal_loss + dice_loss + loss_offset); one launch forward, one backward"""
     return _PointLossesFn.apply(logits, offsets, labels, gt_offsets, instance_labels, int(ignore_index))
+
+
+def point_losses_with_metrics(logits, offsets, labels, gt_offsets, instance_labels, ignore_index: int = -100):
+    """``point_losses`` plus the by-products of the logits the step needs anyway, from the same pass: -> (losses [4],
+    sem_preds [M] i64 = torch.argmax(logits, -1), accu [2] = ((sem_preds == labels).sum().float() / M,
+    ((sem_preds == labels) & (labels > 0)).sum() / (labels > 0).sum()) - network/model.py:531-541)"""
+    return _PointLossesFn.apply(logits, offsets, labels, gt_offsets, instance_labels, int(ignore_index), True)
 
 
 class _SegmentedMaxpoolFn(torch.autograd.Function):

@@ -497,8 +497,10 @@ def conv_wgrad(features, dout, rb: Rulebook, layout="kio"):
 
 
 # ---------------------------------------------------------------------------------------------------- P
-def point_losses_fwd(logits, labels, offsets, gt_offsets, instance_labels, ignore_index):
-    """-> (losses [4] f32 = focal, dice, offset distance, offset direction; stats = opaque device block for the backward)"""
+def point_losses_fwd(logits, labels, offsets, gt_offsets, instance_labels, ignore_index, metrics=False):
+    """-> (losses [4] f32 = focal, dice, offset distance, offset direction; stats = opaque device block for the backward);
+    ``metrics``: also (preds [M] i64 = argmax of the logits, accu [2] f32 = point accuracy over all points / over the points
+    on a part) from the same pass (gpn_point_losses_fwd_metrics)"""
     dev = _dev(logits, offsets)
     logits, offsets, gt_offsets = _c(logits, torch.float32), _c(offsets, torch.float32), _c(gt_offsets, torch.float32)
     labels, instance_labels = _c(labels, torch.int64), _c(instance_labels, torch.int32)
@@ -507,6 +509,13 @@ def point_losses_fwd(logits, labels, offsets, gt_offsets, instance_labels, ignor
     stats = torch.empty((4,), dtype=torch.float64, device=dev)
     L = _C.lib()
     ws = _ws(L.gpn_point_losses_ws_bytes(i64(M)), dev)
+    if metrics:
+        preds = torch.empty((M,), dtype=torch.int64, device=dev)
+        accu = torch.empty((2,), dtype=torch.float32, device=dev)
+        check(L.gpn_point_losses_fwd_metrics(ptr(logits), ptr(labels), ptr(offsets), ptr(gt_offsets), ptr(instance_labels), i64(M),
+                                             i32(C), i64(ignore_index), ptr(losses), ptr(preds), ptr(accu), ptr(stats), ptr(ws),
+                                             szt(ws.numel()), _stream()), "gpn_point_losses_fwd_metrics")
+        return losses, stats, preds, accu
     check(L.gpn_point_losses_fwd(ptr(logits), ptr(labels), ptr(offsets), ptr(gt_offsets), ptr(instance_labels), i64(M),
                                  i32(C), i64(ignore_index), ptr(losses), ptr(stats), ptr(ws), szt(ws.numel()), _stream()),
           "gpn_point_losses_fwd")

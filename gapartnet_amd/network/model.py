@@ -503,27 +503,31 @@ class GAPartNet(LightningModule):
 
         # semantic segmentation + centre offsets
         sem_logits = self.forward_sem_seg(pc_feature)
-        sem_preds = torch.argmax(sem_logits.detach(), dim=-1)
         offsets_preds = self.forward_offset(pc_feature)
         if instance_regions is None:
             raise RuntimeError("batch carries no instance_regions (the reference stops in pdb here, model.py:525)")
         gt_offsets = instance_regions[:, :3] - pt_xyz
+        sem_preds = all_accu = pixel_accu = None
         if (sem_labels is not None and self.use_sem_focal_loss and self.use_sem_dice_loss
                 and GF.point_losses_available(sem_logits)):
-            # loss_sem_seg (focal + dice) and loss_offset (distance, direction) of all points in one fused pass
-            fused = GF.point_losses(sem_logits, offsets_preds, sem_labels, gt_offsets, instance_labels,
-                                    self.ignore_sem_label)
+            # loss_sem_seg (focal + dice) and loss_offset (distance, direction) of all points in one fused pass, which also
+            # emits the predicted classes and the two accuracies (argmax + ten small torch launches otherwise)
+            fused, sem_preds, accu = GF.point_losses_with_metrics(sem_logits, offsets_preds, sem_labels, gt_offsets,
+                                                                  instance_labels, self.ignore_sem_label)
             loss_sem_seg = fused[0] + fused[1]
             loss_offset_dist, loss_offset_dir = fused[2], fused[3]
+            all_accu, pixel_accu = accu[0], accu[1]
         else:
+            sem_preds = torch.argmax(sem_logits.detach(), dim=-1)
             loss_sem_seg = self.loss_sem_seg(sem_logits, sem_labels) if sem_labels is not None else 0.0
             loss_offset_dist, loss_offset_dir = self.loss_offset(offsets_preds, gt_offsets, sem_labels, instance_labels)
-        all_accu = (sem_preds == sem_labels).sum().float() / sem_labels.shape[0]
-        if sem_labels is not None:
-            on_part = sem_labels > 0  # pixel_accuracy(sem_preds[on_part], sem_labels[on_part]) without the host syncs
-            pixel_accu = ((sem_preds == sem_labels) & on_part).sum() / on_part.sum()
-        else:
-            pixel_accu = 0.0
+        if all_accu is None:
+            all_accu = (sem_preds == sem_labels).sum().float() / sem_labels.shape[0]
+            if sem_labels is not None:
+                on_part = sem_labels > 0  # pixel_accuracy(sem_preds[on_part], sem_labels[on_part]) without the host syncs
+                pixel_accu = ((sem_preds == sem_labels) & on_part).sum() / on_part.sum()
+            else:
+                pixel_accu = 0.0
         sem_seg = Segmentation(batch_size=batch_size, sem_preds=sem_preds, sem_labels=sem_labels, all_accu=all_accu,
                                pixel_accu=pixel_accu)
 

@@ -470,6 +470,12 @@ size_t gpn_point_losses_ws_bytes(int64_t M);
 int gpn_point_losses_fwd(const float* logits, const int64_t* labels, const float* offsets, const float* gt_offsets,
                          const int32_t* instance_labels, int64_t M, int C, int64_t ignore_index, float* losses,
                          void* stats, void* ws, size_t ws_bytes, gpn_stream_t stream);
+/* the same with the step's by-products of the logits: preds [M] i64 = the predicted class of every point (first maximum, as
+ * torch.argmax), accu [2] f32 = (share of points with preds == labels, the same share among the points with labels > 0; both
+ * as fp32 quotients of the exact counts - network/model.py:535-541) */
+int gpn_point_losses_fwd_metrics(const float* logits, const int64_t* labels, const float* offsets, const float* gt_offsets,
+                                 const int32_t* instance_labels, int64_t M, int C, int64_t ignore_index, float* losses,
+                                 int64_t* preds, float* accu, void* stats_out, void* ws, size_t ws_bytes, gpn_stream_t stream);
 int gpn_point_losses_bwd(const float* logits, const int64_t* labels, const float* offsets, const float* gt_offsets,
                          const int32_t* instance_labels, int64_t M, int C, int64_t ignore_index, const void* stats,
                          const float* grad_losses, float* d_logits, float* d_offsets, gpn_stream_t stream);

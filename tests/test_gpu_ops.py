@@ -938,3 +938,26 @@ def test_copy_many_segments_in_one_launch(H, cuda):
     dst2 = torch.zeros(6, 8, device=cuda)
     optim._copy_many([dst2, dsts[4]], [src2, srcs[5][:4097]])
     assert torch.equal(dst2, src2) and torch.equal(dsts[4], srcs[5][:4097])
+
+
+def test_point_losses_emit_predictions_and_accuracies(H, cuda):
+    """gpn_point_losses_fwd_metrics: the losses of gpn_point_losses_fwd bit for bit, plus torch.argmax of the logits (first
+    maximum on ties) and the two accuracies exactly as network/model.py:535-541 forms them"""
+    rng = np.random.default_rng(11)
+    M, C = 5000, 10
+    logits = torch.from_numpy(rng.normal(size=(M, C)).astype(np.float32)).to(cuda)
+    logits[::7, 3] = logits[::7].max(dim=1).values  # ties: the first maximum wins
+    labels = torch.from_numpy(rng.integers(0, C, size=M)).to(cuda)
+    labels[::5] = 0
+    off = torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)).to(cuda)
+    gt = torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)).to(cuda)
+    inst = torch.from_numpy(rng.integers(-1, 6, size=M).astype(np.int32)).to(cuda)
+    base, _ = H.point_losses_fwd(logits, labels, off, gt, inst, -100)
+    losses, _, preds, accu = H.point_losses_fwd(logits, labels, off, gt, inst, -100, metrics=True)
+    assert torch.equal(losses, base)
+    want = torch.argmax(logits, dim=-1)
+    assert preds.dtype == torch.int64 and torch.equal(preds, want)
+    all_accu = (want == labels).sum().float() / M
+    on_part = labels > 0
+    pixel_accu = ((want == labels) & on_part).sum() / on_part.sum()
+    assert torch.equal(accu[0], all_accu) and torch.equal(accu[1], pixel_accu)
