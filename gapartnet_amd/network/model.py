@@ -514,9 +514,10 @@ class GAPartNet(LightningModule):
             # emits the predicted classes and the two accuracies (argmax + ten small torch launches otherwise)
             fused, sem_preds, accu = GF.point_losses_with_metrics(sem_logits, offsets_preds, sem_labels, gt_offsets,
                                                                   instance_labels, self.ignore_sem_label)
-            loss_sem_seg = fused[0] + fused[1]
-            loss_offset_dist, loss_offset_dir = fused[2], fused[3]
-            all_accu, pixel_accu = accu[0], accu[1]
+            # (unbind, not four selects: its backward is one stack instead of four zero-filled [4] tensors and their sums)
+            focal, dice, loss_offset_dist, loss_offset_dir = fused.unbind(0)
+            loss_sem_seg = focal + dice
+            all_accu, pixel_accu = accu.unbind(0)
         else:
             sem_preds = torch.argmax(sem_logits.detach(), dim=-1)
             loss_sem_seg = self.loss_sem_seg(sem_logits, sem_labels) if sem_labels is not None else 0.0
