@@ -34,7 +34,7 @@ def _counts_of(base, batch, cuda):
     return list(probe._prop_plan)
 
 
-@pytest.mark.parametrize("n_scenes,n_points", [(2, 5000), (8, 20000)])
+@pytest.mark.parametrize("n_scenes,n_points", [(2, 5000), (8, 20000), (4, 50000)])  # (the last two: BASELINE configs 3 and 4 as the bench runs them)
 def test_sync_free_step_with_the_exact_plan_is_bit_equal(cuda, n_scenes, n_points):
     batch = [pc.to(cuda) for pc in make_batch(n_scenes, n_points, seed0=640)]
     base = make_model((0, 0), channels=[16, 32, 48] if n_points < 10000 else None).to(cuda)
