@@ -296,6 +296,250 @@ __global__ __launch_bounds__(kThreads) void prop_finish_kernel(const int32_t* __
   if (t < counts[kM] && pc_voxel_id[t] < 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[kDropped]), 1ull);
 }
 
+// ---- re-voxelisation of the proposals without a sort (round 4) -----------------------------------------------------------------
+// What gpn_voxelize_ex computes for the proposal points - unique (proposal, x, y, z) cells in ascending key order, every
+// point's voxel, the points grouped by voxel in ascending point order (CSR), points outside their grid behind all others -
+// from ~27 launches (64-bit keys, rocPRIM's merge sort of the 2 N bound, flags, scan, emit, mean) in three: the points arrive
+// grouped by proposal, and a proposal's grid (fullscale + 1)^3 cells = 24 389 for the reference's 28 fits one workgroup's LDS.
+//   count: per proposal a cell bitmap in LDS -> its number of voxels and of points outside the grid;
+//   scan:  one workgroup: exclusive sums over the proposals -> first voxel / first position / first dropped position of each;
+//   place: per proposal the bitmap again, points per cell (LDS atomics: integers), popcount prefix of the bitmap = rank of a
+//          cell among the proposal's voxels (the stride-2 rulebook's trick, rulebook.hip), exclusive sum of the cell counts =
+//          first position of a cell; then the points in order, 256 at a time: position = cell start + points of the cell in
+//          earlier chunks + earlier points of the cell in this chunk (stable, no sort).
+// Bit-equal to the sort path (tests/test_gpu_proposals.py compare both with the oracle).  GPN_PROPOSALS_REVOX=0 / a grid of
+// more than kRevoxMaxCells cells: the sort path.
+constexpr int kRevoxMaxCells = 32768;  // (fullscale <= 30)
+constexpr int kRevoxWords = kRevoxMaxCells / 32;
+
+struct RevoxCell {
+  int cell;  // linear cell of the point inside its proposal's grid, or -1: outside (dropped)
+};
+__device__ __forceinline__ int revox_cell(const float* __restrict__ scaled, int64_t m, float full, int D) {
+  // (vox_keys_kernel's test and arithmetic with range [0, full), voxel size 1)
+  int c[3];
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float p = scaled[m * 3 + a];
+    ok = ok && (p >= 0.0f) && (p < full);
+    const int ci = (int)floorf(__fdiv_rn(__fsub_rn(p, 0.0f), 1.0f));
+    ok = ok && ci >= 0 && ci < D;
+    c[a] = ci;
+  }
+  return ok ? (c[0] * D + c[1]) * D + c[2] : -1;
+}
+
+__global__ __launch_bounds__(kThreads) void revox_count_kernel(const float* __restrict__ scaled,
+                                                               const int32_t* __restrict__ proposal_offsets,
+                                                               const int64_t* __restrict__ counts, float full, int D,
+                                                               int32_t* __restrict__ n_vox, int32_t* __restrict__ n_out) {
+  __shared__ uint32_t bm[kRevoxWords];
+  __shared__ int acc[2];
+  const int words = (D * D * D + 31) >> 5;
+  const int64_t P = counts[kP];
+  for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+    for (int w = threadIdx.x; w < words; w += kThreads) bm[w] = 0u;
+    if (threadIdx.x < 2) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t b = proposal_offsets[p], e = proposal_offsets[p + 1];
+    int outside = 0;
+    for (int64_t m = b + threadIdx.x; m < e; m += kThreads) {
+      const int cell = revox_cell(scaled, m, full, D);
+      if (cell >= 0) atomicOr(&bm[cell >> 5], 1u << (cell & 31));
+      else ++outside;
+    }
+    if (outside) atomicAdd(&acc[1], outside);
+    __syncthreads();
+    int bits = 0;
+    for (int w = threadIdx.x; w < words; w += kThreads) bits += __builtin_popcount(bm[w]);
+    if (bits) atomicAdd(&acc[0], bits);
+    __syncthreads();
+    if (threadIdx.x == 0) n_vox[p] = acc[0], n_out[p] = acc[1];
+    __syncthreads();
+  }
+}
+
+// exclusive sums over the proposals (one workgroup of 1024): first voxel, first position among the kept points, first
+// position among the dropped ones; totals -> counts[kV], vstart[V] (= number of kept points: where the dropped ones begin)
+__global__ __launch_bounds__(1024) void revox_scan_kernel(const int32_t* __restrict__ proposal_offsets, int64_t* __restrict__ counts,
+                                                          const int32_t* __restrict__ n_vox, const int32_t* __restrict__ n_out,
+                                                          int32_t* __restrict__ vox_base, int32_t* __restrict__ kept_base,
+                                                          int32_t* __restrict__ out_base, int32_t* __restrict__ vstart) {
+  __shared__ int part[3][1024];
+  __shared__ int carry[3];
+  const int t = threadIdx.x;
+  const int64_t P = counts[kP];
+  if (t < 3) carry[t] = 0;
+  __syncthreads();
+  for (int64_t p0 = 0; p0 < P; p0 += 1024) {
+    const int64_t p = p0 + t;
+    int v[3] = {0, 0, 0};
+    if (p < P) {
+      const int size = proposal_offsets[p + 1] - proposal_offsets[p];
+      v[0] = n_vox[p], v[2] = n_out[p], v[1] = size - v[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) part[k][t] = v[k];
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele over the chunk
+      int add[3] = {0, 0, 0};
+      if (t >= off) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) add[k] = part[k][t - off];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 3; ++k) part[k][t] += add[k];
+      __syncthreads();
+    }
+    if (p < P) {
+      vox_base[p] = carry[0] + part[0][t] - v[0];
+      kept_base[p] = carry[1] + part[1][t] - v[1];
+      out_base[p] = carry[2] + part[2][t] - v[2];
+    }
+    __syncthreads();
+    if (t < 3) carry[t] += part[t][1023];
+    __syncthreads();
+  }
+  if (t == 0) {
+    counts[kV] = carry[0];
+    vstart[carry[0]] = carry[1];
+    kept_base[P] = carry[1];  // (total of kept points, read by the place kernel)
+  }
+}
+
+// exclusive prefix of one value per thread over the workgroup's 256 threads (+ the total): wave shuffles, then the 4 wave totals
+__device__ __forceinline__ int revox_thread_scan(int v, int* wave_tot /* [4] */, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int before = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) before += w < wave ? wave_tot[w] : 0;
+  total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  __syncthreads();
+  return before + incl - v;
+}
+// in-place exclusive sum of a[0 .. n) in LDS by the workgroup (a contiguous run per thread); returns the total
+__device__ __forceinline__ int revox_block_scan(int* a, int n, int* wave_tot) {
+  const int t = threadIdx.x;
+  const int run_len = (n + kThreads - 1) / kThreads;
+  const int b = min(t * run_len, n), e = min(b + run_len, n);
+  int s = 0;
+  for (int i = b; i < e; ++i) s += a[i];
+  int total;
+  int run = revox_thread_scan(s, wave_tot, total);
+  for (int i = b; i < e; ++i) {
+    const int c = a[i];
+    a[i] = run;
+    run += c;
+  }
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(kThreads) void revox_place_kernel(const float* __restrict__ scaled,
+                                                               const int32_t* __restrict__ proposal_offsets,
+                                                               const int64_t* __restrict__ counts, float full, int D, int64_t T2,
+                                                               const int32_t* __restrict__ vox_base, const int32_t* __restrict__ kept_base,
+                                                               const int32_t* __restrict__ out_base, int32_t* __restrict__ vc3,
+                                                               int32_t* __restrict__ vseg, int32_t* __restrict__ pc_voxel_id,
+                                                               int32_t* __restrict__ point_order, int32_t* __restrict__ vstart) {
+  // per VOXEL of the proposal (rank of its cell among the proposal's occupied cells; what a proposal touches scales with its
+  // points, not with the 24k cells of its grid): points, then first position, then cursor; [n_vox] = the dropped points
+  __shared__ int cur[kRevoxMaxCells + 1];
+  __shared__ uint32_t bm[kRevoxWords];
+  __shared__ int wprefix[kRevoxWords];  // voxels of the proposal in earlier bitmap words
+  __shared__ int wave_tot[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cells = D * D * D, words = (cells + 31) >> 5;
+  const int64_t P = counts[kP], T = counts[kM];
+  const int kept_total = kept_base[P];
+  auto local_voxel = [&](int cell) {
+    const uint32_t word = bm[cell >> 5];
+    return wprefix[cell >> 5] + __builtin_popcount(word & ((1u << (cell & 31)) - 1u));
+  };
+  for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+    for (int w = t; w < words; w += kThreads) bm[w] = 0u;
+    __syncthreads();
+    const int64_t b = proposal_offsets[p], e = proposal_offsets[p + 1];
+    for (int64_t m = b + t; m < e; m += kThreads) {
+      const int cell = revox_cell(scaled, m, full, D);
+      if (cell >= 0) atomicOr(&bm[cell >> 5], 1u << (cell & 31));
+    }
+    __syncthreads();
+    for (int w = t; w < words; w += kThreads) wprefix[w] = __builtin_popcount(bm[w]);
+    __syncthreads();
+    const int n_vox = revox_block_scan(wprefix, words, wave_tot);
+    for (int v = t; v <= n_vox; v += kThreads) cur[v] = 0;
+    __syncthreads();
+    for (int64_t m = b + t; m < e; m += kThreads) {
+      const int cell = revox_cell(scaled, m, full, D);
+      atomicAdd(&cur[cell >= 0 ? local_voxel(cell) : n_vox], 1);
+    }
+    __syncthreads();
+    revox_block_scan(cur, n_vox, wave_tot);  // (cur[n_vox], the dropped points' count, is not part of the sum)
+    if (t == 0) cur[n_vox] = 0;
+    const int vb = vox_base[p], kb = kept_base[p], ob = kept_total + out_base[p];
+    for (int w = t; w < words; w += kThreads) {  // the proposal's voxels: first position, coordinates
+      uint32_t word = bm[w];
+      int vid = vb + wprefix[w];
+      while (word) {
+        const int bit = __builtin_ctz(word);
+        word &= word - 1u;
+        const int c = w * 32 + bit;
+        vstart[vid] = kb + cur[vid - vb];
+        vc3[(int64_t)vid * 3 + 2] = c % D;
+        vc3[(int64_t)vid * 3 + 1] = (c / D) % D;
+        vc3[(int64_t)vid * 3 + 0] = c / (D * D);
+        vseg[vid] = (int32_t)p;
+        ++vid;
+      }
+    }
+    __syncthreads();
+    // the proposal's points in order, 256 at a time, the four waves one after the other: position = first position of the
+    // voxel + its points so far (cursor) + earlier lanes of this wave in the same voxel (ballots over the key's bits)
+    for (int64_t m0 = b; m0 < e; m0 += kThreads) {
+      const int64_t m = m0 + t;
+      int key = -1;  // no point
+      if (m < e) {
+        const int cell = revox_cell(scaled, m, full, D);
+        key = cell >= 0 ? local_voxel(cell) : n_vox;
+      }
+      uint64_t same = __builtin_amdgcn_ballot_w64(key >= 0);
+#pragma unroll
+      for (int bit = 0; bit < 16; ++bit) {  // (keys < 2^15 + 1)
+        const uint64_t has = __builtin_amdgcn_ballot_w64(((key >> bit) & 1) != 0);
+        same &= ((key >> bit) & 1) ? has : ~has;
+      }
+      const int earlier = __builtin_popcountll(same & ((1ull << lane) - 1ull));
+      const int group = __builtin_popcountll(same);
+      for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv && key >= 0) {
+          const int base = cur[key];
+          const int pos = (key < n_vox ? kb : ob) + base + earlier;
+          point_order[pos] = (int32_t)m;
+          pc_voxel_id[m] = key < n_vox ? vb + key : -1;
+          if (earlier == 0) cur[key] = base + group;  // (the wave's lanes have read `base`: one instruction stream)
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // rows behind the last proposal (the buffers' bound): dropped, in their own order behind everything else
+  for (int64_t m = T + (int64_t)blockIdx.x * kThreads + t; m < T2; m += (int64_t)gridDim.x * kThreads) {
+    point_order[m] = (int32_t)m;
+    pc_voxel_id[m] = -1;
+  }
+}
+
 // ---- differentiable per-voxel mean of gathered point features --------------------------------------------------------
 // out[v, c] = mean over the voxel's points (CSR order = ascending proposal-point index) of feats[point_indices[m], c]:
 // ordered fp32 sum then one division - what kernel V computes on the gathered features (voxelize.hip vox_mean_kernel)
@@ -356,7 +600,7 @@ __global__ __launch_bounds__(kThreads) void prop_voxel_mean_bwd_kernel(const flo
 
 struct PropWs {
   int32_t *lab, *flag, *rank, *scene_off, *cnt, *begin_end, *la, *lb, *start, *incl, *run_pos, *run_size, *keep_run, *new_pid,
-      *keep_elem, *slot, *vc3, *vseg, *nbr, *cnt2, *begin_end2, *nbr2;
+      *keep_elem, *slot, *vc3, *vseg, *nbr, *cnt2, *begin_end2, *nbr2, *rv_nvox, *rv_nout, *rv_vbase, *rv_kbase, *rv_obase;
   uint32_t *keys, *skeys, *vals, *svals;
   float *xyz, *xyz_shift, *mean, *scale, *shift, *scaled, *rmin, *rmax, *vf;
   int64_t* seg64;
@@ -391,6 +635,8 @@ PropWs carve(void* ws, size_t ws_bytes, int64_t N, int64_t B, int Kmax, int64_t 
   o.mean = w.take<float>(3 * pu), o.scale = w.take<float>(pu), o.shift = w.take<float>(3 * pu);
   o.scaled = w.take<float>(3 * t2), o.rmin = w.take<float>(3 * pu), o.rmax = w.take<float>(3 * pu), o.vf = w.take<float>(3 * t2);
   o.seg64 = w.take<int64_t>(pu);
+  o.rv_nvox = w.take<int32_t>(pu + 1), o.rv_nout = w.take<int32_t>(pu + 1), o.rv_vbase = w.take<int32_t>(pu + 1);
+  o.rv_kbase = w.take<int32_t>(pu + 1), o.rv_obase = w.take<int32_t>(pu + 1);  // sort-free re-voxelisation: per-proposal counts / bases
   o.nbr = w.take<int32_t>(n * (size_t)Kmax);
   o.nbr2 = w.take<int32_t>(n * (size_t)Kmax), o.cnt2 = w.take<int32_t>(n), o.begin_end2 = w.take<int32_t>(2 * n);  // second cluster set (own stream)
   o.prim_bytes = prim_bytes_for((int64_t)t2);
@@ -435,6 +681,28 @@ ForkLane* fork_lane() {
 }
 
 inline int grid_of(int64_t n) { return (int)gpn::cdiv(n > 0 ? n : 1, kThreads); }
+
+bool revox_fits(float fullscale) {
+  const int64_t D = (int64_t)fullscale + 1;
+  return fullscale >= 1.0f && D * D * D <= kRevoxMaxCells;
+}
+int revoxelize(const float* scaled, const int32_t* proposal_offsets, int64_t* counts, int64_t T2, int64_t P_ub, float fullscale,
+               int32_t* vc3, int32_t* vseg, int32_t* pc_voxel_id, int32_t* point_order, int32_t* vstart, int32_t* n_vox,
+               int32_t* n_out, int32_t* vox_base, int32_t* kept_base, int32_t* out_base, hipStream_t stream) {
+  const int D = (int)fullscale + 1;
+  const int64_t pw = P_ub > 0 ? P_ub : 1;
+  hipLaunchKernelGGL(revox_count_kernel, dim3((unsigned)std::min<int64_t>(pw, 2048)), dim3(kThreads), 0, stream, scaled,
+                     proposal_offsets, counts, fullscale, D, n_vox, n_out);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(revox_scan_kernel, dim3(1), dim3(1024), 0, stream, proposal_offsets, counts, n_vox, n_out, vox_base, kept_base,
+                     out_base, vstart);
+  GPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(revox_place_kernel, dim3((unsigned)std::min<int64_t>(std::max<int64_t>(pw, 256), 512)), dim3(kThreads), 0, stream,
+                     scaled, proposal_offsets, counts, fullscale, D, T2, vox_base, kept_base, out_base, vc3, vseg, pc_voxel_id,
+                     point_order, vstart);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
 
 }  // namespace
 
@@ -554,13 +822,23 @@ extern "C" int gpn_proposals_build(const float* points, int point_stride, const 
   hipLaunchKernelGGL(prop_scale_points_kernel, dim3(grid_of(T2)), dim3(kThreads), 0, stream, pt_xyz_p, proposal_indices, counts,
                      o.mean, o.scale, o.shift, T2, o.scaled);
   GPN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(prop_ranges_kernel, dim3(grid_of(P_ub * 3)), dim3(kThreads), 0, stream, P_ub, fullscale, o.rmin, o.rmax);
-  GPN_CHECK_LAUNCH();
-  const float vs[3] = {1.0f, 1.0f, 1.0f};
-  const int32_t dims[3] = {(int32_t)fullscale + 1, (int32_t)fullscale + 1, (int32_t)fullscale + 1};
-  int rc = gpn_voxelize_ex(o.scaled, o.scaled, o.seg64, o.rmin, o.rmax, T2, 3, P_ub, vs, dims, o.vf, o.vc3, o.vseg, pc_voxel_id,
-                           counts + kV, point_order, voxel_point_start, o.sub, o.sub_bytes, stream_);
-  if (rc) return rc;
+  static const bool revox_enabled = [] {  // GPN_PROPOSALS_REVOX=0: the sort-based voxeliser (A/B switch)
+    const char* e = getenv("GPN_PROPOSALS_REVOX");
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (revox_enabled && revox_fits(fullscale)) {
+    int rc = revoxelize(o.scaled, proposal_offsets, counts, T2, P_ub, fullscale, o.vc3, o.vseg, pc_voxel_id, point_order,
+                        voxel_point_start, o.rv_nvox, o.rv_nout, o.rv_vbase, o.rv_kbase, o.rv_obase, stream);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(prop_ranges_kernel, dim3(grid_of(P_ub * 3)), dim3(kThreads), 0, stream, P_ub, fullscale, o.rmin, o.rmax);
+    GPN_CHECK_LAUNCH();
+    const float vs[3] = {1.0f, 1.0f, 1.0f};
+    const int32_t dims[3] = {(int32_t)fullscale + 1, (int32_t)fullscale + 1, (int32_t)fullscale + 1};
+    int rc = gpn_voxelize_ex(o.scaled, o.scaled, o.seg64, o.rmin, o.rmax, T2, 3, P_ub, vs, dims, o.vf, o.vc3, o.vseg, pc_voxel_id,
+                             counts + kV, point_order, voxel_point_start, o.sub, o.sub_bytes, stream_);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(prop_finish_kernel, dim3(grid_of(T2)), dim3(kThreads), 0, stream, o.vc3, o.vseg, pc_voxel_id, T2,
                      voxel_coords4, counts);
   GPN_CHECK_LAUNCH();
@@ -619,4 +897,30 @@ extern "C" int gpn_proposals_voxel_mean_bwd(const float* dout, const int32_t* me
                      pc_voxel_id, voxel_point_start, N, C, dfeats);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
+}
+
+// The re-voxelisation step of gpn_proposals_build on its own (tests; include/gpn.h): counts[1] = points, counts[2] = proposals
+// (inputs, on the device), counts[3] = voxels (output).  ws: 5 x (P_ub + 2) int32.
+extern "C" size_t gpn_proposals_revoxelize_ws_bytes(int64_t P_ub) {
+  gpn::WsCarver w(nullptr, 0);
+  for (int k = 0; k < 5; ++k) w.take<int32_t>((size_t)(P_ub > 0 ? P_ub : 1) + 2);
+  return w.used;
+}
+extern "C" int gpn_proposals_revoxelize(const float* scaled, const int32_t* proposal_offsets, int64_t* counts, int64_t T2, int64_t P_ub,
+                                        float fullscale, int32_t* voxel_coords3, int32_t* voxel_seg, int32_t* pc_voxel_id,
+                                        int32_t* point_order, int32_t* voxel_point_start, void* ws, size_t ws_bytes,
+                                        gpn_stream_t stream_) {
+  GPN_CHECK_ARG(T2 >= 1 && P_ub >= 1 && scaled && proposal_offsets && counts);
+  GPN_CHECK_ARG(voxel_coords3 && voxel_seg && pc_voxel_id && point_order && voxel_point_start);
+  if (!revox_fits(fullscale)) {
+    gpn::set_error("gpn_proposals_revoxelize: a grid of (%d + 1)^3 cells does not fit one workgroup's LDS (max %d cells)", (int)fullscale,
+                   kRevoxMaxCells);
+    return GPN_ERR_ARG;
+  }
+  gpn::WsCarver w(ws, ws_bytes);
+  int32_t* a[5];
+  for (int k = 0; k < 5; ++k) a[k] = w.take<int32_t>((size_t)P_ub + 2);
+  GPN_CHECK_WS(w);
+  return revoxelize(scaled, proposal_offsets, counts, T2, P_ub, fullscale, voxel_coords3, voxel_seg, pc_voxel_id, point_order,
+                    voxel_point_start, a[0], a[1], a[2], a[3], a[4], (hipStream_t)stream_);
 }

@@ -534,6 +534,17 @@ int gpn_proposals_build(const float* points, int point_stride, const float* offs
                         int32_t* sem_preds_p, int32_t* instance_labels_p, int64_t* sizes, int32_t* proposal_offsets,
                         int32_t* member_slot, int32_t* voxel_coords4, int32_t* pc_voxel_id, int32_t* point_order,
                         int32_t* voxel_point_start, void* ws, size_t ws_bytes, gpn_stream_t stream);
+/* the re-voxelisation step of gpn_proposals_build on its own: the points of the proposals (grouped by proposal, ascending
+ * point order inside one; scaled [T2,3] = coordinates in the proposal's grid of (fullscale + 1)^3 unit cells, kept when
+ * 0 <= c < fullscale on every axis) -> what gpn_voxelize_ex gives for them with the proposals as segments - unique cells in
+ * (proposal, x, y, z) order, voxel of every point (-1 = outside its grid), points grouped by voxel in ascending point order
+ * (point_order [T2], voxel_point_start [V + 1]; the dropped points behind all others) - WITHOUT a sort: one workgroup per
+ * proposal keeps the grid's bitmap and per-cell counts in LDS.  counts = the stage's count block on the device: [1] = points
+ * and [2] = proposals are read, [3] = voxels is written.  fullscale <= 30. */
+size_t gpn_proposals_revoxelize_ws_bytes(int64_t P_ub);
+int gpn_proposals_revoxelize(const float* scaled, const int32_t* proposal_offsets, int64_t* counts, int64_t T2, int64_t P_ub,
+                             float fullscale, int32_t* voxel_coords3, int32_t* voxel_seg, int32_t* pc_voxel_id,
+                             int32_t* point_order, int32_t* voxel_point_start, void* ws, size_t ws_bytes, gpn_stream_t stream);
 int gpn_proposals_voxel_mean(const float* feats, const int64_t* point_indices, const int32_t* point_order,
                              const int32_t* voxel_point_start, int64_t V, int C, float* out, gpn_stream_t stream);
 int gpn_proposals_voxel_mean_bwd(const float* dout, const int32_t* member_slot, const int32_t* pc_voxel_id,

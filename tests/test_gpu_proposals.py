@@ -121,3 +121,49 @@ def test_fused_npcs_loss_equals_the_torch_formulation(cuda, n_props, seed):
     assert torch.equal(v0, v1)
     assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)), (l0, l1)
     assert torch.allclose(g0, g1, rtol=1e-4, atol=1e-7), float((g0 - g1).abs().max())
+
+
+@pytest.mark.parametrize("seed,full", [(0, 28.0), (1, 28.0), (2, 7.0)])
+def test_revoxelisation_without_a_sort_equals_the_sorting_voxeliser(cuda, seed, full):
+    """gpn_proposals_revoxelize (one workgroup per proposal: LDS bitmap, popcount ranks, stable placement) against
+    gpn_voxelize_ex (keys + radix sort) on the same grouped points: unique cells, voxel of every point, point order, CSR -
+    with points outside their grid, many points per cell, proposals of 1 ... 3000 points, empty tail rows, unused proposal
+    slots"""
+    import ctypes
+    from gapartnet_amd import _C, hip_ops as H
+    rng = np.random.default_rng(seed)
+    sizes = [1, 5, 7, 3000, 257, 256, 255, 64, 1000] + [int(n) for n in rng.integers(5, 400, size=40)]
+    P, T = len(sizes), int(sum(sizes))
+    P_ub, T2 = P + 23, T + 517
+    off = np.full(P_ub + 1, T, np.int64)
+    off[:P + 1] = np.concatenate([[0], np.cumsum(sizes)])
+    xyz = rng.uniform(-0.5, full + 0.5, size=(T2, 3)).astype(np.float32)     # some points leave their grid
+    xyz[off[3]:off[3] + 1500] = np.float32(3.25)                               # 1500 points in one cell
+    xyz[off[8]:off[9]] = np.floor(xyz[off[8]:off[9]] / 4) * 4 + 0.5           # few cells, many points each
+    xyz[T:] = -1.0
+    scaled = torch.from_numpy(xyz).to(cuda)
+    counts = torch.zeros(8, dtype=torch.int64, device=cuda)
+    counts[1], counts[2] = T, P
+    off32 = torch.from_numpy(off.astype(np.int32)).to(cuda)
+    vc = torch.full((T2, 3), -9, dtype=torch.int32, device=cuda)
+    vseg = torch.full((T2,), -9, dtype=torch.int32, device=cuda)
+    pid = torch.full((T2,), -9, dtype=torch.int32, device=cuda)
+    order = torch.full((T2,), -9, dtype=torch.int32, device=cuda)
+    vstart = torch.full((T2 + 1,), -9, dtype=torch.int32, device=cuda)
+    L = _C.lib()
+    ws = torch.empty((int(L.gpn_proposals_revoxelize_ws_bytes(H.i64(P_ub))),), dtype=torch.uint8, device=cuda)
+    rc = L.gpn_proposals_revoxelize(H.ptr(scaled), H.ptr(off32), H.ptr(counts), H.i64(T2), H.i64(P_ub), ctypes.c_float(full), H.ptr(vc),
+                                    H.ptr(vseg), H.ptr(pid), H.ptr(order), H.ptr(vstart), H.ptr(ws), H.szt(ws.numel()),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.gpn_last_error()
+    d = int(full) + 1
+    zero, top = torch.zeros(3, device=cuda), torch.full((3,), full, device=cuda)
+    _, rvc, rvseg, rpid, rorder, rvstart = H.voxelize(scaled, scaled, torch.from_numpy(off).to(cuda), zero, top, (1.0, 1.0, 1.0),
+                                                      (d, d, d), want_csr=True)
+    V = rvc.shape[0]
+    assert int(counts[3]) == V and V > 100
+    assert int((rpid < 0).sum()) > T2 - T, "the case needs points outside their grid inside proposals"
+    assert torch.equal(vc[:V], rvc) and torch.equal(vseg[:V], rvseg)
+    assert torch.equal(pid, rpid)
+    assert torch.equal(order, rorder)
+    assert torch.equal(vstart[:V + 1], rvstart)
