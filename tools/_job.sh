@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2 | cut -c1-250
-b() { env "$@" python bench.py --steps 60 --warmup 15 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],3), round(d['host']['cpu_ms_per_step'],2))"; }
-for r in 1 2 3 4; do b GPN_PROPOSALS_REVOX=0; b GPN_PROPOSALS_REVOX=1; done
+bash tools/final_measure_r04.sh
