@@ -1,4 +1,4 @@
-// spconv_tiles.hip — the masked-tile sparse convolution kernel (forward and dgrad launches) for gfx950, round 3.
+// spconv_tiles.hip — the masked-tile sparse convolution kernel (forward and dgrad launches) for gfx950 (round 3; tap loop round 4).
 //
 // Same arithmetic as the direct kernel of spconv_fwd.hip (output-stationary: MFMA row i of a 16-row tile IS destination row
 // i for every tap, fp32 accumulators in registers, every output row written once, no atomics, v_mfma_f32_16x16x4_f32),
@@ -13,20 +13,22 @@
 //     operand load of the same wave (the first version of this kernel did that: 1 us per tap).
 //   * main loop over the LIVE taps only (scalar bit scan, dynamic trip count; a dead tap costs nothing): per (tap, row tile)
 //     one ds_read of the offset and one v_add, per 16-channel input block R row-gathers + NT weight fragments (1 KiB from
-//     L2, shared by the R row tiles) feeding R x NT x 4 MFMAs.  Groups of U taps per iteration (~32 MFMAs), straight-line
-//     body with unconditional buffer loads (an absent neighbour reads at an out-of-range offset: zeros, no memory access),
-//     so the compiler interleaves loads and MFMAs and emits counted s_waitcnt; what latency remains is covered by the
-//     other waves of the SIMD (<= 64 VGPRs: 8 resident).
-//   * the rulebook's TILE ORDER (gpn_rulebook_tile_order: rows sorted by neighbour mask inside 4096-row blocks) makes the
+//     L2, shared by the R row tiles) feeding R x NT x 4 MFMAs.  Round 4: the loop is a RING of operand slots - the operands
+//     of 1 - 5 taps are requested ahead of the tap in the MFMAs (see "the tap loop" below); unconditional buffer loads (an
+//     absent neighbour reads at an out-of-range offset: zeros, no memory access), counted s_waitcnt; what latency remains
+//     is covered by the other waves of the SIMD.
+//   * the rulebook's TILE ORDER (gpn_rulebook_tile_order: rows sorted by neighbour mask inside 16384-row blocks) makes the
 //     rows of a tile share their taps: 2.4x (level 0) / 1.4x (levels 1, 2) the MFMA row-slots of the useful pairs instead
 //     of 4.3x / 2.2x / 2.0x in voxel order; a stride-2 / inverse conv drops from 4.4x to 1.0-1.3x.
 //   * a wave owns ONE row tile and NT (1..7) column tiles (the widest divisor of the layer's column tiles that still leaves
 //     ~1500 waves: cols_per_wave below).  R = 2 row tiles per wave - half the waves, a weight fragment shared by both - is
 //     implemented (template parameter) and measured 25-38 % slower at the 80k-row level: the kernel lives on the number of
 //     waves a SIMD interleaves.
-// (A hand-rolled register ring across loop iterations was tried first: hipcc 7.2 hoists the requests above the MFMAs that
-// still read the slot, gives them fresh registers and closes every iteration with s_waitcnt vmcnt(0) and a block of v_mov
-// copies - nothing stays in flight across iterations; scheduling barriers do not hold buffer loads back.)
+// (Round 3's first attempt at a register ring - a loop over slot indices - was undone by hipcc 7.2: requests hoisted above the
+// MFMAs that still read the slot, fresh registers, s_waitcnt vmcnt(0) and a block of v_mov copies per iteration.  The ring of
+// round 4 writes the slots out (compile-time slot indices) and puts a scheduling barrier after every request block.)
+// What a launch waits for, measured wave by wave (tools/probes/tiles_trace.py): the most loaded SIMD's MFMAs plus
+// a prologue and an epilogue that all waves go through together - not the gathers.
 // Summation order per output element = the direct kernel's: ascending tap, a tap's input blocks and channels in one MFMA
 // chain, the taps' sums added in fp32 (two-level); taps a row does not have add exact zeros, so the result does not depend
 // on the tile order, equals the direct kernel's bit for bit and is deterministic.
