@@ -13,7 +13,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxC = 64;        // cin, cout <= 64
-constexpr int kRowsPerWg = 512;  // rows a workgroup of the dW pass reduces
+constexpr int kRowsPerWg = 128;  // rows a workgroup of the dW pass reduces (round 4: 512 -> 128 - a pass over 10k rows had 20 workgroups
+                                 // for 256 CUs: 23.9 -> 14.6 us for 16 -> 27 channels, 104 -> 30 us for 4096 x 64 -> 64; unchanged at 160k rows)
 constexpr int kTileRows = 128;
 
 // thread = (row, j): outputs 4j .. 4j + 3 of that row.  W^T is staged in LDS ([ci][cout padded to 4]: the four outputs of a
