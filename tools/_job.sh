@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-bash tools/mini_measure.sh
-python -m pytest tests -m gpu -q 2>&1 | tail -1 | cut -c1-200
-for i in 1 2 3; do python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],3), round(d['value'],1), d['roofline']['frac_source'][:9])"; done
+b() { env "$@" python bench.py --steps 60 --warmup 15 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],3))"; }
+for r in 1 2 3; do b GPN_WGRAD_PARTIAL_MB=4; b GPN_WGRAD_PARTIAL_MB=8; b GPN_WGRAD_PARTIAL_MB=16; b GPN_WGRAD_PARTIAL_MB=8 GPN_WGRAD_TARGET_WGS=8192; b GPN_WGRAD_PARTIAL_MB=16 GPN_WGRAD_TARGET_WGS=8192 GPN_WGRAD_ROWS_PER_SLICE=64; done
