@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | cut -c1-300
-b() { env "$@" python bench.py --steps 60 --warmup 15 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],3))"; }
-for r in 1 2 3 4; do b GPN_BN_MASK_FROM_X=0; b GPN_BN_MASK_FROM_X=1; done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+for i in 1 2 3; do python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],3), round(d['value'],1))"; done
