@@ -294,12 +294,6 @@ def main():
     pool = [[pc.to(device) for pc in make_batch(args.batch, args.points, seed0=1000 + (2 * rank + j) * args.batch)]
             for j in range(2)]
     model.train()
-    # experiment switch: the whole run on a non-blocking stream of its own instead of the NULL stream (what a CU-masked
-    # weight-gradient stream needs next to it: GPN_WGRAD_CU_MASK, csrc/net.hip)
-    own_stream = torch.cuda.Stream(device) if os.environ.get("GPN_BENCH_STREAM") == "1" else None
-    if own_stream is not None:
-        torch.cuda.set_stream(own_stream)
-
     # batches are prepared (voxelised, rulebooks built) one step ahead on a second stream: the loader side of the path
     from gapartnet_amd.dataset.prefetch import DevicePrefetcher
     total_steps = args.warmup + args.steps + 1

@@ -679,7 +679,7 @@ int gpn::bn_fwd_train_rows(const float* x, const float* res, const float* weight
   GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
   GPN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   const int C4 = C / 4;
-  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (res ? 4 : 3));  // x twice (statistics, apply) [+ res], y
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (res ? 4 : 3), rows.dev, N);  // x twice (statistics, apply) [+ res], y
   if (Np <= kSmallRows && N < ((int64_t)1 << 31)) {
     // (the forward kernel stays at 256 threads: at 1024 it measured 51 us instead of 10 - every thread carries the
     // double-precision mean / 1/sqrt epilogue; the backward kernel, three streams and no epilogue, gains from 1024)
@@ -755,7 +755,7 @@ int gpn::bn_bwd_rows(const float* x, const float* y, const float* dy, const floa
   GPN_CHECK_ARG(x && dy && weight && mean && invstd && dx && dweight && dbias && ws && (y || !relu));
   GPN_CHECK_ARG(ws_bytes >= (size_t)kMaxBlocks * 2 * C * sizeof(double));
   const int C4 = C / 4;
-  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (7 + (dres ? 1 : 0)));  // x, y, dy twice each; dx [, dres]
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (7 + (dres ? 1 : 0)), rows.dev, N);  // x, y, dy twice each; dx [, dres]
   if (Np <= kSmallRows && N < ((int64_t)1 << 31)) {
     // few workgroups, each a serial chain of row loads: 1024 threads per workgroup keep the chain one batch long
     if (C4 % 4 == 0 && Np > 256)
@@ -820,7 +820,7 @@ int gpn::bn_fwd_train_fused(const gpn::BnFwdPtrs& p, const gpn::BnFwdPtrs* twin,
   GPN_CHECK_ARG(gpn::bn_two_pass(N, C));
   GPN_CHECK_ARG(!twin || (twin->res == nullptr) == (p.res == nullptr));
   const int64_t total4 = N * (C / 4);
-  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (p.res ? 3 : 2) * (twin ? 2 : 1));  // x [+ res] read, y written
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (p.res ? 3 : 2) * (twin ? 2 : 1), rows.dev, N);  // x [+ res] read, y written (N = the bound when rows.dev: scaled to the live rows by gpn_prof_get)
   const int64_t Np = gpn::plan_rows(N, rows);  // (slot sets in use: the same function of the plan the producing conv used)
   hipLaunchKernelGGL(bn_apply_fwd_fold_kernel<true>, dim3(fold_grid(Np * (C / 4)), twin ? 2 : 1), dim3(kApplyThreads), 0, stream, p,
                      twin ? *twin : p, gpn::stat_slot_count(Np), N, total4, C / 4, eps, momentum, relu, rows.dev);
@@ -837,7 +837,7 @@ int gpn::bn_bwd_fused(const gpn::BnBwdPtrs& p, const gpn::BnBwdPtrs* twin, int64
   GPN_CHECK_ARG(gpn::bn_two_pass(N, C));
   GPN_CHECK_ARG(!twin || (twin->dres == nullptr) == (p.dres == nullptr));
   const int64_t total4 = N * (C / 4);
-  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (4 + (p.dres ? 1 : 0)) * (twin ? 2 : 1));  // x, y, dy read; dx [, dres] written
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (4 + (p.dres ? 1 : 0)) * (twin ? 2 : 1), rows.dev, N);  // x, y, dy read; dx [, dres] written
   const int64_t Np = gpn::plan_rows(N, rows);
   hipLaunchKernelGGL(bn_apply_bwd_fold_kernel<true>, dim3(fold_grid(Np * (C / 4)), twin ? 2 : 1), dim3(kApplyThreads), 0, stream, p,
                      twin ? *twin : p, gpn::stat_slot_count(Np), total4, C / 4, 1.0f / (float)N, relu, training, rows.dev);

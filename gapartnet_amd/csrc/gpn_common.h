@@ -20,6 +20,10 @@ struct ProfScope {
   hipEvent_t start = nullptr;
   int64_t tag = 0;
   ProfScope(int kernel_id, hipStream_t s, double flops, double bytes, int64_t tag = 0);
+  // the same for a launch whose row count is a device counter: `bytes` / `flops` were computed for `bound` rows; gpn_prof_get reads
+  // the counter and scales them to the live rows (round 5: the BatchNorm passes of the device-counted proposal networks were
+  // accounted at their 2 N bound - a family fraction above 1)
+  ProfScope(int kernel_id, hipStream_t s, double flops, double bytes, const int64_t* rows_dev, int64_t bound, int64_t tag = 0);
   ~ProfScope();
 };
 // shape of a conv launch as a profiler tag (gpn_prof_get_launches): rows of the launch's output, taps, channel blocks, and
@@ -183,10 +187,6 @@ struct WgradReduceJob {
 int wgrad_slices(int K, int cin, int cout, int64_t n_dst);
 int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream,
                    const int64_t* n_dst_dev = nullptr);
-// the same contraction without LDS staging (spconv_wgrad.hip): rows from L2 straight into MFMA operands
-bool wgrad_rows_supported(int64_t n_rows_bound, int cin, int cout);
-int wgrad_rows_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream,
-                        const int64_t* n_dst_dev);
 WgradReduceJob wgrad_reduce_job(const float* partial, int S, int K, int cin, int cout, int flags, float* dW);
 int wgrad_reduce_many(const WgradReduceJob* jobs, int n, hipStream_t stream);
 // gpn_rulebook_level_counts with row count and level-0 extent on the device (rulebook.hip; used by gpn_voxelize_scenes)

@@ -13,8 +13,14 @@ struct ProfRec {
   hipEvent_t a, b;
   int64_t tag;  // what the launch was (gpn::prof_shape_tag for the conv kernels), 0 = untagged
 };
+struct ProfLive {  // work accounted at a buffer bound whose live row count is a device counter: scaled when the totals are read
+  const int64_t* rows_dev;
+  int64_t bound;
+  double flops, bytes;
+};
 struct ProfSlot {
   std::vector<ProfRec> recs;
+  std::vector<ProfLive> live;
   double flops = 0, bytes = 0;
   int64_t launches = 0;
 };
@@ -25,7 +31,7 @@ ProfSlot g_prof[GPN_K_COUNT];
 const char* kEntryPoints[] = {
     "gpn_voxelize", "gpn_voxelize_ws_bytes", "gpn_rulebook_subm3", "gpn_rulebook_subm3_ws_bytes",
     "gpn_rulebook_down", "gpn_rulebook_down_ws_bytes", "gpn_rulebook_down_lists",
-    "gpn_rulebook_down_lists_ws_bytes", "gpn_rulebook_level_counts", "gpn_rulebook_identity", "gpn_rulebook_level_counts_ws_bytes", "gpn_voxelize_ex", "gpn_voxelize_scenes", "gpn_voxelize_scenes_ws_bytes", "gpn_spconv_pack_weights", "gpn_spconv_fwd", "gpn_spconv_fwd_ws_bytes", "gpn_spconv_fwd_ordered", "gpn_rulebook_tile_order_ws_bytes", "gpn_rulebook_tile_order", "gpn_spconv_tiles_min_tiles", "gpn_spconv_direct_split", "gpn_spconv_fwd_w", "gpn_spconv_fwd_w_ws_bytes", "gpn_spconv_wgrad", "gpn_spconv_wgrad_rows",
+    "gpn_rulebook_down_lists_ws_bytes", "gpn_rulebook_level_counts", "gpn_rulebook_identity", "gpn_rulebook_level_counts_ws_bytes", "gpn_voxelize_ex", "gpn_voxelize_scenes", "gpn_voxelize_scenes_ws_bytes", "gpn_spconv_pack_weights", "gpn_spconv_fwd", "gpn_spconv_fwd_ws_bytes", "gpn_spconv_fwd_ordered", "gpn_rulebook_tile_order_ws_bytes", "gpn_rulebook_tile_order", "gpn_spconv_tiles_min_tiles", "gpn_spconv_direct_split", "gpn_spconv_fwd_w", "gpn_spconv_fwd_w_ws_bytes", "gpn_spconv_wgrad",
     "gpn_spconv_wgrad_ws_bytes", "gpn_gather_rows", "gpn_scatter_rows_csr", "gpn_bn_ws_bytes", "gpn_bn_fwd_train", "gpn_bn_fwd_eval", "gpn_bn_bwd", "gpn_net_ws_bytes", "gpn_net_bn_fusion", "gpn_net_wgrad_group", "gpn_net_forward", "gpn_linear_supported", "gpn_linear_fwd", "gpn_linear_bwd_ws_bytes", "gpn_linear_bwd", "gpn_net_backward", "gpn_net_forward_pair", "gpn_net_backward_pair", "gpn_point_losses_ws_bytes", "gpn_point_losses_fwd", "gpn_point_losses_fwd_metrics", "gpn_point_losses_bwd", "gpn_score_loss", "gpn_npcs_loss_fwd", "gpn_npcs_loss_bwd", "gpn_ball_query", "gpn_ball_query_grid_ws_bytes", "gpn_ball_query_grid", "gpn_ccl",
     "gpn_ccl_ws_bytes", "gpn_segmented_reduce", "gpn_segmented_maxpool_fwd", "gpn_segmented_maxpool_bwd",
     "gpn_instance_iou", "gpn_nms", "gpn_nms_ws_bytes", "gpn_pn2_ball_query", "gpn_pn2_group_points",
@@ -33,7 +39,7 @@ const char* kEntryPoints[] = {
     "gpn_pn2_furthest_point_sampling", "gpn_pn2_furthest_point_sampling_ws_bytes",
     "gpn_pn2_furthest_point_sampling_ws", "gpn_pn2_three_nn", "gpn_pn2_knn", "gpn_pn2_three_interpolate",
     "gpn_pn2_three_interpolate_grad", "gpn_proposals_max_proposals", "gpn_proposals_build_ws_bytes", "gpn_proposals_build", "gpn_proposals_voxel_mean",
-    "gpn_proposals_voxel_mean_bwd", "gpn_proposals_revoxelize_ws_bytes", "gpn_proposals_revoxelize", "gpn_pose_fit_ws_bytes", "gpn_pose_fit", "gpn_copy_many", "gpn_adam_blocks", "gpn_adam_step", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get", "gpn_prof_get_launches",
+    "gpn_proposals_voxel_mean_bwd", "gpn_proposals_revoxelize_ws_bytes", "gpn_proposals_revoxelize", "gpn_pose_fit_ws_bytes", "gpn_pose_fit", "gpn_copy_many", "gpn_adam_blocks", "gpn_adam_step", "gpn_adam_step_gated", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get", "gpn_prof_get_launches",
     "gpn_rulebook_subm3_dev", "gpn_rulebook_down_dev_ws_bytes", "gpn_rulebook_down_dev", "gpn_rulebook_down_lists_dev", "gpn_rulebook_identity_dev", "gpn_gather_rows_dev", "gpn_scatter_rows_csr_dev", "gpn_proposals_voxel_mean_dev", "gpn_proposals_targets_dev", "gpn_linear_fwd_dev", "gpn_linear_bwd_dev", "gpn_segmented_maxpool_fwd_dev", "gpn_segmented_maxpool_bwd_dev", "gpn_instance_iou_dev", "gpn_score_loss_dev", "gpn_npcs_loss_fwd_dev", "gpn_npcs_loss_bwd_dev",
     "gpn_last_error", "gpn_version"};
 }  // namespace
@@ -54,6 +60,12 @@ ProfScope::ProfScope(int kernel_id, hipStream_t s, double flops, double bytes, i
   g_prof[id].launches += 1;
   if (hipEventCreate(&start) != hipSuccess) { start = nullptr; return; }
   hipEventRecord(start, stream);
+}
+ProfScope::ProfScope(int kernel_id, hipStream_t s, double flops, double bytes, const int64_t* rows_dev, int64_t bound, int64_t tag_)
+    : ProfScope(kernel_id, s, rows_dev ? 0.0 : flops, rows_dev ? 0.0 : bytes, tag_) {
+  if (!g_prof_on || !rows_dev) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof[id].live.push_back({rows_dev, bound, flops, bytes});
 }
 ProfScope::~ProfScope() {
   if (!start) return;
@@ -113,6 +125,7 @@ int gpn_prof_reset(void) {
   for (auto& s : g_prof) {
     for (auto& r : s.recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     s.recs.clear();
+    s.live.clear();
     s.flops = s.bytes = 0;
     s.launches = 0;
   }
@@ -130,10 +143,21 @@ int gpn_prof_get(int kernel_id, int64_t* launches_host, double* ms_host, double*
     GPN_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
     ms += t;
   }
+  // launches over device-counted rows: their work at the LIVE row count (the counters still hold the instrumented step's values:
+  // the caller reads the totals before it runs another step)
+  double live_flops = 0, live_bytes = 0;
+  for (auto& l : s.live) {
+    int64_t n = 0;
+    GPN_CHECK_HIP(hipMemcpy(&n, l.rows_dev, sizeof(n), hipMemcpyDeviceToHost));
+    n = n < 0 ? 0 : (n > l.bound ? l.bound : n);
+    const double share = l.bound > 0 ? (double)n / (double)l.bound : 0.0;
+    live_flops += l.flops * share;
+    live_bytes += l.bytes * share;
+  }
   if (launches_host) *launches_host = s.launches;
   if (ms_host) *ms_host = ms;
-  if (flops_host) *flops_host = s.flops;
-  if (bytes_host) *bytes_host = s.bytes;
+  if (flops_host) *flops_host = s.flops + live_flops;
+  if (bytes_host) *bytes_host = s.bytes + live_bytes;
   return GPN_OK;
 }
 // the same measurements launch by launch, in launch order: ms[i] / tag[i] of launch i (tag: see gpn.h); returns the number of

@@ -238,7 +238,7 @@ static int linear_fwd_impl(const float* x, const float* W, const float* b, int64
   GPN_CHECK_ARG(shape_ok(N, cin, cout));
   if (N == 0) return GPN_OK;
   GPN_CHECK_ARG(x && W && y);
-  gpn::ProfScope prof(GPN_K_LINEAR, stream, 2.0 * (double)N * cin * cout, 4.0 * (double)N * (cin + cout));
+  gpn::ProfScope prof(GPN_K_LINEAR, stream, 2.0 * (double)N * cin * cout, 4.0 * (double)N * (cin + cout), rows.dev, N);
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid_for(gpn::plan_rows(N, rows) * ((cout + 3) / 4))), dim3(kThreads), 0, stream, x, W, b, N,
                      cin, cout, y, rows.dev);
   GPN_CHECK_LAUNCH();
@@ -281,7 +281,7 @@ static int linear_bwd_impl(const float* x, const float* W, const float* dy, int6
   }
   GPN_CHECK_ARG(dy && (!dx || W) && (!dW || x));
   gpn::ProfScope prof(GPN_K_LINEAR, stream, (dx ? 2.0 : 0.0) * (double)N * cin * cout + (dW ? 2.0 : 0.0) * (double)N * cin * cout,
-                      4.0 * (double)N * ((dx ? cin + cout : 0) + (dW || db ? cin + cout : 0)));
+                      4.0 * (double)N * ((dx ? cin + cout : 0) + (dW || db ? cin + cout : 0)), rows.dev, N);
   if (dx) {
     hipLaunchKernelGGL(linear_dx_kernel, dim3(grid_for(gpn::plan_rows(N, rows) * (cin / 4))), dim3(kThreads), 0, stream, dy, W, N, cin, cout,
                        dx, rows.dev);

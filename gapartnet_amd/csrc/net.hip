@@ -242,24 +242,9 @@ SideStream* side_stream() {
   if (!s.stream) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically largest = lowest priority
-    // experiment switch (env GPN_WGRAD_CU_MASK = "<pattern>:<k>"): confine the weight-gradient stream to a subset of the CUs.
-    // pattern "mod8" keeps CU i when i % 8 < k, "first" keeps the first k x 32 CUs.  A CU-masked stream is a BLOCKING stream:
-    // it serialises with the NULL stream, so the training step must run on a non-blocking stream of its own for this to say
-    // anything (bench.py: GPN_BENCH_STREAM=1)
-    const char* cm = getenv("GPN_WGRAD_CU_MASK");
-    bool made = false;
-    if (cm && *cm) {
-      const std::string spec(cm);
-      const size_t colon = spec.find(':');
-      const int k = colon == std::string::npos ? 0 : atoi(spec.c_str() + colon + 1);
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < 256; ++i) {
-        const bool keep = spec.compare(0, 4, "mod8") == 0 ? (i % 8 < k) : (i < k * 32);
-        if (keep) mask[i >> 5] |= 1u << (i & 31);
-      }
-      made = hipExtStreamCreateWithCUMask(&s.stream, 8, mask) == hipSuccess;
-    }
-    if (!made && hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+    // (confining this stream to a subset of the CUs - hipExtStreamCreateWithCUMask, rounds 3 and 4 - changed nothing at any mask
+    // that left it >= 128 CUs and cost 20 % at 64: profiles/r04_cu_mask.txt; removed)
+    if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
     for (auto& e : s.fork)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;

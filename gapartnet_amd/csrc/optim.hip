@@ -15,9 +15,29 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kChunk = 4096;  // elements per workgroup
 
+// `gate` (optional): a device counter deciding whether this launch's tensors take a step at all - the proposal networks of a
+// training step whose proposal count stayed on the device (include/gpn.h section DEV): with *gate == 0 the reference never ran
+// those networks, their gradients are None and torch.optim.Adam leaves value, moments and step count alone.  Here the networks ran
+// over zero rows and produced zero gradients; a step with them would still decay the moments and move the parameters by the
+// momentum term.  So: *gate == 0 -> nothing is touched and *skipped += 1; later launches take their step number as
+// step - *skipped (bias corrections recomputed from it in double, as the host does).
 __global__ __launch_bounds__(kThreads) void adam_kernel(const gpn_adam_tensor_t* __restrict__ table,
                                                         const int32_t* __restrict__ block_first, int n_tensors, float b1w,
-                                                        float b2, float b2w, float bc2_sqrt, float eps, float neg_step) {
+                                                        float b2, float b2w, float bc2_sqrt, float eps, float neg_step,
+                                                        const int64_t* __restrict__ gate, int64_t* __restrict__ skipped,
+                                                        double lr, double beta1, double beta2, int64_t step) {
+  if (gate) {
+    if (*gate == 0) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) *skipped += 1;  // (nobody reads it in this launch)
+      return;
+    }
+    const int64_t sk = *skipped;
+    if (sk > 0) {
+      const double n = (double)(step - sk > 1 ? step - sk : 1);
+      bc2_sqrt = (float)sqrt(1.0 - pow(beta2, n));
+      neg_step = (float)(-lr / (1.0 - pow(beta1, n)));
+    }
+  }
   // tensor of this block: last t with block_first[t] <= blockIdx.x
   int lo = 0, hi = n_tensors - 1;
   while (lo < hi) {
@@ -81,15 +101,23 @@ extern "C" int gpn_adam_blocks(int64_t numel) { return (int)gpn::cdiv(numel > 0 
 
 extern "C" int gpn_adam_step(const gpn_adam_tensor_t* table_dev, const int32_t* block_first_dev, int n_tensors, int n_blocks,
                              double lr, double beta1, double beta2, double eps, int64_t step, gpn_stream_t stream_) {
+  return gpn_adam_step_gated(table_dev, block_first_dev, n_tensors, n_blocks, lr, beta1, beta2, eps, step, nullptr, nullptr, stream_);
+}
+
+extern "C" int gpn_adam_step_gated(const gpn_adam_tensor_t* table_dev, const int32_t* block_first_dev, int n_tensors, int n_blocks,
+                                   double lr, double beta1, double beta2, double eps, int64_t step, const int64_t* gate_dev,
+                                   int64_t* skipped_dev, gpn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GPN_CHECK_ARG(n_tensors >= 0 && n_blocks >= 0 && step >= 1);
+  GPN_CHECK_ARG((gate_dev == nullptr) == (skipped_dev == nullptr));
   if (n_tensors == 0 || n_blocks == 0) return GPN_OK;
   GPN_CHECK_ARG(table_dev && block_first_dev);
   // scalars in double like torch's Python-side arithmetic, rounded to fp32 once (1 - 0.999f would be off by 1.3e-5)
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(n_blocks), dim3(kThreads), 0, stream, table_dev, block_first_dev, n_tensors,
-                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-lr / bc1));
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-lr / bc1),
+                     gate_dev, skipped_dev, lr, beta1, beta2, step);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

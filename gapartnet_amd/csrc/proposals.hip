@@ -600,12 +600,12 @@ __global__ __launch_bounds__(kThreads) void prop_voxel_mean_bwd_kernel(const flo
 
 struct PropWs {
   int32_t *lab, *flag, *rank, *scene_off, *cnt, *begin_end, *la, *lb, *start, *incl, *run_pos, *run_size, *keep_run, *new_pid,
-      *keep_elem, *slot, *vc3, *vseg, *nbr, *cnt2, *begin_end2, *nbr2, *rv_nvox, *rv_nout, *rv_vbase, *rv_kbase, *rv_obase;
+      *keep_elem, *slot, *vc3, *vseg, *nbr, *rv_nvox, *rv_nout, *rv_vbase, *rv_kbase, *rv_obase;
   uint32_t *keys, *skeys, *vals, *svals;
   float *xyz, *xyz_shift, *mean, *scale, *shift, *scaled, *rmin, *rmax, *vf;
   int64_t* seg64;
-  void *prim, *sub, *sub2;
-  size_t prim_bytes, sub_bytes, sub2_bytes, total;
+  void *prim, *sub;
+  size_t prim_bytes, sub_bytes, total;
 };
 
 size_t prim_bytes_for(int64_t T2) {
@@ -638,48 +638,18 @@ PropWs carve(void* ws, size_t ws_bytes, int64_t N, int64_t B, int Kmax, int64_t 
   o.rv_nvox = w.take<int32_t>(pu + 1), o.rv_nout = w.take<int32_t>(pu + 1), o.rv_vbase = w.take<int32_t>(pu + 1);
   o.rv_kbase = w.take<int32_t>(pu + 1), o.rv_obase = w.take<int32_t>(pu + 1);  // sort-free re-voxelisation: per-proposal counts / bases
   o.nbr = w.take<int32_t>(n * (size_t)Kmax);
-  o.nbr2 = w.take<int32_t>(n * (size_t)Kmax), o.cnt2 = w.take<int32_t>(n), o.begin_end2 = w.take<int32_t>(2 * n);  // second cluster set (own stream)
   o.prim_bytes = prim_bytes_for((int64_t)t2);
   o.prim = w.take<char>(o.prim_bytes);
   o.sub_bytes = std::max(std::max(gpn_ball_query_grid_ws_bytes(N), gpn_ccl_ws_bytes(N)), gpn_voxelize_ws_bytes((int64_t)t2, 3));
   o.sub_bytes = std::max(o.sub_bytes, gpn_rulebook_level_counts_ws_bytes((int64_t)t2, 1));
   o.sub = w.take<char>(o.sub_bytes);
-  o.sub2_bytes = std::max(gpn_ball_query_grid_ws_bytes(N), gpn_ccl_ws_bytes(N));
-  o.sub2 = w.take<char>(o.sub2_bytes);
   o.total = w.used;
   return o;
 }
 
-// The two cluster sets (ball query + connected components on the points' own and on their shifted coordinates) are independent
-// chains of ~20 small launches each: the second one runs on a stream of its own (per device, created on first use), forked from
-// and joined to the caller's stream with two events - with GPN_PROPOSALS_FORK=1.  Default: one after the other on the caller's
-// stream (measured, four interleaved pairs: 7.65 / 7.73 / 7.63 / 7.64 ms per step without the fork, 7.79 / 7.64 / 7.86 / 7.71 with).
-struct ForkLane {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool tried = false;
-};
-ForkLane* fork_lane() {
-  static const bool enabled = [] {
-    const char* e = getenv("GPN_PROPOSALS_FORK");
-    return e ? atoi(e) != 0 : false;
-  }();
-  if (!enabled) return nullptr;
-  static ForkLane lanes[gpn::kMaxDevices];
-  static std::mutex mu;
-  int device = 0;
-  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= gpn::kMaxDevices) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  ForkLane& l = lanes[device];
-  if (!l.tried) {
-    l.tried = true;
-    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess)
-      l.stream = nullptr;
-  }
-  return l.stream ? &l : nullptr;
-}
-
+// (The two cluster sets - independent chains of ~20 small launches each - run one after the other on the caller's stream: the
+// second on a stream of its own, forked and joined with events, measured 7.65 / 7.73 / 7.63 / 7.64 -> 7.79 / 7.64 / 7.86 / 7.71 ms
+// per step in round 4 - nothing, noisier - and was removed in round 5; profiles/r04_findings.md.)
 inline int grid_of(int64_t n) { return (int)gpn::cdiv(n > 0 ? n : 1, kThreads); }
 
 bool revox_fits(float fullscale) {
@@ -756,17 +726,11 @@ extern "C" int gpn_proposals_build(const float* points, int point_stride, const 
   const float* coords[2] = {o.xyz, o.xyz_shift};
   const int ks[2] = {K1, K2};
   int32_t* labels[2] = {o.la, o.lb};
-  ForkLane* lane = fork_lane();
-  if (lane) {
-    GPN_CHECK_HIP(hipEventRecord(lane->fork, stream));
-    GPN_CHECK_HIP(hipStreamWaitEvent(lane->stream, lane->fork, 0));
-  }
   for (int set = 0; set < 2; ++set) {
-    const bool aside = lane && set == 1;
-    hipStream_t st = aside ? lane->stream : stream;
-    int32_t *nbr = aside ? o.nbr2 : o.nbr, *cnt = aside ? o.cnt2 : o.cnt, *begin_end = aside ? o.begin_end2 : o.begin_end;
-    void* sub = aside ? o.sub2 : o.sub;
-    const size_t sub_bytes = aside ? o.sub2_bytes : o.sub_bytes;
+    hipStream_t st = stream;
+    int32_t *nbr = o.nbr, *cnt = o.cnt, *begin_end = o.begin_end;
+    void* sub = o.sub;
+    const size_t sub_bytes = o.sub_bytes;
     int rc = gpn_ball_query_grid(coords[set], coords[set], batch_indices, o.scene_off, o.lab, o.lab, N, N, B, radius,
                                  ks[set] | GPN_BQ_NO_PAD, nbr, cnt, sub, sub_bytes, (gpn_stream_t)st);
     if (rc) return rc;
@@ -775,11 +739,6 @@ extern "C" int gpn_proposals_build(const float* points, int point_stride, const 
     rc = gpn_ccl(begin_end, nbr, N, N * (int64_t)ks[set], 0, labels[set], sub, sub_bytes, (gpn_stream_t)st);
     if (rc) return rc;
   }
-  if (lane) {
-    GPN_CHECK_HIP(hipEventRecord(lane->join, lane->stream));
-    GPN_CHECK_HIP(hipStreamWaitEvent(stream, lane->join, 0));
-  }
-
   // ---- one stable sort orders both sets by component (= by the component's first point), members ascending
   hipLaunchKernelGGL(prop_keys_kernel, dim3(grid_of(T2)), dim3(kThreads), 0, stream, o.lab, o.la, o.lb, N, o.keys, o.vals);
   GPN_CHECK_LAUNCH();

@@ -325,12 +325,8 @@ int launch_wgrad(const gpn::WgradSets& sets, int K, int64_t n_dst, int cin, int 
   const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
   const int ct_tiles = cin / 16;
   const int cig = (ct_tiles + CT - 1) / CT;
-  static const bool by_xcd = [] {  // GPN_WGRAD_XCD=0: (tap, slice, layer) = blockIdx (A/B switch)
-    const char* e = getenv("GPN_WGRAD_XCD");
-    return e ? atoi(e) != 0 : true;
-  }();
   const int n_z = sets.n * cig;
-  const int dealt = (by_xcd && S >= 8 && S % 8 == 0) ? 1 : 0;
+  const int dealt = (S >= 8 && S % 8 == 0) ? 1 : 0;  // slices dealt to the XCDs (round 4: -10 % per layer at the two large levels)
   const dim3 grid = dealt ? dim3((unsigned)(K * S * n_z)) : dim3(K, S, n_z);
   hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), grid, dim3(256), 0, stream, sets, n_tiles, cin, K, S, cig, n_z, dealt, n_dev);
   GPN_CHECK_LAUNCH();
@@ -468,7 +464,6 @@ int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cou
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int nt = cout / 16;
   gpn::ProfScope prof(GPN_K_SPCONV_WGRAD, stream, 0.0, 0.0);
-  if (gpn::wgrad_rows_supported(n_dst, cin, cout)) return gpn::wgrad_rows_contract(sets, K, n_dst, cin, cout, S, stream, n_dst_dev);
   switch (CT) {
     case 1: return dispatch_wgrad_nt<1>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);
     case 2: return dispatch_wgrad_nt<2>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);

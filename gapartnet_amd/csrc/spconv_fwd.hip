@@ -694,13 +694,10 @@ int launch_direct(const float* in, const float* packed, const int32_t* nbr, cons
 // a layer has too few (tile, column) units to fill the chip and the tap-split lock-step kernel stays in use; so do the
 // k = 1 layers and input widths the unrolled stage loop is not instantiated for.
 bool use_direct(int K, int64_t n_dst, int cin, int cout) {
-  static const bool disabled = getenv("GPN_CONV_NO_DIRECT") != nullptr;  // A/B switch for measurements
-  if (disabled) return false;
   const int CB = cin / 16;
   // k = 1 layers (the residual blocks' shortcut convs, linear heads) take it too since round 3: its epilogue carries the
   // BatchNorm sums (bn_stats.h), the lock-step kernel's does not
-  static const bool k1_direct = getenv("GPN_K1_LOCKSTEP") == nullptr;
-  if (!(K == 27 || K == 8 || (K == 1 && k1_direct))) return false;
+  if (!(K == 27 || K == 8 || K == 1)) return false;
   if (!(CB >= 1 && (CB <= 8 || CB == 10 || CB == 12))) return false;
   // 32-bit byte offsets: source rows (at most 8 n_dst of them, for a stride-2 conv), output rows, the neighbour table
   if (n_dst * (int64_t)8 * std::max(cin, cout) * 4 >= ((int64_t)1 << 31) || (int64_t)K * n_dst * 4 >= ((int64_t)1 << 31)) return false;

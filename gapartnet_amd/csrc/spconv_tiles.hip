@@ -44,10 +44,27 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kMaxTaps = 27;
 
+// x = hi + mid + lo exactly (three round-to-nearest bf16 planes of eight fp32 values): the A-operand side of a split-bf16 product
+__device__ __forceinline__ void split_bf16x3(const f32x4 a0, const f32x4 a1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)x[i];
+    const float r1 = x[i] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    hi[i] = h, mid[i] = m, lo[i] = (__bf16)(r1 - (float)m);
+  }
+}
+
 // compile-time measurement switches (tools/probes/tiles_ablation.sh; 0 in the product): 1 = no row gathers, 2 = no weight loads,
-// 4 = no MFMAs (an element-wise stand-in keeps the loads alive), 8 = no BatchNorm sums in the epilogue
+// 4 = no MFMAs (an element-wise stand-in keeps the loads alive), 8 = no BatchNorm sums in the epilogue, 16 = the TIMING of a
+// split-bf16 contraction (round 5, profiles/r05_bf16x6.txt): every gathered fp32 row piece split on the fly into three bf16 planes
+// (hi / mid / lo, round-to-nearest), six v_mfma_f32_16x16x32_bf16 per (32-channel block, column tile) against weight planes that
+// are stand-ins (the fp32 fragments' bits plus a third 1 KiB fragment per block pair, so that the weight traffic is the 1.5x a
+// pre-split bf16 x 3 layout would move).  Results are wrong by design; CB must be even.
 #ifndef GPN_TILES_ABL
 #define GPN_TILES_ABL 0
 #endif
@@ -74,7 +91,7 @@ __device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int,
 }
 
 constexpr int cfg_slots(int CB, int R, int NT) {  // operand slots of the tap loop's ring: what the register budget holds, 2 .. 6
-  const int regs_per_tap = CB * (R + NT) * 4;
+  const int regs_per_tap = CB * (R + NT) * 4 + ((GPN_TILES_ABL & 16) ? (CB / 2) * NT * 4 : 0);
   const int S = GPN_TILES_OPERAND_REGS / regs_per_tap;
   return S < 2 ? 2 : (S > 6 ? 6 : S);
 }
@@ -218,6 +235,9 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
   // past the wave's last live tap read at out-of-range offsets (zeros, no memory access) and are never multiplied.
   constexpr int S = cfg_slots(CB, R, NT);
   f32x4 ra[S][CB][R], rb[S][CB][NT];
+#if GPN_TILES_ABL & 16
+  f32x4 rbx[S][(CB + 1) / 2][NT];
+#endif
   int to_issue = remaining, issued = 0;
   auto issue = [&](auto slot_tag) {
     constexpr int sl = decltype(slot_tag)::value;
@@ -252,6 +272,18 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
               f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(bvoff + woff), (cb * nt_total + nt) * 1024, 0));
         }
       }
+#if GPN_TILES_ABL & 16
+    {  // the third weight plane: one more 1 KiB fragment per (block pair, column tile), from another tap's part of the weights
+      const int k2 = has ? (k + 1 < K ? k + 1 : 0) : 0;
+      const uint32_t woff2 = has ? (uint32_t)(k2 * CB * nt_total + nt0) * 1024u : 0x7ffffc00u - (uint32_t)(CB * nt_total) * 1024u;
+#pragma unroll
+      for (int c2 = 0; c2 < (CB + 1) / 2; ++c2)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          rbx[sl][c2][nt] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(bvoff + woff2), (c2 * nt_total + nt) * 1024, 0));
+    }
+#endif
   };
   auto consume = [&](auto slot_tag) {
     constexpr int sl = decltype(slot_tag)::value;
@@ -264,6 +296,32 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
     for (int t = 0; t < R; ++t)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) part[t][nt] = zero;
+#if GPN_TILES_ABL & 16
+    if constexpr (CB >= 2) {  // (an odd block count: the last pair's second half is zeros, as a padded layout would have it)
+#pragma unroll
+      for (int c2 = 0; c2 < (CB + 1) / 2; ++c2) {
+        constexpr int kLast = CB - 1;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+          bf16x8 ah, am, al;
+          split_bf16x3(ra[sl][2 * c2][t], 2 * c2 + 1 < CB ? ra[sl][2 * c2 + 1 < CB ? 2 * c2 + 1 : kLast][t] : zero, ah, am, al);
+          // smallest products first: hi x lo, mid x mid, hi x mid, lo x hi, mid x hi, hi x hi (column tiles interleaved)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) part[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, rbx[sl][c2][nt]), part[t][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) part[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8, rb[sl][2 * c2 + 1 < CB ? 2 * c2 + 1 : kLast][nt]), part[t][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) part[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, rb[sl][2 * c2 + 1 < CB ? 2 * c2 + 1 : kLast][nt]), part[t][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) part[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, rb[sl][2 * c2][nt]), part[t][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) part[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8, rb[sl][2 * c2][nt]), part[t][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) part[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, rb[sl][2 * c2][nt]), part[t][nt], 0, 0, 0);
+        }
+      }
+    } else
+#endif
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
       // column tiles interleaved: a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles, an independent one after 32

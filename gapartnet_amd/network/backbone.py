@@ -102,6 +102,13 @@ class SparseUNet(nn.Module):
             out = net_exec.run(self, x)
             if out is not None:
                 return out
+        if getattr(x, "rows_dev", None) is not None:
+            # a tensor whose buffers are sized for a BOUND (live row count on the device): only the native executor reads that
+            # counter; the module-by-module path below would run BatchNorm statistics, convs and weight gradients over the
+            # unwritten rows behind it without any error
+            raise RuntimeError("SparseUNet.forward: the input's row count is a device counter (sync-free proposal stage); that "
+                               "form runs on the native layer-program executor only (use_native_executor, HIP backend, uniform "
+                               "BatchNorm training flags) - set GPN_PROPOSALS_SYNC=1 or model.sync_free_proposals = False")
         if self.stem is not None:
             x = self.stem(x)
         return self.ublock(x)

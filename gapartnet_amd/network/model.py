@@ -101,6 +101,8 @@ class GAPartNet(LightningModule):
         self.sync_free_proposals = os.environ.get("GPN_PROPOSALS_SYNC", "0") != "1"
         self._prop_plan = None       # [Q, M, P, V, dropped, runs, coarse] of the latest step whose counts have arrived
         self._prop_pending = []      # (pinned int64 [8], event) of counts still on their way
+        self._prop_hist = []         # the last few plans (floor of the next one: a step without proposals must not shrink the grids)
+        self._prop_gate = None       # (device counts, index) deciding whether this step's proposal networks take an Adam step
         self._prop_pinned = []       # pinned buffers ready for reuse
 
         self.ball_query_radius = instance_seg_cfg["ball_query_radius"]
@@ -281,7 +283,9 @@ class GAPartNet(LightningModule):
             rng_before = (gen, gen.get_state())
             jitter = (torch.rand(3, dtype=torch.float32, device=pt_xyz.device),
                       torch.rand(3, dtype=torch.float32, device=pt_xyz.device))
-        sync_free = self.training and self.sync_free_proposals and not self.record_npcs_preds and torch.is_grad_enabled()
+        self._prop_gate = None
+        sync_free = (self.training and self.sync_free_proposals and not self.record_npcs_preds and torch.is_grad_enabled()
+                     and self._proposal_unets_take_device_counts())
         if sync_free:
             self._take_over_proposal_counts()
             sync_free = self._prop_plan is not None
@@ -293,13 +297,13 @@ class GAPartNet(LightningModule):
             return self._proposals_without_a_read(pt_features, built)
         if built is None:
             if self.training and self.sync_free_proposals:
-                self._prop_plan = [0] * 7  # (a step without proposals is a plan too: the next one need not wait for its counts)
+                self._set_proposal_plan([0] * 7)  # (a step without proposals is a plan too: the next one need not wait for its counts)
             if rng_before is not None:
                 rng_before[0].set_state(rng_before[1])
             return None, None, None
         if self.training and self.sync_free_proposals:
             Q, M, P, V, dropped, coarse = built["counts_host"]
-            self._prop_plan = [Q, M, P, V, dropped, 0, coarse]
+            self._set_proposal_plan([Q, M, P, V, dropped, 0, coarse])
         if built["dropped"] != 0:
             raise RuntimeError("re-voxelisation dropped points: a proposal left its score_fullscale^3 grid "
                                "(the reference stops in pdb here, model.py:328-330)")
@@ -316,19 +320,45 @@ class GAPartNet(LightningModule):
                               instance_labels=built["instance_labels"])
         return voxel_tensor, built["pc_voxel_id"], proposals
 
+    def _proposal_unets_take_device_counts(self) -> bool:
+        """the device-counted form of the proposal stage hands ScoreNet / NPCS-Net tensors at their 2 N bound: only the native
+        executor reads the live row count, so the form is used only when both networks will run there (HIP backend, switch on,
+        a program exists for the module tree, BatchNorm training flags uniform)"""
+        if backend.raw().name != "hip":
+            return False
+        from . import net_exec
+        for net in (self.score_unet, self.npcs_unet):
+            if not getattr(net, "use_native_executor", False) or not net_exec.runs_natively(net):
+                return False
+        return True
+
     def _take_over_proposal_counts(self, wait: bool = False):
-        """counts of earlier steps whose copy to pinned memory has completed become the plan (never waits unless asked to)"""
+        """the counts of the step BEFORE the previous one become the plan.  Always that step's (round 5; before: whichever copy
+        had arrived, i.e. host timing): the plan picks kernel variants and slice counts - BatchNorm small-N against two-pass,
+        the weight-gradient slices whose partial sums are added in slice order - so a plan that depended on when the host looked
+        made two runs of one seed differ in the last bits.  The copy of step i - 2 was queued before step i - 1's backbone:
+        by the time step i asks, it has long arrived (synchronize() returns at once; `wait` drains everything, e.g. at the end
+        of an epoch)."""
         pend = self._prop_pending
-        while pend and (wait or pend[0][1].query()):
+        while pend and (wait or len(pend) > 1):
             host, ev = pend.pop(0)
-            if wait:
-                ev.synchronize()
+            ev.synchronize()
             counts = host.tolist()
             self._prop_pinned.append(host)
             if counts[4] != 0:
                 raise RuntimeError("re-voxelisation dropped points in an earlier training step: a proposal left its "
                                    "score_fullscale^3 grid (the reference stops in pdb there, model.py:328-330)")
-            self._prop_plan = counts[:7]
+            self._set_proposal_plan(counts[:7])
+
+    def _set_proposal_plan(self, counts):
+        """plan = the given counts, but no entry below half the largest of the last four plans: after a step without (or
+        with few) proposals the next one would otherwise launch single-workgroup grids and pick the small-matrix kernel
+        variants for 10^4 - 10^5 live rows (correct, and milliseconds slower)"""
+        hist = self._prop_hist
+        hist.append(list(counts))
+        del hist[:-4]
+        floor = [max(h[k] for h in hist) // 2 for k in range(len(counts))]
+        self._prop_plan = [max(c, f) for c, f in zip(counts, floor)]
 
     def _proposals_without_a_read(self, pt_features, built):
         """the outputs of gpn_proposals_build as they are - every tensor at its bound, the counts as device counters - for a
@@ -340,6 +370,10 @@ class GAPartNet(LightningModule):
         ev = torch.cuda.Event()
         ev.record()
         self._prop_pending.append((host, ev))
+        # ScoreNet / NPCS-Net and their heads take an optimizer step only if this step had a proposal (optim.FusedAdam.set_gate:
+        # the reference does not run them otherwise); with several ranks the all-reduced gradient decides for all of them alike
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+            self._prop_gate = (counts, 2)
         plan = self._prop_plan
         dev = dict(M=DevCount(built["M_dev"], max(plan[1], 1)), P=DevCount(built["P_dev"], max(plan[2], 1)),
                    V=DevCount(built["V_dev"], max(plan[3], 1)))
@@ -713,4 +747,7 @@ class GAPartNet(LightningModule):
         """Adam(lr) over every parameter (model.py:1051-1055); FusedAdam is a torch.optim.Adam whose step on the GPU is one
         launch (gapartnet_amd/optim.py), with torch's implementation for everything else"""
         from ..optim import FusedAdam
-        return FusedAdam(list(self.parameters()), lr=self.learning_rate)
+        opt = FusedAdam(list(self.parameters()), lr=self.learning_rate)
+        gated = [p for m in (self.score_unet, self.score_head, self.npcs_unet, self.npcs_head) for p in m.parameters()]
+        opt.set_gate(gated, lambda: self._prop_gate)
+        return opt

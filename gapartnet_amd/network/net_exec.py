@@ -13,7 +13,6 @@ summed in reverse program order.
 """
 import ctypes
 import os
-import sys
 from typing import List, Optional
 
 import numpy as np
@@ -112,11 +111,16 @@ class NetProgram:
         self.grad_total = int(sum(self.grad_sizes))
         self.last_pgrad = None
         self._grad_cache = {}
-        self.retired_total = 0     # persistent gradient buffers replaced because somebody else held them (grad_buffer)
+        self.retired_total = 0     # persistent gradient buffers replaced because their gradients were never released (grad_buffer)
         self.retired_in_a_row = 0
+        self.grad_generation = 0   # backward passes that handed out the persistent gradient buffer ...
+        self.grad_released = 0     # ... and the last of them whose gradients the consumer has acknowledged (release_gradients)
         self._static_tables = None
         self._anchor = torch.zeros(1, requires_grad=True)  # see _NetFn
         self.signature = self._signature(unet)
+        global _PROGRAM_COUNT
+        _PROGRAMS.add(self)
+        _PROGRAM_COUNT += 1
 
     # ------------------------------------------------------------------ program construction
     def _new_slot(self, level, channels):
@@ -345,12 +349,21 @@ class NetProgram:
             cached = self._static_tables = (sig, conv_table, bn_table)
         return cached[1].copy(), cached[2].copy()
 
+    def release_gradients(self):
+        """the consumer of the last backward pass's gradients is done with them (see grad_buffer)"""
+        self.grad_released = self.grad_generation
+
     def grad_buffer(self, device, params, fresh: bool):
-        """-> (flat fp32 buffer of grad_total elements, per-parameter views of it in params() order).  The persistent pair
-        is created once per device and handed out again every step (the kernels overwrite it); ``fresh`` asks for a
-        private buffer instead (gradient accumulation, parameters as autograd inputs).  A persistent pair that somebody
-        else still references - a ``.grad`` kept past ``zero_grad(set_to_none=True)`` for accumulation or deferred logging,
-        a view or ``detach()`` of one - is retired (it stays alive with its holder, untouched) and replaced by a new one."""
+        """-> (flat fp32 buffer of grad_total elements, per-parameter views of it in params() order).  ``fresh`` asks for a
+        private buffer (gradient accumulation into existing ``.grad``, parameters as autograd inputs).  Otherwise the
+        PERSISTENT pair of this device is handed out - created once, overwritten by every backward pass - under an explicit
+        contract (round 5; it replaces reference-count heuristics): every hand-out is a generation, and the pair is reused
+        only when the previous generation was RELEASED by whoever consumed the gradients (``release_gradients()``: called by
+        FusedAdam.step / .zero_grad, the Trainer and bench.py's loop after the optimizer step; ``net_exec.release_gradients
+        (model)`` for any other loop).  Without a release the previous pair is retired - it stays alive, untouched, with
+        whoever holds its views - and a new one is made: correct for any training loop, one allocation per pass slower.
+        After a release the views are overwritten in place by the next backward pass, exactly like ``.grad`` tensors under
+        ``zero_grad(set_to_none=False)``: clone what you keep."""
         def make():
             flat = torch.empty((self.grad_total,), dtype=torch.float32, device=device)
             pieces = flat.split(self.grad_sizes)
@@ -362,71 +375,49 @@ class NetProgram:
             cached = make()
             self._grad_cache[device] = cached
             self.retired_in_a_row = 0
-        elif _shared(cached, params):
+        elif self.grad_released != self.grad_generation:
             cached = make()
             self._grad_cache[device] = cached
-            # a buffer retired on EVERY pass means something keeps hold of the gradients (or the counts above are off): every
-            # gradient address then moves every step - FusedAdam re-learns its table, GradSync loses the in-place exchange
+            # a buffer retired on EVERY pass: every gradient address then moves every step - FusedAdam re-learns its table,
+            # GradSync loses the in-place exchange
             self.retired_total += 1
             self.retired_in_a_row += 1
-            if self.retired_in_a_row == 8 and _REFCOUNTS is not None:
+            if self.retired_in_a_row == 8:
                 print("[gapartnet_amd] the persistent gradient buffer of a U-Net was replaced on 8 backward passes in a row: "
-                      "something holds references to its gradients past zero_grad() (clone what you keep), or "
-                      "GPN_NET_AUTOGRAD_PARAMS=1 is the form you want")
+                      "nobody acknowledges its gradients - call gapartnet_amd.network.net_exec.release_gradients(model) "
+                      "after optimizer.step() (FusedAdam and the Trainer do), or set GPN_NET_AUTOGRAD_PARAMS=1")
         else:
             self.retired_in_a_row = 0
+        self.grad_generation += 1
         return cached
 
 
-def _calibrate_refcounts():
-    """The reference counts `_shared` compares against, MEASURED on a throw-away buffer with the statements `_shared` itself
-    uses - not constants of one CPython / torch build.  -> (references to an unshared view object, what a parameter's ``.grad``
-    adds to that, storage holders besides the views) or None when the private storage counter is not available (every
-    persistent buffer then counts as shared: private buffers per backward, slower but never overwritten under a holder)."""
-    try:
-        flat = torch.zeros(2)
-        views = list(flat.split([1, 1]))
-        param = nn.Parameter(torch.zeros(1))
-        base_use = torch._C._storage_Use_Count(flat.untyped_storage()._cdata) - len(views)
-        for i in range(len(views)):
-            v = views[i]
-            base_ref = sys.getrefcount(v)
-            break
-        param.grad = views[0]
-        for i in range(len(views)):
-            v = views[i]
-            with_grad = sys.getrefcount(v) if param.grad is v else base_ref
-            break
-        return base_ref, with_grad - base_ref, base_use
-    except Exception:
-        return None
+# every live program, for optimizers that acknowledge consumed gradients (NetProgram.release_gradients)
+import weakref
+_PROGRAMS = weakref.WeakSet()
+_PROGRAM_COUNT = 0
 
 
-_REFCOUNTS = _calibrate_refcounts()
-_warned_no_counts = False
+def program_count() -> int:
+    """programs created so far (a cheap 'has the set changed' key for callers that cache programs_of())"""
+    return _PROGRAM_COUNT
 
 
-def _shared(pair, params) -> bool:
-    """is the persistent gradient buffer (or one of its per-parameter views) referenced by anything but the cache, the
-    parameters' own ``.grad`` and the program's ``last_pgrad``?  Baselines from _calibrate_refcounts()."""
-    global _warned_no_counts
-    if _REFCOUNTS is None:
-        if not _warned_no_counts:
-            _warned_no_counts = True
-            print("[gapartnet_amd] reference counts of gradient buffers cannot be read in this interpreter / torch build: "
-                  "every backward pass of a U-Net uses a private gradient buffer (slower; no in-place gradient exchange)")
-        return True
-    base_ref, grad_ref, base_use = _REFCOUNTS
-    flat, views = pair
-    # storage holders: the flat tensor, one per view, the temporary wrapper made by untyped_storage() (= base_use, measured)
-    if torch._C._storage_Use_Count(flat.untyped_storage()._cdata) > len(views) + base_use:
-        return True
-    for i in range(len(views)):
-        v = views[i]
-        # references to the view object: the list slot, `v`, getrefcount's argument (+ the parameter's .grad)
-        if sys.getrefcount(v) > base_ref + (grad_ref if params[i].grad is v else 0):
-            return True
-    return False
+def programs_of(params):
+    """the live programs that hand gradients to any of ``params``"""
+    ids = {id(p) for p in params}
+    return [prog for prog in list(_PROGRAMS) if any(id(p) in ids for p in prog.params())]
+
+
+def release_gradients(module: nn.Module):
+    """acknowledge, for every sparse U-Net inside ``module``, that the gradients of its last backward pass have been consumed
+    (optimizer step done / gradients dropped): the executor may overwrite its persistent gradient buffer in the next backward
+    pass.  FusedAdam.step() / .zero_grad() and gapartnet_amd.trainer call this themselves; a training loop around another
+    optimizer calls it after ``optimizer.step()`` - or not at all, and pays one gradient-buffer allocation per U-Net and step."""
+    for m in module.modules():
+        prog = m.__dict__.get("_net_program")
+        if prog:
+            prog.release_gradients()
 
 
 def _vp(a: np.ndarray):
@@ -456,8 +447,9 @@ def _call(fn_name, prog, slots, rb_table, conv_table, bn_table, extra, device):
 #   Consequences: (1) ``torch.autograd.grad(loss, unet_parameters)`` raises "not used in the graph" and
 #   ``backward(inputs=[...])`` still fills the parameters' ``.grad``; (2) tensor hooks / post-accumulate-grad hooks on these
 #   parameters would not fire - a parameter WITH such a hook switches the call to the autograd form automatically;
-#   (3) the buffer is reused by the next backward: a reference kept past ``zero_grad(set_to_none=True)`` is detected
-#   (grad_buffer / _shared) and the buffer retired instead of overwritten; (4) parameters with ``requires_grad=False`` get
+#   (3) the buffer is reused by the next backward once the consumer of the gradients has RELEASED them (an explicit
+#   acknowledgement: NetProgram.release_gradients, see grad_buffer; FusedAdam / the Trainer give it) - a reference kept past
+#   that point sees the next step's gradients, as a ``.grad`` kept past ``zero_grad(set_to_none=False)`` does; (4) parameters with ``requires_grad=False`` get
 #   no gradient and their weight-gradient launches are skipped.  GradSync and FusedAdam build on the flat buffer.
 #   autograd form - ``GPN_NET_AUTOGRAD_PARAMS=1`` or ``set_autograd_parameters(True)``: parameters are autograd inputs,
 #   gradients come back through AccumulateGrad like any other op's (everything of (1)-(2) works; ~3 ms of host time per
@@ -728,6 +720,17 @@ def program_for(unet) -> Optional[NetProgram]:
         return None
     unet.__dict__["_net_program"] = prog
     return prog
+
+
+def runs_natively(unet) -> bool:
+    """will ``run(unet, x)`` take a float32 device tensor (rather than hand it back to the per-layer path)?  A program exists
+    for the module tree and every BatchNorm agrees on its training flag - what GAPartNet checks before it hands the network
+    a tensor whose row count is a device counter, which only the executor can read"""
+    prog = program_for(unet)
+    if prog is None or prog.python_stem_conv is not None:
+        return False
+    training = prog.bns[0].training
+    return all(bn.training == training for bn in prog.bns)
 
 
 def invalidate(unet):

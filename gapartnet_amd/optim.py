@@ -53,13 +53,37 @@ class FusedAdam(torch.optim.Adam):
         self._own_grad = {}
         self._last_sig = {}  # group index -> signature of the previous step (to see which gradients moved)
         self._snap = {}      # group index -> (signature, tables, object snapshot) of the previous step, see _unchanged
+        # parameters that take a step only when a DEVICE counter is non-zero (set_gate): the proposal networks of a training
+        # step whose proposal count was never read on the host
+        self._gated = frozenset()
+        self._gate_fn = None
+        self._gate_skipped = None  # device int64 [1]: steps the gate suppressed (the gated tensors' step number lags by it)
+
+    def set_gate(self, params, gate_fn):
+        """``params`` take part in a step only if the device counter ``gate_fn()`` points at is non-zero (gpn_adam_step_gated);
+        ``gate_fn() -> (int64 device tensor, element index) | None`` is asked at every step (None = no gate this step: the
+        ordinary rule - parameters without a gradient are skipped on the host - applies).  Reference behaviour this keeps:
+        GAPartNet does not run ScoreNet / NPCS-Net on a batch without proposals (network/model.py:573-574), so their
+        parameters, moments and step counts stay as they are; the device-counted training step cannot know on the host that
+        there were none."""
+        self._gated = frozenset(params)
+        self._gate_fn = gate_fn
+        self._cache.clear()
+        self._last_sig.clear()
+        self._snap.clear()
 
     # ---------------------------------------------------------------------------------------------- state (de)serialisation
     def _sync_step_tensors(self):
+        skipped = int(self._gate_skipped.item()) if self._gate_skipped is not None else 0  # (a host read: checkpoints only)
         for p, n in self._nstep.items():
             st = self.state.get(p)
             if st:
-                st["step"] = torch.tensor(float(n), dtype=torch.float32)
+                st["step"] = torch.tensor(float(n - skipped if p in self._gated else n), dtype=torch.float32)
+        if skipped:  # the host-side counts take the suppressed steps over, the device counter starts again
+            for p in self._nstep:
+                if p in self._gated:
+                    self._nstep[p] -= skipped
+            self._gate_skipped.zero_()
 
     def state_dict(self):
         self._sync_step_tensors()
@@ -196,7 +220,7 @@ class FusedAdam(torch.optim.Adam):
             self._nstep.setdefault(p, int(st["step"]))
         by_step = {}
         for p in params:
-            by_step.setdefault(self._nstep[p], []).append(p)
+            by_step.setdefault((self._nstep[p], p in self._gated), []).append(p)
         subs = []
         for plist in by_step.values():
             host = np.zeros(len(plist), _TABLE_DT)
@@ -271,6 +295,15 @@ class FusedAdam(torch.optim.Adam):
                     while len(sets) >= self._MAX_TABLE_SETS:
                         sets.pop(next(iter(sets)))
                     sets[sig] = tables
+            if prev is None or prev[0] is not sig:
+                # the set of tensors that take a step changed: a table set cached under this signature was grouped by the step
+                # counts of the time it was built, and some of its tensors may have sat out steps since (round 5: a batch
+                # without proposals, then one with - the cached table gave ScoreNet / NPCS-Net the backbone's step number,
+                # i.e. the wrong bias corrections, for the rest of the run)
+                nstep = self._nstep
+                if any(len({nstep[p] for p in plist}) > 1 for _t, _f, _b, plist, _pin in tables):
+                    tables = self._build(group, [p for p in group["params"] if p.grad is not None])
+                    sets[sig] = tables
             self._last_sig[gi] = sig
             if prev is None or prev[0] is not sig:
                 self._snap[gi] = (sig, tables, self._snapshot(group))
@@ -279,11 +312,40 @@ class FusedAdam(torch.optim.Adam):
             stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
             beta1, beta2 = group["betas"]
             nstep = self._nstep
+            gate = self._gate_fn() if (self._gate_fn is not None and self._gated) else None
             for table, first, blocks, plist, _pinned in tables:
                 n = nstep[plist[0]] + 1
-                _C.check(L.gpn_adam_step(ctypes.c_void_p(table.data_ptr()), ctypes.c_void_p(first.data_ptr()), len(plist), blocks,
-                                         ctypes.c_double(group["lr"]), ctypes.c_double(beta1), ctypes.c_double(beta2),
-                                         ctypes.c_double(group["eps"]), ctypes.c_int64(n), stream), "gpn_adam_step")
+                gate_ptr = skip_ptr = None
+                if plist[0] in self._gated and (gate is not None or self._gate_skipped is not None):
+                    # (once a step was suppressed the gated tensors' step number lags: every later launch goes through the
+                    # gated entry point, with an always-open gate when this step has none)
+                    if self._gate_skipped is None:
+                        self._gate_skipped = torch.zeros((1,), dtype=torch.int64, device=dev)
+                        self._gate_open = torch.ones((1,), dtype=torch.int64, device=dev)
+                    g_t, g_i = gate if gate is not None else (self._gate_open, 0)
+                    gate_ptr, skip_ptr = g_t.data_ptr() + 8 * int(g_i), self._gate_skipped.data_ptr()
+                _C.check(L.gpn_adam_step_gated(ctypes.c_void_p(table.data_ptr()), ctypes.c_void_p(first.data_ptr()), len(plist), blocks,
+                                               ctypes.c_double(group["lr"]), ctypes.c_double(beta1), ctypes.c_double(beta2),
+                                               ctypes.c_double(group["eps"]), ctypes.c_int64(n), ctypes.c_void_p(gate_ptr),
+                                               ctypes.c_void_p(skip_ptr), stream), "gpn_adam_step")
                 for p in plist:
                     nstep[p] = n
+        self._release_executor_gradients()
         return loss
+
+    def _release_executor_gradients(self):
+        """tell the sparse U-Nets' executor that this step has consumed their gradients (the update kernels are queued behind
+        the backward pass on the stream): the persistent gradient buffers may be overwritten by the next backward pass
+        (network/net_exec.py, "gradient hand-over contract")"""
+        from .network import net_exec
+        progs = self.__dict__.get("_executor_programs")
+        if progs is None or progs[0] != net_exec.program_count():
+            found = net_exec.programs_of(p for g in self.param_groups for p in g["params"])
+            progs = self._executor_programs = (net_exec.program_count(), found)
+        for prog in progs[1]:
+            prog.release_gradients()
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=set_to_none)
+        if set_to_none:
+            self._release_executor_gradients()

@@ -29,7 +29,6 @@ class PointCloudBatch:
     voxel_tensor: Any = None
     pc_voxel_id: Any = None
     pc_voxel_csr: Any = None  # (order, starts): points grouped by voxel, for the deterministic gather backward
-    pending_voxels: Any = None  # PendingVoxels of a batch collated with defer_voxels=True (voxel part missing until finish_voxels)
     # semantics
     sem_labels: Optional[torch.Tensor] = None
     obj_cls_labels: Optional[torch.Tensor] = None
@@ -76,12 +75,9 @@ class PointCloud:
     # -------------------------------------------------------------------------------------------------
     @staticmethod
     def collate(point_clouds: Sequence["PointCloud"], voxel_size: Optional[Sequence[float]] = None,
-                augmentation: Optional[Dict[str, float]] = None, pyramid_levels: int = 0,
-                defer_voxels: bool = False) -> PointCloudBatch:
+                augmentation: Optional[Dict[str, float]] = None, pyramid_levels: int = 0) -> PointCloudBatch:
         """``pyramid_levels`` (the caller's U-Net depth - 1; the device prefetcher passes it): the row counts of that many
-        stride-2 levels come back with the voxelisation's single host read and ride on ``voxel_tensor.level_counts``.
-        ``defer_voxels``: queue the voxelisation but do not read its sizes - the batch comes back without its voxel part and
-        ``finish_voxels(batch)`` completes it (the device prefetcher calls that a step later)"""
+        stride-2 levels come back with the voxelisation's single host read and ride on ``voxel_tensor.level_counts``."""
         n_scenes = len(point_clouds)
         first = point_clouds[0]
         if first.num_instances is None and first.instance_labels is not None and first.voxel_coords is None:
@@ -89,7 +85,7 @@ class PointCloud:
             # statistics run here, per batch, on the scenes' device
             from ..dataset.device_pipeline import prepare_batch
             assert voxel_size is not None, "un-voxelised scenes need voxel_size"
-            return prepare_batch(point_clouds, voxel_size, augmentation, pyramid_levels=pyramid_levels, defer_voxels=defer_voxels)
+            return prepare_batch(point_clouds, voxel_size, augmentation, pyramid_levels=pyramid_levels)
         assert not augmentation, "augmentation at collate time needs raw scenes (GAPartNetDataset(device_pipeline=True))"
         device = first.points.device
         counts = [int(pc.points.shape[0]) for pc in point_clouds]
@@ -123,7 +119,7 @@ class PointCloud:
                 instance_sem_labels.view(-1)[flat] = torch.cat([pc.instance_sem_labels.to(torch.int32).reshape(-1)
                                                                 for pc in point_clouds])
 
-        csr = pending = None
+        csr = None
         if first.voxel_coords is not None:
             # reference contract: concatenate per-scene voxelisations (structure/point_cloud.py:139-170)
             n_vox = [int(pc.voxel_coords.shape[0]) for pc in point_clouds]
@@ -143,11 +139,8 @@ class PointCloud:
         else:
             assert voxel_size is not None, "un-voxelised scenes need voxel_size"
             level_counts = None
-            voxels = voxelize_scenes(points[:, :3], points, counts, voxel_size, pyramid_levels, defer=defer_voxels)
-            if isinstance(voxels, PendingVoxels):
-                pending = voxels
-                indices = voxel_features = spatial_shape = pc_voxel_id = None
-            elif pyramid_levels:
+            voxels = voxelize_scenes(points[:, :3], points, counts, voxel_size, pyramid_levels)
+            if pyramid_levels:
                 indices, voxel_features, spatial_shape, pc_voxel_id, csr, level_counts = voxels
             else:
                 indices, voxel_features, spatial_shape, pc_voxel_id, csr = voxels
@@ -160,30 +153,11 @@ class PointCloud:
         return PointCloudBatch(
             pc_ids=[pc.pc_id for pc in point_clouds], points=points, batch_indices=batch_indices,
             batch_size=n_scenes, device=device, voxel_tensor=voxel_tensor, pc_voxel_id=pc_voxel_id,
-            pc_voxel_csr=csr, pending_voxels=pending, sem_labels=cat("sem_labels"),
+            pc_voxel_csr=csr, sem_labels=cat("sem_labels"),
             obj_cls_labels=torch.tensor([pc.obj_cat for pc in point_clouds]),
             instance_labels=cat("instance_labels"), num_instances=num_instances,
             instance_regions=cat("instance_regions"), num_points_per_instance=num_points_per_instance,
             instance_sem_labels=instance_sem_labels, gt_npcs=cat("gt_npcs"))
-
-
-def finish_voxels(batch: PointCloudBatch) -> PointCloudBatch:
-    """complete a batch collated with ``defer_voxels=True``: read the voxelisation's sizes (no wait when its kernels have run)
-    and attach the voxel tensor, the point -> voxel map and its CSR"""
-    pending = batch.pending_voxels
-    if pending is None:
-        return batch
-    out = pending.finish()
-    level_counts = None
-    if pending.pyramid_levels:
-        indices, voxel_features, spatial_shape, pc_voxel_id, csr, level_counts = out
-    else:
-        indices, voxel_features, spatial_shape, pc_voxel_id, csr = out
-    voxel_tensor = spconv.SparseConvTensor(voxel_features, indices, spatial_shape, batch.batch_size)
-    if level_counts:
-        voxel_tensor.level_counts = list(level_counts)
-    batch.voxel_tensor, batch.pc_voxel_id, batch.pc_voxel_csr, batch.pending_voxels = voxel_tensor, pc_voxel_id, csr, None
-    return batch
 
 
 _VOXEL_SIZE_CACHE = {}
@@ -199,28 +173,9 @@ def _voxel_size_on(device, voxel_size):
     return t
 
 
-class PendingVoxels:
-    """a scene-batch voxelisation whose kernels are queued and whose sizes have not been read yet (voxelize_scenes(defer=True));
-    ``finish()`` -> what voxelize_scenes returns.  Between the two the host is free: the device prefetcher starts the
-    voxelisation of batch i + 2 a step before it finishes it, so that the read of the sizes never waits (dataset/prefetch.py)."""
-
-    def __init__(self, handle, args, pyramid_levels):
-        self.handle, self.args, self.pyramid_levels = handle, args, pyramid_levels
-
-    def finish(self):
-        got = backend.raw().voxelize_scenes_finish(self.handle)
-        self.handle = None
-        if got is None:  # a cell index did not fit the packed keys: the general path, with its reads
-            return voxelize_scenes(*self.args, pyramid_levels=self.pyramid_levels, _packed=False)
-        vf, indices, pid, order, starts, max_coord, _dropped, level_counts = got
-        spatial_shape = [max(int(m) + 1, 128) for m in max_coord] if indices.shape[0] > 0 else [128] * 3
-        out = (indices, vf, spatial_shape, pid, (order, starts))
-        return out + (level_counts,) if self.pyramid_levels else out
-
-
 @torch.no_grad()
 def voxelize_scenes(xyz: torch.Tensor, feats: torch.Tensor, counts: Sequence[int], voxel_size: Sequence[float],
-                    pyramid_levels: int = 0, defer: bool = False, _packed: bool = True):
+                    pyramid_levels: int = 0, _packed: bool = True):
     """Batched scene voxelisation with the reference's per-scene conventions (dataset/gapartnet.py:179-205):
     range = [min - 1e-4, max + 1e-4] per scene, spatial extent per scene = (max coord + 1).clamp(min=128), batch
     extent = elementwise max over scenes.  On the HIP backend the whole preparation is one library call and ONE host read
@@ -235,9 +190,6 @@ def voxelize_scenes(xyz: torch.Tensor, feats: torch.Tensor, counts: Sequence[int
             offsets_dev = torch.arange(n_scenes + 1, dtype=torch.int64, device=device) * int(counts[0])
         else:
             offsets_dev = torch.as_tensor([0] + list(np.cumsum(counts)), dtype=torch.int64).to(device, non_blocking=True)
-        if defer and hasattr(ops, "voxelize_scenes_begin"):
-            return PendingVoxels(ops.voxelize_scenes_begin(xyz, feats, offsets_dev, [float(v) for v in voxel_size], pyramid_levels),
-                                 (xyz, feats, counts, voxel_size), pyramid_levels)
         got = ops.voxelize_scenes(xyz, feats, offsets_dev, [float(v) for v in voxel_size], pyramid_levels)
         if got is not None:
             vf, indices, pid, order, starts, max_coord, _dropped, level_counts = got

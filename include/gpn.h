@@ -215,11 +215,6 @@ int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src
                      const int32_t* pair_dst, const int32_t* tile_off, int K, int64_t n_dst, int cin,
                      int cout, int flags /* GPN_LAYOUT_OKI: write dW as [Cout][K][Cin] */, float* dW, void* ws,
                      size_t ws_bytes, gpn_stream_t stream);
-/* which contraction gpn_spconv_wgrad and the executor run: 2 = gathered rows straight into MFMA operands (csrc/spconv_wgrad.hip)
- * for every shape, 1 = for layers with >= 64 channels on a side, 0 = the LDS-staged kernel (csrc/spconv.hip) everywhere
- * (default: the faster one in the training step); mode < 0 only queries.  Returns the previous value (env GPN_WGRAD_ROWS).
- * Both are deterministic; they differ in the order of the sum over pairs (last bits). */
-int gpn_spconv_wgrad_rows(int mode);
 
 /* BN — BatchNorm1d over a feature matrix [N, C] fused with the residual add and ReLU that follow it in every block of
  * the reference network (network/backbone.py:40-49 relu(bn(conv(x)) [+ shortcut]); norm_fn = BatchNorm1d(eps=1e-4,
@@ -575,6 +570,16 @@ int gpn_copy_many(const gpn_copy_seg_t* segs_host, int n_segs, gpn_stream_t stre
 int gpn_adam_blocks(int64_t numel);
 int gpn_adam_step(const gpn_adam_tensor_t* table_dev, const int32_t* block_first_dev, int n_tensors, int n_blocks, double lr,
                   double beta1, double beta2, double eps, int64_t step, gpn_stream_t stream);
+/* the same step for tensors whose gradients exist only if a DEVICE counter is non-zero (round 5): the ScoreNet / NPCS-Net
+ * parameters of a training step whose proposal count was never read on the host (section DEV).  The reference does not run
+ * those networks for a batch without proposals (network/model.py:573-574: the gradients stay None and torch.optim.Adam skips
+ * the tensors - value, moments and step count unchanged); the device-counted step runs them over zero rows and gets zero
+ * gradients, which an ungated Adam step would still turn into a parameter update (momentum) and a moment decay.
+ * *gate_dev == 0: nothing is touched and *skipped_dev += 1.  Otherwise the step number is step - *skipped_dev (>= 1).
+ * gate_dev == skipped_dev == NULL: gpn_adam_step. */
+int gpn_adam_step_gated(const gpn_adam_tensor_t* table_dev, const int32_t* block_first_dev, int n_tensors, int n_blocks,
+                        double lr, double beta1, double beta2, double eps, int64_t step, const int64_t* gate_dev,
+                        int64_t* skipped_dev, gpn_stream_t stream);
 
 /* ================================================================================================
  * PF - pose fitting.  replaces the per-proposal numpy loop of gapartnet/misc/pose_fitting.py:4-147 (estimate_pose_from_npcs:

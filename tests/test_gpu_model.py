@@ -180,18 +180,20 @@ def test_executor_gradient_hand_over_contract(cuda):
     loss, _ = run()
     loss.backward()
     ref = {k: p.grad.clone() for k, p in zip(names, params)}
-    # nobody keeps a gradient: the next backward reuses the persistent buffer (no allocation, same addresses)
+    # the consumer released the gradients (what FusedAdam.step / the Trainer do): the next backward reuses the persistent buffer
+    # (no allocation, same addresses)
     first_ptrs = [p.grad.data_ptr() for p in params]
     net.zero_grad(set_to_none=True)
+    net_exec.release_gradients(net)
     loss, _ = run()
     loss.backward()
     assert [p.grad.data_ptr() for p in params] == first_ptrs, "the persistent gradient buffer must be reused step after step"
-    kept = params[0].grad                       # somebody holds on to a gradient (accumulation, deferred logging)
+    kept = params[0].grad                       # nobody released this pass's gradients (a foreign training loop): they stay
     kept_copy = kept.clone()
     net.zero_grad(set_to_none=True)
     loss, _ = run(scale=3.0)
     loss.backward()
-    assert torch.equal(kept, kept_copy), "a retained gradient must survive the next backward"
+    assert torch.equal(kept, kept_copy), "an unreleased gradient must survive the next backward"
     assert params[0].grad is not kept and torch.allclose(params[0].grad, 3.0 * kept_copy, rtol=1e-4, atol=1e-6)
     # frozen parameter
     net.zero_grad(set_to_none=True)
@@ -664,6 +666,37 @@ def test_fused_adam_matches_torch_adam(cuda):
     # state_dict round trip into a plain torch Adam
     opt_c = torch.optim.Adam([torch.nn.Parameter(t.clone()) for t in base], lr=1e-3)
     opt_c.load_state_dict(opt_a.state_dict())
+
+
+@pytest.mark.gpu
+def test_fused_adam_tensors_that_sit_out_steps_keep_their_own_step_count(cuda):
+    """(round 5) batches without proposals alternate with batches that have some: ScoreNet / NPCS-Net parameters then have no
+    gradient on some steps and torch.optim.Adam leaves their step counts behind the backbone's.  FusedAdam caches its device
+    tables by signature (which tensors have a gradient) - a table set cached BEFORE a tensor sat out a step groups it with the
+    backbone's step number and must be regrouped when it is used again (it was not: wrong bias corrections from then on)."""
+    from gapartnet_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    base = [torch.randn(s, generator=g).to(cuda) for s in [(64, 27, 16), (300,), (16,), (48, 48)]]
+    a = [torch.nn.Parameter(t.clone()) for t in base]
+    b = [torch.nn.Parameter(t.clone()) for t in base]
+    opt_a = FusedAdam(a, lr=1e-2)
+    opt_b = torch.optim.Adam(b, lr=1e-2, foreach=False, fused=False)
+    hold = []
+    for step in range(9):
+        for i, (p, q) in enumerate(zip(a, b)):
+            if step in (3, 6, 7) and i in (1, 2):
+                p.grad = q.grad = None
+                continue
+            grad = torch.randn(p.shape, generator=g).to(cuda)
+            if step % 2:
+                hold.append(torch.empty(p.shape, device=cuda))  # (the allocator hands out other blocks: gradient addresses move)
+            p.grad, q.grad = grad.clone(), grad.clone()
+        opt_a.step()
+        opt_b.step()
+    opt_a.state_dict()
+    for p, q in zip(a, b):
+        assert float(opt_a.state[p]["step"]) == float(opt_b.state[q]["step"])
+        assert torch.allclose(p, q, rtol=1e-6, atol=2e-7), float((p - q).abs().max())
 
 
 def test_grouped_weight_gradient_contractions_are_bit_equal(cuda):

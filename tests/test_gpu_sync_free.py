@@ -148,3 +148,94 @@ def test_three_sync_free_steps_train_like_three_blocking_steps(cuda):
         if sync_free:
             assert model._prop_plan is not None
     assert torch.allclose(runs[0], runs[1], rtol=1e-4, atol=1e-5), (runs[0], runs[1])
+
+
+def test_a_step_without_proposals_leaves_the_proposal_networks_to_the_optimizer_untouched(cuda):
+    """ the reference never runs ScoreNet / NPCS-Net on a batch without proposals: their gradients stay None and
+    torch.optim.Adam skips them - value, moments and step count unchanged.  The device-counted step runs them over zero rows (zero
+    gradients); FusedAdam's gate (gpn_adam_step_gated on the step's own proposal counter) must leave them exactly as the
+    blocking path does - also AFTER a momentum has built up - and the step that follows must use the un-advanced step number."""
+    def background(model, on):
+        with torch.no_grad():
+            if on:
+                model._saved_head = (model.sem_seg_head.weight.clone(), model.sem_seg_head.bias.clone())
+                model.sem_seg_head.weight.zero_()
+                model.sem_seg_head.bias.fill_(-10.0)
+                model.sem_seg_head.bias[0] = 10.0
+            else:
+                model.sem_seg_head.weight.copy_(model._saved_head[0])
+                model.sem_seg_head.bias.copy_(model._saved_head[1])
+
+    scenes = [[pc.to(cuda) for pc in make_batch(2, 5000, seed0=900 + 10 * j)] for j in range(4)]
+    base = make_model((0, 0), channels=[16, 32, 48]).to(cuda)
+    finals = []
+    for sync_free in (False, True):
+        model = copy.deepcopy(base)
+        model.sync_free_proposals = sync_free
+        model.revoxelize_jitter = tuple(j.to(cuda) for j in JITTER)
+        opt = model.configure_optimizers()
+        snapshots = []
+        for i, batch in enumerate(scenes):
+            empty = i == 2  # steps 0, 1 build up moments; step 2 has no proposal; step 3 has some again
+            if empty:
+                background(model, True)
+            opt.zero_grad(set_to_none=True)
+            model.training_step(batch, i).backward()
+            if empty:  # (the point head itself is put back before the update so that both runs update the same values)
+                for p in (model.sem_seg_head.weight, model.sem_seg_head.bias):
+                    p.grad = None
+            opt.step()
+            if empty:
+                background(model, False)
+            torch.cuda.synchronize()
+            snapshots.append({k: p.detach().clone() for k, p in model.named_parameters()
+                              if k.startswith(("score_unet", "npcs_unet", "score_head", "npcs_head"))})
+        if sync_free:
+            assert model._prop_gate is not None, "the device-counted step ran (otherwise this test compares nothing)"
+        sd = opt.state_dict()
+        index_of = {p: i for i, p in enumerate(p for g in opt.param_groups for p in g["params"])}
+        finals.append((snapshots, {k: float(sd["state"][index_of[p]]["step"]) for k, p in model.named_parameters()
+                                   if index_of[p] in sd["state"]}))
+    (blocking, sd_b), (gated, sd_g) = finals
+    for k in blocking[2]:
+        assert torch.equal(blocking[2][k], blocking[1][k]), f"reference behaviour: {k} untouched by the empty step"
+        assert torch.equal(gated[2][k], gated[1][k]), f"{k} moved in a step without proposals"
+    for k in blocking[3]:  # the step after: same update as the blocking run (same bias corrections = same step number)
+        assert torch.allclose(gated[3][k], blocking[3][k], rtol=1e-4, atol=1e-6), k
+    differ = {k: (sd_b[k], sd_g.get(k)) for k in sd_b if sd_b[k] != sd_g.get(k)}
+    assert not differ and len(sd_b) == len(sd_g), f"state_dict step counts (the gated tensors skipped one step): {differ}"
+
+
+def test_sync_free_is_not_used_when_a_proposal_network_runs_module_by_module(cuda):
+    """ only the native executor reads a tensor's device row count: with use_native_executor = False on a proposal
+    U-Net the model keeps the blocking read (same results as the blocking path over two steps), and handing the per-layer path
+    a device-counted tensor raises instead of normalising over unwritten rows"""
+    from gapartnet_amd.hip_ops import DevCount
+    from gapartnet_amd.spconv import pytorch as spconv
+    scenes = [[pc.to(cuda) for pc in make_batch(2, 5000, seed0=940 + 10 * j)] for j in range(2)]
+    base = make_model((0, 0), channels=[16, 32, 48]).to(cuda)
+    base.score_unet.use_native_executor = False
+    runs = []
+    for sync_free in (False, True):
+        model = copy.deepcopy(base)
+        model.score_unet.use_native_executor = False  # (a class attribute shadowed on the instance: deepcopy keeps it)
+        model.sync_free_proposals = sync_free
+        model.revoxelize_jitter = tuple(j.to(cuda) for j in JITTER)
+        opt = model.configure_optimizers()
+        losses = []
+        for i, batch in enumerate(scenes):
+            opt.zero_grad(set_to_none=True)
+            loss = model.training_step(batch, i)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        assert model._prop_gate is None, "no device-counted step may have run"
+        runs.append(torch.stack(losses).cpu())
+    assert torch.equal(runs[0], runs[1]), (runs[0], runs[1])
+    # the guard itself
+    model = copy.deepcopy(base)
+    x = spconv.SparseConvTensor(torch.zeros((64, 16), device=cuda), torch.zeros((64, 4), dtype=torch.int32, device=cuda),
+                                spatial_shape=[28, 28, 28], batch_size=1)
+    x.rows_dev = DevCount(torch.tensor([3], dtype=torch.int64, device=cuda), 3)
+    with pytest.raises(RuntimeError, match="device counter"):
+        model.score_unet(x)

@@ -321,49 +321,46 @@ def test_affinity_helpers_leave_the_process_alone_without_a_gpu(monkeypatch):
 
 
 def test_persistent_gradient_buffer_ownership():
-    """network/net_exec.NetProgram.grad_buffer: the flat per-network gradient buffer is handed out again while only the
-    program and the parameters' own ``.grad`` hold it, and is REPLACED (never overwritten) as soon as anybody else holds the
-    buffer, one of its views, or a view / detach of one.  The reference counts this rests on are measured, not constants
-    (net_exec._calibrate_refcounts); a buffer replaced on every pass is counted (retired_total)."""
+    """network/net_exec.NetProgram.grad_buffer: an explicit hand-over contract (round 5; no reference-count heuristics).  The
+    flat per-network gradient buffer is handed out again only after the consumer of the previous backward pass's gradients
+    RELEASED them (FusedAdam.step / zero_grad, the Trainer, net_exec.release_gradients(model)); without a release it is
+    REPLACED - never overwritten - and the replacement is counted (retired_total)."""
     from gapartnet_amd.network import net_exec
     from gapartnet_amd.network.backbone import SparseUNet
+    from gapartnet_amd.optim import FusedAdam
     import functools
-    assert net_exec._REFCOUNTS is not None, "reference counts cannot be read: every backward would use a private buffer"
     unet = SparseUNet.build(16, [16, 32], 1, functools.partial(torch.nn.BatchNorm1d, eps=1e-4, momentum=0.1), without_stem=True)
     prog = net_exec.program_for(unet)
     assert prog is not None
     params = prog.params()
     dev = torch.device("cpu")
-    flat0, views0 = prog.grad_buffer(dev, params, fresh=False)
+    opt = FusedAdam(list(unet.parameters()), lr=1e-3)
+    assert net_exec.programs_of(unet.parameters()) == [prog]
     ids = []
-    for step in range(4):  # the training loop's sequence: backward assigns .grad, zero_grad(set_to_none) drops it
+    for step in range(4):  # the training loop's sequence: zero_grad, backward assigns .grad, optimizer step
+        opt.zero_grad(set_to_none=True)
         flat, views = prog.grad_buffer(dev, params, fresh=False)
+        flat.zero_()
         ids.append(flat.data_ptr())
         net_exec._hand_over(prog, params, views, flat, False)
         del flat, views
-        for p in params:
-            p.grad = None
-    assert len(set(ids)) == 1 and ids[0] == flat0.data_ptr() and prog.retired_total == 0, (ids, prog.retired_total)
-    # gradients still assigned (no zero_grad): the same buffer is still not "shared" (the caller then asks for fresh=True)
-    flat, views = prog.grad_buffer(dev, params, fresh=False)
-    net_exec._hand_over(prog, params, views, flat, False)
-    del flat, views
-    assert prog.grad_buffer(dev, params, fresh=False)[0].data_ptr() == ids[0] and prog.retired_total == 0
-    # somebody keeps a gradient past zero_grad(set_to_none=True)
+        opt.step()  # (CPU tensors: torch's own Adam; the release is this class's)
+    assert len(set(ids)) == 1 and prog.retired_total == 0, (ids, prog.retired_total)
+    # a loop that never releases (a foreign optimizer): every pass gets a buffer of its own, the old one stays with its holders
     kept = params[3].grad
-    kept.fill_(3.0)  # (the buffer is torch.empty: NaN bit patterns would never compare equal)
+    kept.fill_(3.0)
     for p in params:
         p.grad = None
-    flat, views = prog.grad_buffer(dev, params, fresh=False)
+    flat, views = prog.grad_buffer(dev, params, fresh=False)   # released by the last opt.step(): still the persistent pair
+    assert flat.data_ptr() == ids[0] and prog.retired_total == 0
+    del flat, views
+    flat, views = prog.grad_buffer(dev, params, fresh=False)   # nobody released the pass before
     assert flat.data_ptr() != ids[0] and prog.retired_total == 1
     kept_value = kept.clone()
     flat.fill_(7.0)
     assert torch.equal(kept, kept_value), "the retired buffer stays untouched with its holder"
-    del flat, views, kept
-    # ... or a detach() / view of one (another tensor object on the same storage)
-    flat, views = prog.grad_buffer(dev, params, fresh=False)
     second = flat.data_ptr()
-    alias = views[0].detach()
-    del flat, views
-    assert prog.grad_buffer(dev, params, fresh=False)[0].data_ptr() != second and prog.retired_total == 2
-    del alias
+    del flat, views, kept
+    # the module-level acknowledgement for any other training loop
+    net_exec.release_gradients(unet)
+    assert prog.grad_buffer(dev, params, fresh=False)[0].data_ptr() == second and prog.retired_total == 1
