@@ -907,6 +907,33 @@ def proposals_build(points_xyz, offset_preds, sem_preds, instance_labels, batch_
                 point_order=order[:M], voxel_point_start=vstart[:V + 1])
 
 
+def proposals_postprocess(score_preds, sizes, proposal_offsets, point_indices, proposal_indices, member_slot, score_threshold,
+                          min_points, iou_threshold, rows: Optional[DevCount] = None):
+    """Section PP of include/gpn.h: score filter + NMS + compaction tables of a validation step's proposals in one call and ONE
+    host read.  -> (kept_ids [P''] i32 ascending, new_offsets [P''+1] i32, src_row [M''] i64), or None when a kernel table
+    overflowed (the caller falls back to the torch formulation)."""
+    dev = _dev(score_preds, sizes)
+    P = int(score_preds.shape[0])
+    M = int(point_indices.shape[0])
+    N = int(member_slot.shape[0]) // 2
+    L = _C.lib()
+    kept_ids = torch.empty((max(P, 1),), dtype=torch.int32, device=dev)
+    new_offsets = torch.empty((P + 1,), dtype=torch.int32, device=dev)
+    src_row = torch.empty((max(M, 1),), dtype=torch.int64, device=dev)
+    counts = torch.empty((3,), dtype=torch.int64, device=dev)
+    ws = _ws(L.gpn_proposals_postprocess_ws_bytes(i64(P)), dev)
+    p_dev, p_plan = (rows.ptr, i64(rows.plan)) if rows is not None else (ptr(None), i64(0))
+    check(L.gpn_proposals_postprocess(ptr(_c(score_preds, torch.float32)), ptr(_c(sizes, torch.int64)), ptr(_c(proposal_offsets, torch.int32)),
+                                      ptr(_c(point_indices, torch.int64)), ptr(_c(proposal_indices, torch.int64)),
+                                      ptr(_c(member_slot, torch.int32)), i64(N), i64(P), p_dev, p_plan, f32(score_threshold),
+                                      i64(min_points), f32(iou_threshold), ptr(kept_ids), ptr(new_offsets), ptr(src_row), ptr(counts),
+                                      ptr(ws), szt(ws.numel()), _stream()), "gpn_proposals_postprocess")
+    n_kept, n_points, overflow = counts.tolist()  # the step's one read of its post-processing
+    if overflow:
+        return None
+    return kept_ids[:n_kept], new_offsets[:n_kept + 1], src_row[:n_points]
+
+
 def proposals_targets(sem_labels, gt_npcs, point_indices, rows: DevCount):
     """sem_labels [N] i64 / gt_npcs [N,3] f32 (either may be None) at the proposal points -> ([M] i64 or None, [M,3] f32 or
     None), M = point_indices.shape[0] = the bound; rows past the device count stay unwritten"""

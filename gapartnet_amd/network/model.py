@@ -93,6 +93,7 @@ class GAPartNet(LightningModule):
         self.voxel_size = [float(v) for v in voxel_size]
         self.revoxelize_jitter = None  # tests inject the two uniform 3-vectors of segmented_voxelize here
         self.record_npcs_preds = False  # True: keep proposals.npcs_preds / gt_npcs in training steps too (costs a host read)
+        self._want_npcs_preds = False  # this step keeps proposals.npcs_preds (test steps; training steps with record_npcs_preds)
         self.use_fused_proposals = True  # csrc/proposals.hip on the GPU; False = the torch formulation of the same stage
         # Training steps issue the proposal stage and everything behind it WITHOUT reading its sizes back (include/gpn.h section
         # DEV): buffers at their bounds, counts on the device, the previous step's counts (copied to pinned memory, taken over
@@ -284,8 +285,8 @@ class GAPartNet(LightningModule):
             jitter = (torch.rand(3, dtype=torch.float32, device=pt_xyz.device),
                       torch.rand(3, dtype=torch.float32, device=pt_xyz.device))
         self._prop_gate = None
-        sync_free = (self.training and self.sync_free_proposals and not self.record_npcs_preds and torch.is_grad_enabled()
-                     and self._proposal_unets_take_device_counts())
+        # (training AND validation steps: round 5 - a validation step needs its sizes only once, after its post-processing)
+        sync_free = (self.sync_free_proposals and not self._want_npcs_preds and self._proposal_unets_take_device_counts())
         if sync_free:
             self._take_over_proposal_counts()
             sync_free = self._prop_plan is not None
@@ -296,12 +297,12 @@ class GAPartNet(LightningModule):
         if sync_free:
             return self._proposals_without_a_read(pt_features, built)
         if built is None:
-            if self.training and self.sync_free_proposals:
+            if self.sync_free_proposals:
                 self._set_proposal_plan([0] * 7)  # (a step without proposals is a plan too: the next one need not wait for its counts)
             if rng_before is not None:
                 rng_before[0].set_state(rng_before[1])
             return None, None, None
-        if self.training and self.sync_free_proposals:
+        if self.sync_free_proposals:
             Q, M, P, V, dropped, coarse = built["counts_host"]
             self._set_proposal_plan([Q, M, P, V, dropped, 0, coarse])
         if built["dropped"] != 0:
@@ -318,6 +319,7 @@ class GAPartNet(LightningModule):
                               proposal_offsets=built["proposal_offsets"], proposal_indices=built["proposal_indices"],
                               num_points_per_proposal=built["sizes"], sem_preds=built["sem_preds"],
                               instance_labels=built["instance_labels"])
+        proposals.member_slot = built["member_slot"]  # (row of every point in the other cluster set: gpn_proposals_postprocess)
         return voxel_tensor, built["pc_voxel_id"], proposals
 
     def _proposal_unets_take_device_counts(self) -> bool:
@@ -372,7 +374,8 @@ class GAPartNet(LightningModule):
         self._prop_pending.append((host, ev))
         # ScoreNet / NPCS-Net and their heads take an optimizer step only if this step had a proposal (optim.FusedAdam.set_gate:
         # the reference does not run them otherwise); with several ranks the all-reduced gradient decides for all of them alike
-        if not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+        if self.training and not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                  and torch.distributed.get_world_size() > 1):
             self._prop_gate = (counts, 2)
         plan = self._prop_plan
         dev = dict(M=DevCount(built["M_dev"], max(plan[1], 1)), P=DevCount(built["P_dev"], max(plan[2], 1)),
@@ -389,6 +392,7 @@ class GAPartNet(LightningModule):
                               proposal_offsets=built["proposal_offsets"], proposal_indices=built["proposal_indices"],
                               num_points_per_proposal=built["sizes"], sem_preds=built["sem_preds"],
                               instance_labels=built["instance_labels"], dev_counts=dev)
+        proposals.member_slot = built["member_slot"]
         return voxel_tensor, built["pc_voxel_id"], proposals
 
     # ScoreNet and NPCS-Net read the same proposal grid and have the same structure: with both switched on, their U-Nets run
@@ -450,8 +454,8 @@ class GAPartNet(LightningModule):
         dev_counts = proposals.dev_counts
         proposals.npcs_valid_mask = valid
         valid_idx = None
-        if fused and self.training and not self.record_npcs_preds:
-            # nobody reads the selected predictions during training: skip the compaction (a host read) altogether
+        if fused and not self._want_npcs_preds:
+            # nobody reads the selected predictions in a training or validation step: skip the compaction (a host read) altogether
             proposals.npcs_preds, proposals.gt_npcs = None, None
         else:
             valid_idx = torch.nonzero(valid).squeeze(1)
@@ -522,7 +526,10 @@ class GAPartNet(LightningModule):
             levels = prog.n_levels - 1 if prog is not None and prog.n_levels > 2 else 0
         return PointCloud.collate(point_clouds, voxel_size=self.voxel_size, pyramid_levels=levels)
 
-    def _training_or_validation_step(self, point_clouds, batch_idx: int, running_mode: str):
+    def _training_or_validation_step(self, point_clouds, batch_idx: int, running_mode: str, want_npcs_preds: Optional[bool] = None):
+        # proposals.npcs_preds (the NPCS predictions compacted to the valid points: a host read) are kept by test steps and on
+        # request (record_npcs_preds); the reference computes them in every step and reads them only in test_step
+        self._want_npcs_preds = bool(self.record_npcs_preds if want_npcs_preds is None else want_npcs_preds)
         data_batch = self._collate(point_clouds)
         batch_size = data_batch.batch_size
         points = data_batch.points
@@ -655,25 +662,57 @@ class GAPartNet(LightningModule):
         proposals.pt_sem_classes = proposals.sem_preds[proposals.proposal_offsets[:-1].long()]
         return proposals
 
+    def _post_process_kept(self, proposals: Instances) -> Optional[Instances]:
+        """what validation_step keeps of ``_post_process(proposals)`` - score filter, NMS, re-indexed fields - through ONE library
+        call (gpn_proposals_postprocess, csrc/postprocess.hip: flags, one sort, sparse intersections through the proposal
+        stage's member_slot, NMS in rounds, one compaction) and ONE host read (the two counts), instead of ~300 torch launches
+        and ~25 reads.  Works on exactly-sized and on device-counted proposals.  None: not applicable (no member_slot - the
+        unfused proposal path - or a table overflow inside the kernel): the caller runs the torch formulation."""
+        slot = getattr(proposals, "member_slot", None)
+        if slot is None or proposals.score_preds is None or proposals.point_indices is None:
+            return None
+        dev = proposals.dev_counts
+        out = backend.raw().proposals_postprocess(
+            proposals.score_preds, proposals.num_points_per_proposal, proposals.proposal_offsets, proposals.point_indices,
+            proposals.proposal_indices, slot, self.val_score_threshold, self.val_min_num_points_per_proposal,
+            self.val_nms_iou_threshold, rows=dev["P"] if dev is not None else None)
+        if out is None:
+            return None
+        ids, new_offsets, src_row = out
+        first = proposals.proposal_offsets.index_select(0, ids).long()
+        return Instances(score_preds=proposals.score_preds.index_select(0, ids),
+                         pt_sem_classes=proposals.sem_preds.index_select(0, first),
+                         batch_indices=proposals.batch_indices.index_select(0, src_row),
+                         instance_sem_labels=proposals.instance_sem_labels, ious=proposals.ious.index_select(0, ids),
+                         proposal_offsets=new_offsets, valid_mask=proposals.valid_mask)
+
     def _stash(self, dataloader_idx: int, item) -> None:
         while dataloader_idx > len(self.validation_step_outputs) - 1:
             self.validation_step_outputs.append([])
         self.validation_step_outputs[dataloader_idx].append(item)
 
     def validation_step(self, point_clouds, batch_idx: int, dataloader_idx: int = 0):
-        pc_ids, sem_seg, proposals, _ = self._training_or_validation_step(point_clouds, batch_idx, _SPLITS[dataloader_idx])
+        # validation never reads proposals.npcs_preds: unless asked to keep them (record_npcs_preds) the step runs without a host
+        # read of its sizes
+        fast = backend.raw().name == "hip" and not self.record_npcs_preds
+        pc_ids, sem_seg, proposals, _ = self._training_or_validation_step(point_clouds, batch_idx, _SPLITS[dataloader_idx],
+                                                                          want_npcs_preds=not fast)
         kept = None
         if self.current_epoch >= self.start_scorenet and proposals is not None:
-            p = self._post_process(proposals)
-            kept = Instances(score_preds=p.score_preds, pt_sem_classes=p.pt_sem_classes, batch_indices=p.batch_indices,
-                             instance_sem_labels=p.instance_sem_labels, ious=p.ious,
-                             proposal_offsets=p.proposal_offsets, valid_mask=p.valid_mask)
+            kept = self._post_process_kept(proposals) if fast else None
+            if kept is None:
+                if proposals.dev_counts is not None:
+                    raise RuntimeError("post-processing fell back to the torch formulation on a device-counted step")
+                p = self._post_process(proposals)
+                kept = Instances(score_preds=p.score_preds, pt_sem_classes=p.pt_sem_classes, batch_indices=p.batch_indices,
+                                 instance_sem_labels=p.instance_sem_labels, ious=p.ious,
+                                 proposal_offsets=p.proposal_offsets, valid_mask=p.valid_mask)
         self._stash(dataloader_idx, (pc_ids, sem_seg, kept))
         return pc_ids, sem_seg, kept
 
     def test_step(self, point_clouds, batch_idx: int, dataloader_idx: int = 0):
         pc_ids, sem_seg, proposals, _ = self._training_or_validation_step(
-            point_clouds, batch_idx, ["val", "intra", "inter"][dataloader_idx])
+            point_clouds, batch_idx, ["val", "intra", "inter"][dataloader_idx], want_npcs_preds=True)
         kept = None
         if proposals is not None and proposals.score_preds is not None:  # the reference dereferences None here (model.py:825)
             p = self._post_process(proposals)

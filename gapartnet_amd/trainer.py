@@ -243,7 +243,11 @@ class Trainer:
         loaders = loaders if isinstance(loaders, (list, tuple)) else [loaders]
         step = model.validation_step if kind == "validation" else model.test_step
         for loader_idx, loader in enumerate(loaders):
-            for batch_idx, batch in enumerate(loader):
+            feed = loader
+            if self.device.type == "cuda" and hasattr(model, "voxel_size"):
+                from .dataset.prefetch import DevicePrefetcher
+                feed = DevicePrefetcher(loader, model, self.device)  # batch i + 1 voxelised / rulebooks built while batch i runs
+            for batch_idx, batch in enumerate(feed):
                 if self.limit_val_batches is not None and batch_idx >= self.limit_val_batches:
                     break
                 step(move_batch(batch, self.device), batch_idx, loader_idx)

@@ -546,6 +546,25 @@ int gpn_proposals_voxel_mean_bwd(const float* dout, const int32_t* member_slot, 
                                  const int32_t* voxel_point_start, int64_t N, int C, float* dfeats, gpn_stream_t stream);
 
 /* ================================================================================================
+ * PP - post-processing of a validation / test step's proposals in one call (round 5): filter_invalid_proposals +
+ * apply_nms of the reference (network/grouping_utils.py:159-298, called from network/model.py:667-692, 807-857).
+ * Inputs as gpn_proposals_build left them: score_preds [P] f32 (the sigmoid scores), sizes [P] i64, proposal_offsets [P+1] i32,
+ * point_indices / proposal_indices [M] i64, member_slot [2N] i32 (N = points of the batch).  P may be a bound with the live count
+ * in *p_dev (p_plan sizes grids only).  A proposal survives if score > score_threshold and size > min_points (both strict) and
+ * greedy NMS by descending score (ties: lower id first) on the point-set IoU inter / ((|a| + |b|) - inter + 1e-8) (fp32) does
+ * not suppress it (IoU > iou_threshold with a kept proposal of higher rank).
+ * Outputs: kept_ids [P] i32 = ids of the kept proposals, ascending; new_offsets [P+1] i32 = their CSR offsets after compaction;
+ * src_row [M] i64 = for every point of a kept proposal its row in the inputs; counts [3] i64 (device) = {kept proposals, their
+ * points, != 0: a proposal shared points with more proposals than the kernel tables hold (results incomplete)}.  The caller
+ * re-indexes whatever per-proposal / per-point fields it needs with kept_ids / src_row. */
+size_t gpn_proposals_postprocess_ws_bytes(int64_t P);
+int gpn_proposals_postprocess(const float* score_preds, const int64_t* sizes, const int32_t* proposal_offsets,
+                              const int64_t* point_indices, const int64_t* proposal_indices, const int32_t* member_slot, int64_t N,
+                              int64_t P, const int64_t* p_dev, int64_t p_plan, float score_threshold, int64_t min_points,
+                              float iou_threshold, int32_t* kept_ids, int32_t* new_offsets, int64_t* src_row, int64_t* counts,
+                              void* ws, size_t ws_bytes, gpn_stream_t stream);
+
+/* ================================================================================================
  * O — the optimizer step.  GAPartNet.configure_optimizers (network/model.py:1051-1055): torch.optim.Adam(lr) over every
  * parameter.  One launch for the whole model: table [n_tensors] on the DEVICE describes the fp32 tensors (built once;
  * pointers are stable from step to step), block_first [n_tensors] i32 = first workgroup of each tensor with

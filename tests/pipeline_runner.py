@@ -117,8 +117,12 @@ def run_train_step(gold, device, per_scene_voxelisation=True):
     return out
 
 
-def run_validation_epoch(gold, device, per_scene_voxelisation=True):
+def run_validation_epoch(gold, device, per_scene_voxelisation=True, record_npcs_preds=True):
     model = build_model(device).eval()
+    # True: the fixture pins the selected NPCS predictions of the validation step as well (a host read; the torch formulation of the
+    # post-processing).  False: the product's default validation step - device-counted proposal stage from the second step on,
+    # fused post-processing (csrc/postprocess.hip)
+    model.record_npcs_preds = record_npcs_preds
     model._current_epoch = 10
     logged = {}
     model._log_sink = lambda name, value, bs, sync: logged.setdefault(name, []).append(float(value))

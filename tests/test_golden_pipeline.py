@@ -46,11 +46,15 @@ def gold():
     return np.load(os.path.join(HERE, "glue_step.npz"))
 
 
-def _check_forward(gold, out, prefix, tol):
+def _check_forward(gold, out, prefix, tol, optional=()):
     for k in INT_KEYS:
+        if k in optional and prefix + k not in out:
+            continue
         assert np.array_equal(out[prefix + k], gold[prefix + k]), f"{prefix}{k}: integer output differs from the reference"
     worst = {}
     for k in FP_KEYS:
+        if k in optional and prefix + k not in out:
+            continue
         g, v = gold[prefix + k], out[prefix + k]
         assert g.shape == v.shape, (k, g.shape, v.shape)
         err = float(np.abs(g.astype(np.float64) - v).max()) if g.size else 0.0
@@ -180,9 +184,15 @@ def test_training_step_on_the_gpu_matches_the_reference_model(cuda, gold, per_sc
 
 
 @pytest.mark.gpu
-def test_validation_epoch_on_the_gpu_matches_the_reference_model(cuda, gold):
-    out = R.run_validation_epoch(gold, cuda)
-    worst = _check_forward(gold, out, "eval_", 1e-4)
+@pytest.mark.parametrize("record_npcs_preds", [True, False])
+def test_validation_epoch_on_the_gpu_matches_the_reference_model(cuda, gold, record_npcs_preds):
+    """record_npcs_preds=False is the product's default validation step (round 5): fused post-processing, and from the second
+    step of the epoch on the device-counted proposal stage - the reference's kept proposals and every logged epoch-end metric (AP at
+    ten thresholds, mIoU, accuracies over the three loaders) must come out the same; the NPCS predictions a validation step
+    never reads are not kept then"""
+    out = R.run_validation_epoch(gold, cuda, record_npcs_preds=record_npcs_preds)
+    optional = () if record_npcs_preds else ("prop_npcs_preds", "prop_gt_npcs", "prop_npcs_valid_mask")
+    worst = _check_forward(gold, out, "eval_", 1e-4, optional)
     print("worst fp error / scale per output:", {k: f"{v:.2e}" for k, v in worst.items()})
     _check_kept(gold, out, 1e-4)
     _check_logs(gold, out, "eval_log/", 1e-4)

@@ -64,6 +64,7 @@ def test_fused_stage_equals_the_torch_formulation(cuda, n_scenes, n_points, with
 
 def test_fused_stage_without_proposals(cuda):
     model = make_model((0, 0), channels=[16, 32]).to(cuda).eval()
+    model.sync_free_proposals = False  # (the blocking form: a stage that finds nothing says so; tests/test_gpu_sync_free.py has the other)
     batch = PointCloud.collate([pc.to(cuda) for pc in make_batch(2, 3000)], voxel_size=(0.01,) * 3)
     N = batch.points.shape[0]
     feats = torch.zeros(N, 16, device=cuda)
@@ -167,3 +168,67 @@ def test_revoxelisation_without_a_sort_equals_the_sorting_voxeliser(cuda, seed, 
     assert torch.equal(pid, rpid)
     assert torch.equal(order, rorder)
     assert torch.equal(vstart[:V + 1], rvstart)
+
+
+def _eval_model(cuda, seed_offset=0):
+    model = make_model((0, 0))
+    model.load_state_dict(recipe.name_keyed_state(model))  # non-trivial BatchNorm statistics: several classes, real proposals
+    model = model.to(cuda).eval()
+    model.revoxelize_jitter = tuple(j.to(cuda) for j in JITTER)
+    model._log_sink = lambda name, value, bs, sync: None
+    return model
+
+
+KEPT_FIELDS = ("score_preds", "pt_sem_classes", "batch_indices", "instance_sem_labels", "ious", "proposal_offsets", "valid_mask")
+
+
+@pytest.mark.parametrize("n_scenes,n_points", [(2, 5000), (4, 20000), (8, 20000)])
+@pytest.mark.parametrize("thresholds", [(0.09, 3, 0.3), (0.5, 20, 0.05), (0.0, 0, 0.9)])
+def test_fused_post_processing_equals_the_torch_formulation(cuda, n_scenes, n_points, thresholds):
+    """gpn_proposals_postprocess (csrc/postprocess.hip: score filter, sparse intersections through member_slot, NMS in rounds, one
+    compaction) against the torch formulation of filter_invalid_proposals + apply_nms (network/grouping_utils.py - itself
+    pinned to the reference by tests/test_golden_pipeline.py) on the proposals of a validation step: every field validation_step
+    keeps must be EQUAL (integers and floats alike: scores and IoUs are selected, never recomputed)."""
+    model = _eval_model(cuda)
+    model.sync_free_proposals = False
+    model.val_score_threshold, model.val_min_num_points_per_proposal, model.val_nms_iou_threshold = thresholds
+    batch = [pc.to(cuda) for pc in make_batch(n_scenes, n_points, seed0=1300 + n_points)]
+    with torch.no_grad():
+        _, _, proposals, _ = model._training_or_validation_step(batch, 0, "val", want_npcs_preds=False)
+        assert proposals is not None and proposals.score_preds is not None
+        fused = model._post_process_kept(proposals)
+        assert fused is not None, "the fused form must apply to the fused proposal stage's output"
+        ref = model._post_process(proposals)
+    assert ref.score_preds.shape[0] < proposals.score_preds.shape[0] or thresholds[0] == 0.0
+    for name in KEPT_FIELDS:
+        a, b = getattr(ref, name), getattr(fused, name)
+        assert a.dtype == b.dtype and a.shape == b.shape, (name, a.dtype, b.dtype, tuple(a.shape), tuple(b.shape))
+        assert torch.equal(a, b), name
+
+
+def test_validation_step_without_a_host_read_equals_the_blocking_step(cuda):
+    """round 5: validation steps run the device-counted proposal stage too (row counts as device counters, one host read at the
+    end of the step: the post-processing's two counts) - what the step keeps for the epoch-end AP must equal the blocking
+    step's, the stale plan of the first device-counted step included"""
+    batches = [[pc.to(cuda) for pc in make_batch(4, 20000, seed0=1500 + 10 * j)] for j in range(3)]
+    kept = {}
+    for sync_free in (False, True):
+        model = _eval_model(cuda)
+        model.sync_free_proposals = sync_free
+        outs = []
+        with torch.no_grad():
+            for i, batch in enumerate(batches):
+                outs.append(model.validation_step(batch, i, 0))
+        if sync_free:
+            assert model._prop_pending, "validation steps after the first one ran without reading the proposal counts"
+        kept[sync_free] = outs
+    for (ids_a, seg_a, a), (ids_b, seg_b, b) in zip(kept[False], kept[True]):
+        assert ids_a == ids_b and torch.equal(seg_a.sem_preds, seg_b.sem_preds)
+        assert (a is None) == (b is None)
+        for name in KEPT_FIELDS:
+            x, y = getattr(a, name), getattr(b, name)
+            assert x.dtype == y.dtype and x.shape == y.shape, (name, x.dtype, y.dtype, tuple(x.shape), tuple(y.shape))
+            if x.dtype.is_floating_point:
+                assert torch.allclose(x, y, rtol=1e-5, atol=1e-6), name  # (kernel variants follow the plan: last bits)
+            else:
+                assert torch.equal(x, y), name

@@ -1,32 +1,23 @@
-import sys, torch
+import cProfile, pstats, sys, os, io, time
 sys.path.insert(0, '.')
-from gapartnet_amd.optim import FusedAdam
-dev = torch.device('cuda:0')
-ps = [torch.nn.Parameter(torch.randn(100, device=dev)) for _ in range(4)]
-opt = FusedAdam(ps, lr=1e-2)
-keep = []
-for it in range(6):
-    opt.zero_grad(set_to_none=True)
-    for i, p in enumerate(ps):
-        g = torch.randn(100, device=dev)
-        if it % 2: keep.append(torch.empty(100, device=dev))  # shift allocator state: addresses move
-        p.grad = g
-    if it == 3:
-        ps[1].grad = None
-    before = ps[1].detach().clone()
-    opt.step()
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+from gapartnet_amd.smoke import make_batch, make_model
+from tests.golden import recipe
+dev = torch.device("cuda:0")
+model = make_model((0, 0)).eval()
+model.load_state_dict(recipe.name_keyed_state(model))
+model = model.to(dev)
+model._log_sink = lambda name, value, bs, sync: None
+pools = [[pc.to(dev) for pc in make_batch(4, 20000, seed0=2000 + 10 * j)] for j in range(2)]
+with torch.no_grad():
+    for i in range(6): model.validation_step(pools[i % 2], i, 0)
     torch.cuda.synchronize()
-    print(it, 'own', len(opt._own_grad), 'p1 moved', not torch.equal(before, ps[1].detach()), 'nstep', [opt._nstep.get(p) for p in ps])
-# against torch.optim.Adam
-torch.manual_seed(0)
-a = [torch.nn.Parameter(torch.randn(100, device=dev)) for _ in range(4)]
-b = [torch.nn.Parameter(p.detach().clone()) for p in a]
-oa, ob = FusedAdam(a, lr=1e-2), torch.optim.Adam(b, lr=1e-2)
-for it in range(8):
-    gs = [torch.randn(100, device=dev) for _ in a]
-    for opt, ps in ((oa, a), (ob, b)):
-        opt.zero_grad(set_to_none=True)
-        for i, p in enumerate(ps):
-            p.grad = gs[i].clone() if not (it in (3, 6) and i in (1, 2)) else None
-        opt.step()
-print('max diff vs torch Adam', max(float((x - y).abs().max()) for x, y in zip(a, b)))
+    pr = cProfile.Profile(); pr.enable()
+    t0 = time.perf_counter()
+    for i in range(20): model.validation_step(pools[i % 2], i, 0)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    pr.disable()
+print("ms/step under cProfile", (t1 - t0) / 20 * 1e3)
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(60); print(s.getvalue()[:9000])

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=12, help="validation steps per loader and epoch")
     ap.add_argument("--epochs", type=int, default=3)
     args = ap.parse_args()
+    from gapartnet_amd.dataset.prefetch import DevicePrefetcher
     from gapartnet_amd.smoke import make_batch, make_model
     from tests.golden import recipe
     dev = torch.device("cuda:0")
@@ -44,8 +45,10 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for l in range(3):
-                for i in range(args.steps):
-                    out = model.validation_step(pools[l][i % 2], i, l)
+                # (as the Trainer's evaluation loop does: the next batch is prepared on the side stream while this one runs)
+                feed = DevicePrefetcher((pools[l][i % 2] for i in range(args.steps)), model, dev)
+                for i, batch in enumerate(feed):
+                    out = model.validation_step(batch, i, l)
                     if out[2] is not None:
                         kept = int(out[2].score_preds.shape[0])
             torch.cuda.synchronize()
