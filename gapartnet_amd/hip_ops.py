@@ -908,7 +908,7 @@ def proposals_build(points_xyz, offset_preds, sem_preds, instance_labels, batch_
 
 
 def proposals_postprocess(score_preds, sizes, proposal_offsets, point_indices, proposal_indices, member_slot, score_threshold,
-                          min_points, iou_threshold, rows: Optional[DevCount] = None):
+                          min_points, iou_threshold, rows: Optional[DevCount] = None, defer: bool = False):
     """Section PP of include/gpn.h: score filter + NMS + compaction tables of a validation step's proposals in one call and ONE
     host read.  -> (kept_ids [P''] i32 ascending, new_offsets [P''+1] i32, src_row [M''] i64), or None when a kernel table
     overflowed (the caller falls back to the torch formulation)."""
@@ -928,10 +928,35 @@ def proposals_postprocess(score_preds, sizes, proposal_offsets, point_indices, p
                                       ptr(_c(member_slot, torch.int32)), i64(N), i64(P), p_dev, p_plan, f32(score_threshold),
                                       i64(min_points), f32(iou_threshold), ptr(kept_ids), ptr(new_offsets), ptr(src_row), ptr(counts),
                                       ptr(ws), szt(ws.numel()), _stream()), "gpn_proposals_postprocess")
+    if defer:  # the read is the caller's, later (PostprocessHandle.result): nothing waits for this step's kernels now
+        host = _PINNED_COUNTS.pop() if _PINNED_COUNTS else torch.empty((3,), dtype=torch.int64).pin_memory()
+        host.copy_(counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return PostprocessHandle(kept_ids, new_offsets, src_row, host, ev)
     n_kept, n_points, overflow = counts.tolist()  # the step's one read of its post-processing
     if overflow:
         return None
     return kept_ids[:n_kept], new_offsets[:n_kept + 1], src_row[:n_points]
+
+
+_PINNED_COUNTS = []
+
+
+class PostprocessHandle:
+    """outputs of a gpn_proposals_postprocess call whose counts have not been read yet; ``result()`` waits for them (no wait if
+    the call's kernels have run) -> (kept_ids, new_offsets, src_row) sliced to size, or None after a table overflow"""
+
+    def __init__(self, kept_ids, new_offsets, src_row, host, event):
+        self.kept_ids, self.new_offsets, self.src_row, self.host, self.event = kept_ids, new_offsets, src_row, host, event
+
+    def result(self):
+        self.event.synchronize()
+        n_kept, n_points, overflow = self.host.tolist()
+        _PINNED_COUNTS.append(self.host)
+        if overflow:
+            return None
+        return self.kept_ids[:n_kept], self.new_offsets[:n_kept + 1], self.src_row[:n_points]
 
 
 def proposals_targets(sem_labels, gt_npcs, point_indices, rows: DevCount):

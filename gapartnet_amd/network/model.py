@@ -40,6 +40,26 @@ from .losses import dice_loss, focal_loss, mean_iou, pixel_accuracy
 _SPLITS = ["val", "test_intra", "test_inter"]
 
 
+class _PendingKept:
+    """the proposals a validation step keeps, before the one host read of its post-processing (GAPartNet.defer_validation_outputs):
+    ``resolve()`` -> Instances (or the torch formulation's result after a table overflow inside the kernel)"""
+
+    def __init__(self, model, proposals, handle):
+        self.model, self.proposals, self.handle = model, proposals, handle
+
+    def resolve(self):
+        kept = GAPartNet._kept_from(self.proposals, self.handle.result())
+        if kept is None:
+            if self.proposals.dev_counts is not None:
+                raise RuntimeError("post-processing fell back to the torch formulation on a device-counted step")
+            p = self.model._post_process(self.proposals)
+            kept = Instances(score_preds=p.score_preds, pt_sem_classes=p.pt_sem_classes, batch_indices=p.batch_indices,
+                             instance_sem_labels=p.instance_sem_labels, ious=p.ious, proposal_offsets=p.proposal_offsets,
+                             valid_mask=p.valid_mask)
+        self.model = self.proposals = self.handle = None
+        return kept
+
+
 class GAPartNet(LightningModule):
     def __init__(
         self,
@@ -93,6 +113,7 @@ class GAPartNet(LightningModule):
         self.voxel_size = [float(v) for v in voxel_size]
         self.revoxelize_jitter = None  # tests inject the two uniform 3-vectors of segmented_voxelize here
         self.record_npcs_preds = False  # True: keep proposals.npcs_preds / gt_npcs in training steps too (costs a host read)
+        self.defer_validation_outputs = False  # True (set by an evaluation loop): validation_step's host read happens a step later
         self._want_npcs_preds = False  # this step keeps proposals.npcs_preds (test steps; training steps with record_npcs_preds)
         self.use_fused_proposals = True  # csrc/proposals.hip on the GPU; False = the torch formulation of the same stage
         # Training steps issue the proposal stage and everything behind it WITHOUT reading its sizes back (include/gpn.h section
@@ -662,12 +683,13 @@ class GAPartNet(LightningModule):
         proposals.pt_sem_classes = proposals.sem_preds[proposals.proposal_offsets[:-1].long()]
         return proposals
 
-    def _post_process_kept(self, proposals: Instances) -> Optional[Instances]:
+    def _post_process_kept(self, proposals: Instances, defer: bool = False):
         """what validation_step keeps of ``_post_process(proposals)`` - score filter, NMS, re-indexed fields - through ONE library
         call (gpn_proposals_postprocess, csrc/postprocess.hip: flags, one sort, sparse intersections through the proposal
         stage's member_slot, NMS in rounds, one compaction) and ONE host read (the two counts), instead of ~300 torch launches
         and ~25 reads.  Works on exactly-sized and on device-counted proposals.  None: not applicable (no member_slot - the
-        unfused proposal path - or a table overflow inside the kernel): the caller runs the torch formulation."""
+        unfused proposal path - or a table overflow inside the kernel): the caller runs the torch formulation.
+        ``defer``: -> a ``_PendingKept`` whose ``resolve()`` does the read (and the re-indexing) later."""
         slot = getattr(proposals, "member_slot", None)
         if slot is None or proposals.score_preds is None or proposals.point_indices is None:
             return None
@@ -675,7 +697,13 @@ class GAPartNet(LightningModule):
         out = backend.raw().proposals_postprocess(
             proposals.score_preds, proposals.num_points_per_proposal, proposals.proposal_offsets, proposals.point_indices,
             proposals.proposal_indices, slot, self.val_score_threshold, self.val_min_num_points_per_proposal,
-            self.val_nms_iou_threshold, rows=dev["P"] if dev is not None else None)
+            self.val_nms_iou_threshold, rows=dev["P"] if dev is not None else None, defer=defer)
+        if defer:
+            return _PendingKept(self, proposals, out)
+        return self._kept_from(proposals, out)
+
+    @staticmethod
+    def _kept_from(proposals: Instances, out) -> Optional[Instances]:
         if out is None:
             return None
         ids, new_offsets, src_row = out
@@ -687,9 +715,16 @@ class GAPartNet(LightningModule):
                          proposal_offsets=new_offsets, valid_mask=proposals.valid_mask)
 
     def _stash(self, dataloader_idx: int, item) -> None:
+        self._resolve_pending_outputs()  # (the previous step's deferred read: its kernels finished while this step was queued)
         while dataloader_idx > len(self.validation_step_outputs) - 1:
             self.validation_step_outputs.append([])
         self.validation_step_outputs[dataloader_idx].append(item)
+
+    def _resolve_pending_outputs(self) -> None:
+        for outputs in self.validation_step_outputs:
+            if outputs and isinstance(outputs[-1][2], _PendingKept):
+                pc_ids, sem_seg, pending = outputs[-1]
+                outputs[-1] = (pc_ids, sem_seg, pending.resolve())
 
     def validation_step(self, point_clouds, batch_idx: int, dataloader_idx: int = 0):
         # validation never reads proposals.npcs_preds: unless asked to keep them (record_npcs_preds) the step runs without a host
@@ -699,7 +734,9 @@ class GAPartNet(LightningModule):
                                                                           want_npcs_preds=not fast)
         kept = None
         if self.current_epoch >= self.start_scorenet and proposals is not None:
-            kept = self._post_process_kept(proposals) if fast else None
+            # (an evaluation LOOP - gapartnet_amd.trainer - lets the step's one host read wait until the next step has been
+            # queued: defer_validation_outputs; a direct call gets its proposals back at once, as the reference's does)
+            kept = self._post_process_kept(proposals, defer=self.defer_validation_outputs) if fast else None
             if kept is None:
                 if proposals.dev_counts is not None:
                     raise RuntimeError("post-processing fell back to the torch formulation on a device-counted step")
@@ -728,6 +765,7 @@ class GAPartNet(LightningModule):
     def _epoch_end_metrics(self) -> None:
         """semantic accuracy / mIoU and instance AP@50 / mAP(0.50:0.05:0.95) per split, plus the monitor_metrics means of
         the two test splits (model.py:694-805, 859-1046)."""
+        self._resolve_pending_outputs()
         all_accus, pixel_accus, mious, mean_ap50, mAPs = [], [], [], [], []
         data_size = 0
         for split, outputs in zip(_SPLITS, self.validation_step_outputs):

@@ -242,6 +242,9 @@ class Trainer:
         model.eval()
         loaders = loaders if isinstance(loaders, (list, tuple)) else [loaders]
         step = model.validation_step if kind == "validation" else model.test_step
+        if hasattr(model, "defer_validation_outputs"):
+            # nobody here looks at a step's return value: the model may read a step's sizes while the next step is queued
+            model.defer_validation_outputs = True
         for loader_idx, loader in enumerate(loaders):
             feed = loader
             if self.device.type == "cuda" and hasattr(model, "voxel_size"):
@@ -252,6 +255,8 @@ class Trainer:
                     break
                 step(move_batch(batch, self.device), batch_idx, loader_idx)
         (model.on_validation_epoch_end if kind == "validation" else model.on_test_epoch_end)()
+        if hasattr(model, "defer_validation_outputs"):
+            model.defer_validation_outputs = False
         return log.reduce(self.device)
 
     def validate(self, model, datamodule=None, dataloaders=None):

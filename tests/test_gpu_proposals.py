@@ -212,17 +212,25 @@ def test_validation_step_without_a_host_read_equals_the_blocking_step(cuda):
     step's, the stale plan of the first device-counted step included"""
     batches = [[pc.to(cuda) for pc in make_batch(4, 20000, seed0=1500 + 10 * j)] for j in range(3)]
     kept = {}
-    for sync_free in (False, True):
+    for sync_free, defer in ((False, False), (True, False), (True, True)):
         model = _eval_model(cuda)
         model.sync_free_proposals = sync_free
+        model.defer_validation_outputs = defer  # (what the Trainer's evaluation loop sets: a step's read a step later)
         outs = []
         with torch.no_grad():
             for i, batch in enumerate(batches):
-                outs.append(model.validation_step(batch, i, 0))
+                out = model.validation_step(batch, i, 0)
+                outs.append(out)
+                assert defer == (type(out[2]).__name__ == "_PendingKept")
         if sync_free:
             assert model._prop_pending, "validation steps after the first one ran without reading the proposal counts"
-        kept[sync_free] = outs
-    for (ids_a, seg_a, a), (ids_b, seg_b, b) in zip(kept[False], kept[True]):
+        if defer:
+            model._resolve_pending_outputs()
+            outs = list(model.validation_step_outputs[0])
+            assert len(outs) == len(batches) and all(type(o[2]).__name__ == "Instances" for o in outs)
+        kept[(sync_free, defer)] = outs
+    pairs = list(zip(kept[(False, False)], kept[(True, False)])) + list(zip(kept[(False, False)], kept[(True, True)]))
+    for (ids_a, seg_a, a), (ids_b, seg_b, b) in pairs:
         assert ids_a == ids_b and torch.equal(seg_a.sem_preds, seg_b.sem_preds)
         assert (a is None) == (b is None)
         for name in KEPT_FIELDS:

@@ -37,6 +37,7 @@ def main():
     model = model.to(dev)
     logged = {}
     model._log_sink = lambda name, value, bs, sync: logged.__setitem__(name, value)
+    model.defer_validation_outputs = True  # (what gapartnet_amd.trainer.Trainer's evaluation loop sets)
     pools = [[[pc.to(dev) for pc in make_batch(args.batch, args.points, seed0=2000 + 1000 * l + 10 * j)] for j in range(2)]
              for l in range(3)]
     step_ms, end_ms, kept = [], [], 0
@@ -48,11 +49,12 @@ def main():
                 # (as the Trainer's evaluation loop does: the next batch is prepared on the side stream while this one runs)
                 feed = DevicePrefetcher((pools[l][i % 2] for i in range(args.steps)), model, dev)
                 for i, batch in enumerate(feed):
-                    out = model.validation_step(batch, i, l)
-                    if out[2] is not None:
-                        kept = int(out[2].score_preds.shape[0])
+                    model.validation_step(batch, i, l)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
+            model._resolve_pending_outputs()
+            last = model.validation_step_outputs[-1][-1][2]
+            kept = int(last.score_preds.shape[0]) if last is not None else 0
             model.on_validation_epoch_end()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
