@@ -25,6 +25,17 @@ import torch
 
 from ..structure.point_cloud import PointCloud, PointCloudBatch
 
+
+def _upload(host: torch.Tensor, dev: torch.device) -> torch.Tensor:
+    """a small host tensor -> device WITHOUT stalling: a pageable host-to-device copy is a synchronising call (it waits for the
+    stream's queued work - here the scenes' own upload and the kernels before it: ~0.5 ms of main-thread time per table and
+    batch, round 5); through a pinned staging tensor the copy is queued like a kernel (the caching host allocator keeps the
+    block until the copy has run)"""
+    if dev.type != "cuda":
+        return host.to(dev)
+    return host.pin_memory().to(dev, non_blocking=True)
+
+
 _KEY_STRIDE = 1 << 32  # instance ids are int32: (scene << 32 | id) orders by scene, then id
 
 
@@ -54,9 +65,9 @@ def augment_points(points: torch.Tensor, batch_indices: torch.Tensor, mats: np.n
     """points [N, 3 + C] float32 -> augmented copy: xyz @ M[scene] (float64 product, rounded once), colours + shift[scene]"""
     dev = points.device
     scene = batch_indices.long()
-    m = torch.from_numpy(np.ascontiguousarray(mats)).to(dev)[scene]                       # [N,3,3] f64
+    m = _upload(torch.from_numpy(np.ascontiguousarray(mats)), dev)[scene]                 # [N,3,3] f64
     xyz = torch.einsum("ni,nij->nj", points[:, :3].double(), m).float()
-    shift = torch.from_numpy(np.ascontiguousarray(shifts)).to(dev)
+    shift = _upload(torch.from_numpy(np.ascontiguousarray(shifts)), dev)
     if bool((shifts != 0).any()):
         rgb = (points[:, 3:].double() + shift[scene]).float()  # numpy adds a float64 row to the float32 colours in place
     else:
@@ -87,7 +98,7 @@ def inst_info_batch(points: torch.Tensor, instance_labels: torch.Tensor, sem_lab
     n, n_scenes = points.shape[0], len(num_instances)
     width = int(max(num_instances))
     k_host = torch.as_tensor(list(num_instances), dtype=torch.int64)
-    base = (torch.cumsum(k_host, 0) - k_host).to(dev)          # first global instance slot of each scene
+    base = _upload(torch.cumsum(k_host, 0) - k_host, dev)      # first global instance slot of each scene
     total = int(k_host.sum())
     member = instance_labels >= 0
     rows = torch.nonzero(member).squeeze(1)
@@ -105,7 +116,7 @@ def inst_info_batch(points: torch.Tensor, instance_labels: torch.Tensor, sem_lab
     first = torch.full((total,), n, dtype=torch.int64, device=dev).scatter_reduce_(0, slot, rows, "amin")
     sem_of_slot = sem_labels[first.clamp(max=n - 1)].to(torch.int32)
     # ragged [total] -> padded [B, width]
-    slot_scene = torch.repeat_interleave(torch.arange(n_scenes, device=dev), k_host.to(dev), output_size=total)
+    slot_scene = torch.repeat_interleave(torch.arange(n_scenes, device=dev), _upload(k_host, dev), output_size=total)
     slot_col = torch.arange(total, device=dev) - base[slot_scene]
     npi = torch.zeros((n_scenes, width), dtype=torch.int32, device=dev)
     isl = torch.full((n_scenes, width), -1, dtype=torch.int32, device=dev)
@@ -123,15 +134,19 @@ def prepare_batch(raw: Sequence[PointCloud], voxel_size: Sequence[float], augmen
     n_scenes = len(raw)
     dev = raw[0].points.device
     counts = [int(pc.points.shape[0]) for pc in raw]
-    points = torch.cat([pc.points for pc in raw], dim=0)
-    sem = torch.cat([pc.sem_labels for pc in raw], dim=0)
-    ins = torch.cat([pc.instance_labels for pc in raw], dim=0)
-    npcs = torch.cat([pc.gt_npcs for pc in raw], dim=0) if raw[0].gt_npcs is not None else None
+    packed = getattr(raw, "packed", None)  # (dataset.packed_cache: the scenes are slices of these four tensors already)
+    if packed is not None:
+        points, sem, ins, npcs = packed
+    else:
+        points = torch.cat([pc.points for pc in raw], dim=0)
+        sem = torch.cat([pc.sem_labels for pc in raw], dim=0)
+        ins = torch.cat([pc.instance_labels for pc in raw], dim=0)
+        npcs = torch.cat([pc.gt_npcs for pc in raw], dim=0) if raw[0].gt_npcs is not None else None
     if len(set(counts)) == 1:
         batch_indices = torch.arange(n_scenes, dtype=torch.int32, device=dev).repeat_interleave(counts[0])
     else:
         batch_indices = torch.repeat_interleave(torch.arange(n_scenes, dtype=torch.int32, device=dev),
-                                                torch.as_tensor(counts, dtype=torch.int64, device=dev),
+                                                _upload(torch.as_tensor(counts, dtype=torch.int64), dev),
                                                 output_size=sum(counts))
     ins, k = compact_instance_labels_batch(ins, batch_indices, n_scenes)
     num_instances = [int(v) for v in k.tolist()]

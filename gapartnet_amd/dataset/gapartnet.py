@@ -151,6 +151,7 @@ class GAPartNetDataset(torch.utils.data.Dataset):
             self.nopart_files = lines[0].split(" ") if lines else []
         skip = {os.path.basename(p).split(".")[0] for p in self.nopart_files}
         self.pc_paths = [p for p in paths if os.path.basename(p).split(".")[0] not in skip]
+        self.all_paths = list(self.pc_paths)  # sorted, before the per-run shuffle / few-shot cut (dataset/packed_cache.py keys on it)
         if shuffle:
             np.random.shuffle(self.pc_paths)
         if few_shot:
@@ -207,7 +208,7 @@ class GAPartNetInst(LightningDataModule):
                  pos_jitter: float = 0., color_jitter: float = 0., flip_prob: float = 0., rotate_prob: float = 0.,
                  train_few_shot: bool = False, val_few_shot: bool = False, intra_few_shot: bool = False,
                  inter_few_shot: bool = False, few_shot_num: int = 256, train_with_all: bool = False,
-                 device_pipeline: bool = False):
+                 device_pipeline: bool = False, packed_cache: bool = False, cache_dir: Optional[str] = None):
         super().__init__()
         self.save_hyperparameters()
         self.root_dir, self.max_points, self.voxel_size = root_dir, max_points, tuple(voxel_size)
@@ -217,6 +218,13 @@ class GAPartNetInst(LightningDataModule):
         self.few = dict(train=train_few_shot, val=val_few_shot, intra=intra_few_shot, inter=inter_few_shot)
         self.few_shot_num, self.train_with_all = few_shot_num, train_with_all
         self.device_pipeline = device_pipeline  # not a reference kwarg: per-batch scene preparation on the GPU
+        # not reference kwargs: the scenes of a split from ONE memory-mapped array file (written on first use under cache_dir,
+        # default <root_dir>/.gpn_cache) and whole batches through pinned staging blocks instead of worker processes unpickling
+        # .pth files (dataset/packed_cache.py); implies the raw hand-over of device_pipeline
+        self.packed_cache = packed_cache
+        self.cache_dir = cache_dir
+        if packed_cache:
+            self.device_pipeline = True
 
     def _dataset(self, split: str, sub: str, augmentation: bool, shuffle: bool):
         few = self.few[split]
@@ -245,6 +253,14 @@ class GAPartNetInst(LightningDataModule):
         self.inter_data_files = self._dataset("inter", "test_inter", False, True)
 
     def _loader(self, dataset, batch_size, shuffle, drop_last, sampler=None):
+        if self.packed_cache and not isinstance(dataset, SyntheticGAPartNetDataset):
+            from .packed_cache import PackedSceneLoader, PackedScenes
+            split = os.path.basename(os.path.dirname(os.path.dirname(dataset.all_paths[0]))) if dataset.all_paths else "empty"
+            cache_dir = self.cache_dir or os.path.join(str(self.root_dir), ".gpn_cache")
+            scenes = PackedScenes.open(dataset.all_paths, cache_dir, split, num_workers=self.num_workers)
+            where = {p: i for i, p in enumerate(dataset.all_paths)}
+            return PackedSceneLoader(scenes, batch_size, shuffle and sampler is None, drop_last, sampler=sampler,
+                                     index_map=[where[p] for p in dataset.pc_paths])
         return torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and sampler is None,
                                            num_workers=self.num_workers, collate_fn=trivial_batch_collator,
                                            pin_memory=True, drop_last=drop_last, sampler=sampler)

@@ -80,7 +80,10 @@ class DevicePrefetcher:
             if isinstance(raw, PointCloudBatch):
                 batch = raw
             else:
-                pcs = [pc.to(self.device) if hasattr(pc, "to") else pc for pc in raw]
+                if hasattr(raw, "scenes"):  # dataset.packed_cache.StagedBatch: one pinned block per field, four copies
+                    pcs = raw.scenes(self.device)
+                else:
+                    pcs = [pc.to(self.device) if hasattr(pc, "to") else pc for pc in raw]
                 raw_scenes = pcs[0].num_instances is None and pcs[0].instance_labels is not None
                 # the backbone's coarse levels: their row counts come back with the voxelisation's one host read
                 levels = prog.n_levels - 1 if prog is not None and prog.n_levels > 2 else 0

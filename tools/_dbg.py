@@ -1,23 +1,31 @@
-import cProfile, pstats, sys, os, io, time
+import cProfile, pstats, sys, os, io, time, tempfile, shutil
 sys.path.insert(0, '.')
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
-from gapartnet_amd.smoke import make_batch, make_model
-from tests.golden import recipe
-dev = torch.device("cuda:0")
-model = make_model((0, 0)).eval()
-model.load_state_dict(recipe.name_keyed_state(model))
-model = model.to(dev)
-model._log_sink = lambda name, value, bs, sync: None
-pools = [[pc.to(dev) for pc in make_batch(4, 20000, seed0=2000 + 10 * j)] for j in range(2)]
-with torch.no_grad():
-    for i in range(6): model.validation_step(pools[i % 2], i, 0)
+sys.argv = ['x']
+from tools.pth_loader_bench import write_dataset
+from gapartnet_amd.dataset.gapartnet import GAPartNetInst
+from gapartnet_amd.dataset.prefetch import DevicePrefetcher
+from gapartnet_amd.smoke import make_model
+device = torch.device("cuda:0")
+root = tempfile.mkdtemp(prefix="gpn_pth_")
+write_dataset(root, 128, 8, 20000)
+dm = GAPartNetInst(root, max_points=20000, train_batch_size=8, val_batch_size=8, test_batch_size=8, num_workers=8, pos_jitter=0.1,
+                   color_jitter=0.3, flip_prob=0.3, rotate_prob=0.3, packed_cache=True)
+dm.setup("fit")
+model = make_model((0, 0)).to(device).train()
+opt = model.configure_optimizers()
+def epoch(prof=None):
+    feed = DevicePrefetcher(dm.train_dataloader(), model, device, augmentation=dm.aug)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
+    if prof: prof.enable()
+    for i, batch in enumerate(feed):
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch, i); loss.backward(); opt.step(); n += 1
     torch.cuda.synchronize()
-    pr = cProfile.Profile(); pr.enable()
-    t0 = time.perf_counter()
-    for i in range(20): model.validation_step(pools[i % 2], i, 0)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    pr.disable()
-print("ms/step under cProfile", (t1 - t0) / 20 * 1e3)
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(60); print(s.getvalue()[:9000])
+    if prof: prof.disable()
+    return (time.perf_counter() - t0) / n * 1e3
+print("warm", epoch()); print("ms/step", epoch(), epoch())
+pr = cProfile.Profile(); print("profiled", epoch(pr))
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:7000])
+shutil.rmtree(root, ignore_errors=True)

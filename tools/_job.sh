@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r05c
-O=gpurun_out/r05c
-python -m pytest tests/test_gpu_proposals.py tests/test_golden_pipeline.py tests/test_eval_ap.py -m gpu -q 2>&1 | tail -30 > $O/pytest.txt; tail -8 $O/pytest.txt
-for i in 1 2; do timeout 300 python tools/eval_bench.py 2>$O/eval.err | tail -1 | tee $O/eval_$i.json; done
+mkdir -p gpurun_out/r05d
+O=gpurun_out/r05d
+timeout 600 python tools/pth_loader_bench.py 2>$O/pth.err | tail -1 | tee $O/pth_loader.json
+tail -3 $O/pth.err

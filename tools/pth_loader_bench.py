@@ -42,7 +42,7 @@ def write_dataset(root, n_train, n_eval, n_points):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--scenes", type=int, default=128)
+    ap.add_argument("--scenes", type=int, default=384)
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--workers", type=int, default=8)
@@ -61,12 +61,17 @@ def main():
         out["write_s"] = time.perf_counter() - t0
         size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) for f in fs)
         out["mb_per_scene"] = size / (args.scenes + 24) / 1e6
-        for device_pipeline in (False, True):
+        for mode in ("per_scene_cpu", "device_pipeline", "packed_cache"):
+            device_pipeline = mode != "per_scene_cpu"
             dm = GAPartNetInst(root, max_points=args.points, train_batch_size=args.batch, val_batch_size=args.batch,
                                test_batch_size=args.batch, num_workers=args.workers, pos_jitter=0.1, color_jitter=0.3,
-                               flip_prob=0.3, rotate_prob=0.3, device_pipeline=device_pipeline)
+                               flip_prob=0.3, rotate_prob=0.3, device_pipeline=device_pipeline, packed_cache=mode == "packed_cache")
             dm.setup("fit")
-            key = "device_pipeline" if device_pipeline else "per_scene_cpu"
+            key = mode
+            if mode == "packed_cache":
+                t0 = time.perf_counter()
+                dm.train_dataloader()  # first use: the cache file is written
+                out["packed_cache/build_s"] = time.perf_counter() - t0
             # loader alone
             loader = dm.train_dataloader()
             n = 0
@@ -84,22 +89,21 @@ def main():
                 loader = dm.train_dataloader()
                 feed = DevicePrefetcher(loader, model, device, augmentation=dm.aug if device_pipeline else None)
                 torch.cuda.synchronize()
-                stamps = []
+                t_start, n = None, 0
                 for i, batch in enumerate(feed):
                     batch = move_batch(batch, device)
                     opt.zero_grad(set_to_none=True)
                     loss = model.training_step(batch, i)
                     loss.backward()
                     opt.step()
-                    if i % 4 == 3:
-                        torch.cuda.synchronize()  # (bounds the host's lead: the stamps then are completion times)
-                    stamps.append(time.perf_counter())
+                    n += 1
+                    if i == 3:  # steady state of the epoch: the worker start-up at its head (the reference re-creates its
+                        torch.cuda.synchronize()  # workers every epoch too) is left out
+                        t_start = time.perf_counter()
                 torch.cuda.synchronize()
-                if epoch > 0 and len(stamps) > 6:
-                    # steady state of the epoch: the worker start-up at its head (the reference re-creates its workers every
-                    # epoch too) is reported separately
-                    times.append((stamps[-1] - stamps[3]) / (len(stamps) - 4))
-                    steps += len(stamps) - 4
+                if epoch > 0 and t_start is not None and n > 8:
+                    times.append((time.perf_counter() - t_start) / (n - 4))
+                    steps += n - 4
             assert bool(torch.isfinite(loss)), "loss is not finite"
             out[f"{key}/ms_per_step_with_loader"] = float(np.median(times)) * 1e3
             out[f"{key}/point_clouds_per_s_with_loader"] = args.batch / float(np.median(times))
