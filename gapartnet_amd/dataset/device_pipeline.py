@@ -127,7 +127,7 @@ def inst_info_batch(points: torch.Tensor, instance_labels: torch.Tensor, sem_lab
 
 @torch.no_grad()
 def prepare_batch(raw: Sequence[PointCloud], voxel_size: Sequence[float], augmentation: Optional[Dict[str, float]] = None,
-                  pyramid_levels: int = 0) -> PointCloudBatch:
+                  pyramid_levels: int = 0, voxels: bool = True) -> PointCloudBatch:
     """raw scenes (tensors on one device: points, sem_labels, instance_labels, gt_npcs; nothing derived) -> the
     ``PointCloudBatch`` the model trains on: what ``GAPartNetDataset._prepare`` + ``PointCloud.collate`` produce."""
     from ..structure.point_cloud import spconv, voxelize_scenes
@@ -157,18 +157,19 @@ def prepare_batch(raw: Sequence[PointCloud], voxel_size: Sequence[float], augmen
         mats, shifts = draw_augmentation(n_scenes, color_channels=points.shape[1] - 3, **augmentation)
         points = augment_points(points, batch_indices, mats, shifts)
     info = inst_info_batch(points, ins, sem, batch_indices, num_instances)
-    level_counts = None
-    voxels = voxelize_scenes(points[:, :3], points, counts, voxel_size, pyramid_levels)
-    if pyramid_levels:
-        indices, voxel_features, spatial_shape, pc_voxel_id, csr, level_counts = voxels
-    else:
-        indices, voxel_features, spatial_shape, pc_voxel_id, csr = voxels
-    voxel_tensor = spconv.SparseConvTensor(voxel_features, indices, spatial_shape, n_scenes)
-    if level_counts:
-        voxel_tensor.level_counts = list(level_counts)
+    level_counts = voxel_tensor = pc_voxel_id = csr = None
+    if voxels:
+        vox = voxelize_scenes(points[:, :3], points, counts, voxel_size, pyramid_levels)
+        if pyramid_levels:
+            indices, voxel_features, spatial_shape, pc_voxel_id, csr, level_counts = vox
+        else:
+            indices, voxel_features, spatial_shape, pc_voxel_id, csr = vox
+        voxel_tensor = spconv.SparseConvTensor(voxel_features, indices, spatial_shape, n_scenes)
+        if level_counts:
+            voxel_tensor.level_counts = list(level_counts)
     return PointCloudBatch(
         pc_ids=[pc.pc_id for pc in raw], points=points, batch_indices=batch_indices, batch_size=n_scenes, device=dev,
         voxel_tensor=voxel_tensor, pc_voxel_id=pc_voxel_id, pc_voxel_csr=csr, sem_labels=sem,
         obj_cls_labels=torch.tensor([pc.obj_cat for pc in raw]), instance_labels=ins, num_instances=num_instances,
         instance_regions=info["instance_regions"], num_points_per_instance=info["num_points_per_instance"],
-        instance_sem_labels=info["instance_sem_labels"], gt_npcs=npcs)
+        instance_sem_labels=info["instance_sem_labels"], gt_npcs=npcs, scene_counts=counts)

@@ -11,10 +11,13 @@ clustering code), i.e. exactly where the host would otherwise wait for the GPU.
 Yields ``PointCloudBatch`` objects (what ``GAPartNet.training_step`` accepts directly) whose ``voxel_tensor`` already
 carries the rulebook pyramid of the backbone in its ``indice_dict``.
 """
+import os
 from typing import Iterable, Optional
 
+import numpy as np
 import torch
 
+from .. import _C
 from ..structure.point_cloud import PointCloud, PointCloudBatch
 
 # (Round 4 measured two variants of this iterator and round 5 removed them - profiles/r04_findings.md: the voxelisation queued one
@@ -55,16 +58,32 @@ class DevicePrefetcher:
     """``for batch in DevicePrefetcher(loader, model, device)``: batches come out collated, voxelised and with the
     backbone's rulebooks built, each prepared on a side stream while the previous one trains."""
 
-    def __init__(self, batches: Iterable, model, device: torch.device, augmentation: Optional[dict] = None):
+    def __init__(self, batches: Iterable, model, device: torch.device, augmentation: Optional[dict] = None,
+                 native: Optional[bool] = None):
         assert device.type == "cuda", "batch preparation runs on the GPU (the product has no CPU path)"
         self.batches, self.model, self.device = batches, model, device
         self.augmentation = augmentation  # for raw scenes (dataset device_pipeline=True): drawn per batch, applied on the GPU
         self.stream = torch.cuda.Stream(device=device)
         self._consumer_mark = None
+        # native: voxelisation, its one host read and the backbone's rulebook pyramid as ONE library call into ONE arena
+        # (gpn_backbone_prepare, csrc/prepare.hip) instead of 17 calls and ~230 allocations; bit-identical tables
+        # (tests/test_gpu_prepare.py).  Issued by THIS thread: round 5 measured the same call on a worker thread (no Python in
+        # it at all) - 7.52 -> 7.78 ms per step and 12.7 -> 19.5 CPU-ms, every one of three interleaved pairs, with or without
+        # holding its kernels back until the backbone has run; from a packed cache 812 - 856 -> 690 - 720 point-clouds/s
+        # (profiles/r05_findings.md): a second launching host thread beside the training thread costs more than the 1.3 ms of
+        # preparation it takes off it, as round 4's Python worker did.
+        self.native = (os.environ.get("GPN_PREFETCH_NATIVE", "1") != "0") if native is None else native
+
+    def _program(self):
+        backbone = getattr(self.model, "backbone", None)
+        if backbone is not None and getattr(backbone, "use_native_executor", False):
+            from ..network import net_exec
+            return net_exec.program_for(backbone)
+        return None
 
     def _prepare(self, raw):
-        """one batch's preparation on the side stream: collate, voxelise (one host read of the sizes - it waits only for this
-        stream's own small kernels), the backbone's rulebooks.  -> (batch, event the consumer waits for) or None"""
+        """a batch's preparation on the side stream: collate here; voxelisation, its one host read and the backbone's
+        rulebooks as one native call (``native``) or call by call.  -> (batch, event the consumer waits for) or None"""
         if raw is None:
             return None
         with torch.cuda.stream(self.stream):
@@ -72,11 +91,8 @@ class DevicePrefetcher:
                 # Everything this stream allocates from here on may reuse blocks of batches the training stream has
                 # finished with: wait for the point of the training stream up to which that is true (see __iter__).
                 self.stream.wait_event(self._consumer_mark)
-            backbone = getattr(self.model, "backbone", None)
-            prog = None
-            if backbone is not None and getattr(backbone, "use_native_executor", False):
-                from ..network import net_exec
-                prog = net_exec.program_for(backbone)
+            prog = self._program()
+            native = self.native and prog is not None and not isinstance(raw, PointCloudBatch)
             if isinstance(raw, PointCloudBatch):
                 batch = raw
             else:
@@ -85,15 +101,49 @@ class DevicePrefetcher:
                 else:
                     pcs = [pc.to(self.device) if hasattr(pc, "to") else pc for pc in raw]
                 raw_scenes = pcs[0].num_instances is None and pcs[0].instance_labels is not None
+                native = native and pcs[0].voxel_coords is None
                 # the backbone's coarse levels: their row counts come back with the voxelisation's one host read
                 levels = prog.n_levels - 1 if prog is not None and prog.n_levels > 2 else 0
                 batch = PointCloud.collate(pcs, voxel_size=self.model.voxel_size,
-                                           augmentation=self.augmentation if raw_scenes else None, pyramid_levels=levels)
-            if prog is not None and batch.voxel_tensor is not None and batch.voxel_tensor.features.shape[0] > 0:
-                prog.rulebooks(batch.voxel_tensor)  # cached in voxel_tensor.indice_dict under the modules' keys
+                                           augmentation=self.augmentation if raw_scenes else None, pyramid_levels=levels,
+                                           voxels=not native)
+            if native and batch.voxel_tensor is None:
+                from .. import hip_ops
+                counts = batch.scene_counts
+                if len(set(counts)) == 1:
+                    offsets = torch.arange(len(counts) + 1, dtype=torch.int64, device=self.device) * int(counts[0])
+                else:
+                    offsets = torch.as_tensor([0] + list(np.cumsum(counts)), dtype=torch.int64).pin_memory().to(self.device, non_blocking=True)
+                job = hip_ops.PreparedBackbone(batch.points[:, :3], batch.points, offsets, self.model.voxel_size, prog.n_levels,
+                                               prog.ident_levels(), self.stream)
+                job.run()  # (blocks for the voxeliser's sizes: where the call-by-call path waits too)
+                if job.rc:
+                    raise _C.GpnError(f"gpn_backbone_prepare failed (code {job.rc}): {job.error}")
+                if not job.fallback():  # (else: an empty level, a cell index beyond the packed keys, ...: the per-call path copes)
+                    from ..structure.point_cloud import spconv
+                    prepared = job.wrap()
+                    vt = spconv.SparseConvTensor(prepared["features"], prepared["indices"], prepared["spatial_shape"], batch.batch_size)
+                    vt.level_counts = list(prepared["level_counts"])
+                    prog.adopt(vt, prepared["levels"])
+                    batch.voxel_tensor, batch.pc_voxel_id, batch.pc_voxel_csr = vt, prepared["pc_voxel_id"], prepared["csr"]
+            batch = self._finish_here(batch, prog)
             done = torch.cuda.Event()
             done.record(self.stream)
         return batch, done
+
+    def _finish_here(self, batch, prog):
+        """the per-call path (on the calling thread, current stream = the side stream): voxelise if still needed, rulebooks"""
+        if batch.voxel_tensor is None and batch.scene_counts is not None:
+            from ..structure.point_cloud import spconv, voxelize_scenes
+            levels = prog.n_levels - 1 if prog is not None and prog.n_levels > 2 else 0
+            vox = voxelize_scenes(batch.points[:, :3], batch.points, batch.scene_counts, self.model.voxel_size, levels)
+            indices, feats, shape, batch.pc_voxel_id, batch.pc_voxel_csr = vox[:5]
+            batch.voxel_tensor = spconv.SparseConvTensor(feats, indices, shape, batch.batch_size)
+            if levels:
+                batch.voxel_tensor.level_counts = list(vox[5])
+        if prog is not None and batch.voxel_tensor is not None and batch.voxel_tensor.features.shape[0] > 0:
+            prog.rulebooks(batch.voxel_tensor)  # cached in voxel_tensor.indice_dict under the modules' keys
+        return batch
 
     def _prepare_pending(self):
         """called by the model in the middle of its step (GAPartNet._prefetch_hook): after the backbone and the point heads

@@ -7,6 +7,7 @@ and is test infrastructure).
 from dataclasses import dataclass
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _C
@@ -199,6 +200,86 @@ def voxelize_scenes(points, feats, seg_offsets, voxel_size, n_levels=0):
     voxel_point_start [V+1], max_coord [3 ints], dropped, level_counts [n_levels ints]) after ONE host read, or None when
     a cell index did not fit the packed keys (>= 1024 cells along an axis: the caller takes voxelize() instead)."""
     return voxelize_scenes_finish(voxelize_scenes_begin(points, feats, seg_offsets, voxel_size, n_levels))
+
+
+# ---------------------------------------------------------------------------------------------------- BP
+class PreparedBackbone:
+    """what gpn_backbone_prepare left in its arena: ``run()`` is the blocking native call (meant for a worker thread: ctypes
+    releases the interpreter lock for its whole duration), ``wrap()`` turns the descriptor into tensors / Rulebooks (views of the
+    arena)"""
+    KHEAD, KRB = 16, 10
+    KLEVEL = 8 + 4 * KRB
+
+    def __init__(self, xyz, feats, seg_offsets, voxel_size, n_levels, ident_levels, stream):
+        dev = _dev(xyz, feats, seg_offsets)
+        self.xyz, self.feats, self.seg_offsets = _c(xyz, torch.float32), _c(feats, torch.float32), _c(seg_offsets, torch.int64)
+        self.voxel_size, self.n_levels, self.ident_levels = [float(v) for v in voxel_size], int(n_levels), int(ident_levels)
+        self.M, self.C, self.S = int(self.xyz.shape[0]), int(self.feats.shape[1]), int(self.seg_offsets.shape[0]) - 1
+        L = _C.lib()
+        L.gpn_backbone_prepare_arena_bytes.restype = _C.ctypes.c_size_t
+        need = int(L.gpn_backbone_prepare_arena_bytes(i64(self.M), i32(self.C), i64(self.S), i32(self.n_levels)))
+        self.arena = torch.empty((need,), dtype=torch.uint8, device=dev)  # (on the caller's current stream)
+        self.desc = np.full((int(L.gpn_backbone_prepare_desc_words(i32(self.n_levels))),), -1, np.int64)
+        self.pinned = torch.empty((8 + self.n_levels,), dtype=torch.int64).pin_memory()
+        self.stream_handle = int(stream.cuda_stream)
+        self.device_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.rc, self.error = None, None
+
+    def run(self):
+        L = _C.lib()
+        rc = L.gpn_backbone_prepare(ptr(self.xyz), ptr(self.feats), ptr(self.seg_offsets), i64(self.M), i32(self.C), i64(self.S),
+                                    host_f32x3(self.voxel_size), i32(self.n_levels), _C.ctypes.c_uint32(self.ident_levels),
+                                    i64(TILE_ORDER_MIN_ROWS), i32(TILE_ORDER_BLOCK), i32(self.device_index), ptr(self.arena),
+                                    szt(self.arena.numel()), _C.ctypes.c_void_p(self.desc.ctypes.data),
+                                    _C.ctypes.c_void_p(self.pinned.data_ptr()), _C.ctypes.c_void_p(self.stream_handle))
+        self.rc = int(rc)
+        if rc:
+            self.error = L.gpn_last_error().decode("utf-8", "replace")
+        return self
+
+    def fallback(self) -> bool:
+        return self.rc != 0 or int(self.desc[5]) != 0
+
+    def _view(self, off, count, dtype):
+        if off < 0:
+            return None
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return self.arena[off:off + nbytes].view(dtype)
+
+    def _rulebook(self, words):
+        o_nbr, o_src, o_dst, o_toff, o_np, o_nbrp, o_perm, n_src, n_dst, K = (int(v) for v in words)
+        if o_nbr < 0:
+            return None
+        # pair-list capacities as gpn_backbone_prepare carved them: 27 n (SubM), the fine row count (stride-2 maps), n (identity)
+        cap = 27 * n_dst if K == 27 else (n_dst if K == 1 else max(n_src, n_dst))
+        rb = Rulebook(self._view(o_src, cap, torch.int32), self._view(o_dst, cap, torch.int32),
+                      self._view(o_toff, K * (n_tiles(n_dst) + 1), torch.int32).view(K, -1), K, n_src, n_dst,
+                      self._view(o_np, 1, torch.int64)[0], self._view(o_nbr, K * n_dst + 1, torch.int32))
+        if o_perm >= 0:
+            rb.perm = self._view(o_perm, (n_dst + 15) // 16 * 16 + 16, torch.int32)
+            rb.nbr_p = self._view(o_nbrp, K * n_dst + 1, torch.int32)
+        return rb
+
+    def wrap(self):
+        """-> dict(features, indices, spatial_shape, pc_voxel_id, csr, level_counts, levels = [dict(indices, shape, subm,
+        down_fwd, down_bwd, ident)])"""
+        d = self.desc
+        V = int(d[0])
+        M, C = self.M, self.C
+        out = dict(features=self._view(int(d[8]), M * C, torch.float32).view(M, C)[:V],
+                   indices=self._view(int(d[9]), M * 4, torch.int32).view(M, 4)[:V], spatial_shape=[int(v) for v in d[1:4]],
+                   pc_voxel_id=self._view(int(d[10]), M, torch.int32),
+                   csr=(self._view(int(d[11]), M, torch.int32), self._view(int(d[12]), M + 1, torch.int32)[:V + 1]),
+                   dropped=int(d[4]), levels=[])
+        for l in range(self.n_levels):
+            w = d[self.KHEAD + l * self.KLEVEL: self.KHEAD + (l + 1) * self.KLEVEL]
+            rows = int(w[0])
+            idx = out["indices"] if l == 0 else self._view(int(w[4]), rows * 4, torch.int32).view(rows, 4)
+            rbs = [self._rulebook(w[8 + k * self.KRB: 8 + (k + 1) * self.KRB]) for k in range(4)]
+            out["levels"].append(dict(indices=idx, shape=[int(v) for v in w[1:4]], subm=rbs[0], down_fwd=rbs[1], down_bwd=rbs[2],
+                                      ident=rbs[3]))
+        out["level_counts"] = [int(lv["indices"].shape[0]) for lv in out["levels"][1:]]
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------- K

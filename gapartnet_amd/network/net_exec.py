@@ -257,6 +257,27 @@ class NetProgram:
             objs.append((rb, rb_t))
         return rows, table, objs, levels, dev_counts
 
+    def ident_levels(self) -> int:
+        """bit l set: level l has k = 1 convs (the decoder blocks' shortcuts) and needs an identity rulebook"""
+        mask = 0
+        for kind, lvl in self.rb_keys:
+            if kind == "ident":
+                mask |= 1 << lvl
+        return mask
+
+    def adopt(self, x, prepared_levels):
+        """fill ``x.indice_dict`` from a finished native batch preparation (hip_ops.PreparedBackbone.wrap()["levels"]) under the
+        keys ``rulebooks`` uses, so that it finds everything built"""
+        for lvl, lv in enumerate(prepared_levels):
+            skey, dkey = self.level_keys[lvl]
+            x.indice_dict[skey] = lv["subm"]
+            if lvl + 1 < self.n_levels:
+                nxt = prepared_levels[lvl + 1]
+                x.indice_dict[dkey] = spconv._DownRecord(lv["indices"], lv["shape"], nxt["indices"], nxt["shape"], lv["down_fwd"],
+                                                         lv["down_bwd"])
+            if lv["ident"] is not None:
+                x.indice_dict[f"__identity_{int(lv['indices'].shape[0])}__"] = lv["ident"]
+
     def rulebooks(self, x):
         """fetch / build the rulebook of every level through the tensor's indice_dict (same keys as the modules)"""
         ops = backend.raw()

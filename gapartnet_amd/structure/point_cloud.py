@@ -29,6 +29,7 @@ class PointCloudBatch:
     voxel_tensor: Any = None
     pc_voxel_id: Any = None
     pc_voxel_csr: Any = None  # (order, starts): points grouped by voxel, for the deterministic gather backward
+    scene_counts: Any = None  # points per scene (not a reference field)
     # semantics
     sem_labels: Optional[torch.Tensor] = None
     obj_cls_labels: Optional[torch.Tensor] = None
@@ -75,9 +76,11 @@ class PointCloud:
     # -------------------------------------------------------------------------------------------------
     @staticmethod
     def collate(point_clouds: Sequence["PointCloud"], voxel_size: Optional[Sequence[float]] = None,
-                augmentation: Optional[Dict[str, float]] = None, pyramid_levels: int = 0) -> PointCloudBatch:
+                augmentation: Optional[Dict[str, float]] = None, pyramid_levels: int = 0, voxels: bool = True) -> PointCloudBatch:
         """``pyramid_levels`` (the caller's U-Net depth - 1; the device prefetcher passes it): the row counts of that many
-        stride-2 levels come back with the voxelisation's single host read and ride on ``voxel_tensor.level_counts``."""
+        stride-2 levels come back with the voxelisation's single host read and ride on ``voxel_tensor.level_counts``.
+        ``voxels=False``: un-voxelised scenes stay un-voxelised (``voxel_tensor`` None, ``scene_counts`` set): the caller does
+        that part itself (dataset/prefetch.py: voxelisation + the backbone's rulebooks as one native call on a worker thread)"""
         n_scenes = len(point_clouds)
         first = point_clouds[0]
         if first.num_instances is None and first.instance_labels is not None and first.voxel_coords is None:
@@ -85,7 +88,7 @@ class PointCloud:
             # statistics run here, per batch, on the scenes' device
             from ..dataset.device_pipeline import prepare_batch
             assert voxel_size is not None, "un-voxelised scenes need voxel_size"
-            return prepare_batch(point_clouds, voxel_size, augmentation, pyramid_levels=pyramid_levels)
+            return prepare_batch(point_clouds, voxel_size, augmentation, pyramid_levels=pyramid_levels, voxels=voxels)
         assert not augmentation, "augmentation at collate time needs raw scenes (GAPartNetDataset(device_pipeline=True))"
         device = first.points.device
         counts = [int(pc.points.shape[0]) for pc in point_clouds]
@@ -136,14 +139,16 @@ class PointCloud:
                 shifted.append(torch.where(ids >= 0, ids + start, ids))  # out of place (the reference mutates the scene)
                 start += nv
             pc_voxel_id = torch.cat(shifted, dim=0)
+        elif not voxels:
+            indices = voxel_features = spatial_shape = pc_voxel_id = None
         else:
             assert voxel_size is not None, "un-voxelised scenes need voxel_size"
             level_counts = None
-            voxels = voxelize_scenes(points[:, :3], points, counts, voxel_size, pyramid_levels)
+            vox = voxelize_scenes(points[:, :3], points, counts, voxel_size, pyramid_levels)
             if pyramid_levels:
-                indices, voxel_features, spatial_shape, pc_voxel_id, csr, level_counts = voxels
+                indices, voxel_features, spatial_shape, pc_voxel_id, csr, level_counts = vox
             else:
-                indices, voxel_features, spatial_shape, pc_voxel_id, csr = voxels
+                indices, voxel_features, spatial_shape, pc_voxel_id, csr = vox
 
         voxel_tensor = None
         if indices is not None:
@@ -157,7 +162,7 @@ class PointCloud:
             obj_cls_labels=torch.tensor([pc.obj_cat for pc in point_clouds]),
             instance_labels=cat("instance_labels"), num_instances=num_instances,
             instance_regions=cat("instance_regions"), num_points_per_instance=num_points_per_instance,
-            instance_sem_labels=instance_sem_labels, gt_npcs=cat("gt_npcs"))
+            instance_sem_labels=instance_sem_labels, gt_npcs=cat("gt_npcs"), scene_counts=counts)
 
 
 _VOXEL_SIZE_CACHE = {}

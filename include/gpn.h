@@ -546,6 +546,31 @@ int gpn_proposals_voxel_mean_bwd(const float* dout, const int32_t* member_slot, 
                                  const int32_t* voxel_point_start, int64_t N, int C, float* dfeats, gpn_stream_t stream);
 
 /* ================================================================================================
+ * BP - the preparation of one batch for a sparse U-Net in ONE call (round 5): gpn_voxelize_scenes, its one host read, and the
+ * rulebook pyramid of the backbone - per level the SubM k = 3 tables (+ tile order from tile_order_min_rows rows), the stride-2
+ * map to the next level and its transpose (+ tile order), and, for the levels in the bit mask ident_levels, the k = 1 identity
+ * map.  Replaces the loader's per-scene CPU voxelisation (dataset/gapartnet.py:179-205) and spconv's indice-pair construction
+ * inside the forward pass (network/backbone.py:19-36, 74-90, 149-152) - the same launches as the separate entry points of
+ * sections V / K1 / K2, issued from one native loop into ONE caller-allocated arena.  The call BLOCKS (a blocking-sync event on
+ * `stream`) for the voxeliser's sizes; it may be called from any thread (`device` = HIP device ordinal, set for the calling
+ * thread) - measured, a worker thread loses to calling it inline (csrc/prepare.hip).
+ * desc_host [gpn_backbone_prepare_desc_words(n_levels)] i64, HOST memory; offsets are bytes from the arena base, -1 = absent:
+ *   [0] voxels V  [1..3] spatial shape of level 0  [4] dropped points  [5] != 0: fall back to the separate calls (a cell index
+ *   beyond the packed keys, an empty batch, an empty level)  [6] n_levels  [7] arena bytes used
+ *   [8] voxel_feats [M,C] f32  [9] indices4 [M,4] i32  [10] pc_voxel_id [M] i32  [11] point_order [M] i32  [12] voxel_point_start [M+1]
+ *   level l at 16 + 48 l: rows, shape[3], indices offset ([rows,4] i32), 3 spare, then 4 rulebooks x 10 words
+ *   (SubM, down = dst coarse, its transpose = dst fine, identity): nbr, pair_src, pair_dst, tile_off, num_pairs, nbr_p, perm
+ *   (offsets), n_src, n_dst, K.  Pair lists have the capacities of the separate entry points (27 n, n fine rows, n).
+ * pinned_stats_host [8 + n_levels] i64: pinned host memory the statistics are copied to.
+ * ================================================================================================ */
+int gpn_backbone_prepare_desc_words(int n_levels);
+size_t gpn_backbone_prepare_arena_bytes(int64_t M, int C, int64_t S, int n_levels);
+int gpn_backbone_prepare(const float* points, const float* feats, const int64_t* seg_offsets, int64_t M, int C, int64_t S,
+                         const float* voxel_size_host, int n_levels, uint32_t ident_levels, int64_t tile_order_min_rows,
+                         int tile_order_block, int device, void* arena, size_t arena_bytes, int64_t* desc_host,
+                         int64_t* pinned_stats_host, gpn_stream_t stream);
+
+/* ================================================================================================
  * PP - post-processing of a validation / test step's proposals in one call (round 5): filter_invalid_proposals +
  * apply_nms of the reference (network/grouping_utils.py:159-298, called from network/model.py:667-692, 807-857).
  * Inputs as gpn_proposals_build left them: score_preds [P] f32 (the sigmoid scores), sizes [P] i64, proposal_offsets [P+1] i32,
