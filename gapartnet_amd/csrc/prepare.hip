@@ -136,6 +136,10 @@ extern "C" int gpn_backbone_prepare(const float* points, const float* feats, con
     return GPN_OK;
   }
   // ---- the rulebook pyramid (sections K1 / K2) ---------------------------------------------------------------------------------
+  // (Round 5 also measured these ~150 launches queued BEHIND an event recorded on the training stream at the prefetcher's mid-step
+  // hook, so that they run beside the proposal stage instead of beside the backbone's decoder: 7.59 - 7.74 -> 7.73 - 7.95 ms per step,
+  // four interleaved pairs - slower; the builders disturb the proposal stage's chain of small dependent kernels more than they
+  // disturb big convs.  Removed.)
   const int32_t* indices = idx4;
   int64_t n = V;
   int32_t shape[3] = {(int32_t)desc_host[1], (int32_t)desc_host[2], (int32_t)desc_host[3]};

@@ -721,13 +721,15 @@ extern "C" int gpn_rulebook_tile_order(const int32_t* nbr, int K, int64_t n, int
   size_t prim_bytes = sort_temp_bytes(n);
   void* prim_tmp = w.take<char>(prim_bytes);
   GPN_CHECK_WS(w);
-  if (block_rows == 16384 || block_rows == 8192 || block_rows == 4096) {  // a block fits one workgroup's LDS: one launch
+  if (block_rows == 16384 || block_rows == 8192 || block_rows == 4096 || block_rows == 2048 || block_rows == 1024) {  // a block fits one workgroup's LDS: one launch
     uint32_t* mask = reinterpret_cast<uint32_t*>(vals);
     hipLaunchKernelGGL(tile_order_mask_kernel, dim3((int)gpn::cdiv(n, kThreads)), dim3(kThreads), 0, stream, nbr, K, n, mask);
     GPN_CHECK_LAUNCH();
     const int rc = block_rows == 16384 ? launch_tile_order_block_sort<1024, 16>(mask, K, n, perm, stream)
                    : block_rows == 8192 ? launch_tile_order_block_sort<512, 16>(mask, K, n, perm, stream)
-                                        : launch_tile_order_block_sort<256, 16>(mask, K, n, perm, stream);
+                   : block_rows == 4096 ? launch_tile_order_block_sort<256, 16>(mask, K, n, perm, stream)
+                   : block_rows == 2048 ? launch_tile_order_block_sort<256, 8>(mask, K, n, perm, stream)
+                                        : launch_tile_order_block_sort<128, 8>(mask, K, n, perm, stream);
     if (rc != GPN_OK) return rc;
   } else {
     const int grid = (int)gpn::cdiv(n, kThreads);

@@ -149,7 +149,7 @@ def voxelize(points, feats, seg_offsets, seg_range_min, seg_range_max, voxel_siz
 _PINNED_STATS = []  # pinned int64 buffers of finished voxelize_scenes_begin / _finish pairs, for reuse
 
 
-def voxelize_scenes_begin(points, feats, seg_offsets, voxel_size, n_levels=0):
+def voxelize_scenes_begin(points, feats, seg_offsets, voxel_size, n_levels=0, sorted_form=False):
     """first half of ``voxelize_scenes``: every launch of gpn_voxelize_scenes plus an asynchronous copy of its statistics to
     pinned memory - NO host read.  ``voxelize_scenes_finish(handle)`` is the second half; issued a step later (the device
     prefetcher does: dataset/prefetch.py) it finds the statistics there and does not wait."""
@@ -165,9 +165,12 @@ def voxelize_scenes_begin(points, feats, seg_offsets, voxel_size, n_levels=0):
     stats = torch.empty((8 + n_levels,), dtype=torch.int64, device=dev)
     L = _C.lib()
     ws = _ws(L.gpn_voxelize_scenes_ws_bytes(i64(M), i32(C), i64(S), i32(n_levels)), dev)
-    check(L.gpn_voxelize_scenes(ptr(points), ptr(feats), ptr(seg_offsets), i64(M), i32(C), i64(S), host_f32x3(voxel_size),
-                                i32(n_levels), ptr(vf), ptr(idx4), ptr(pid), ptr(order), ptr(vstart), ptr(stats), ptr(ws),
-                                szt(ws.numel()), _stream()), "gpn_voxelize_scenes")
+    # (sorted_form: the stable-sort implementation the sort-free one replaced in round 5 - kept as the fallback for grids that do
+    # not fit the occupancy bitmap, and what the tests compare the sort-free form with)
+    fn = L.gpn_voxelize_scenes_sorted if sorted_form else L.gpn_voxelize_scenes
+    check(fn(ptr(points), ptr(feats), ptr(seg_offsets), i64(M), i32(C), i64(S), host_f32x3(voxel_size),
+             i32(n_levels), ptr(vf), ptr(idx4), ptr(pid), ptr(order), ptr(vstart), ptr(stats), ptr(ws),
+             szt(ws.numel()), _stream()), "gpn_voxelize_scenes")
     host = None
     for i, buf in enumerate(_PINNED_STATS):
         if buf.numel() == stats.numel():
@@ -194,12 +197,15 @@ def voxelize_scenes_finish(handle):
             st[8:8 + n_levels])
 
 
-def voxelize_scenes(points, feats, seg_offsets, voxel_size, n_levels=0):
+def voxelize_scenes(points, feats, seg_offsets, voxel_size, n_levels=0, sorted_form=False):
     """Scene-batch voxelisation with the reference's per-scene ranges and NO host read before or between the launches
     (gpn_voxelize_scenes).  -> (voxel_feats [V,C], indices [V,4] i32 = (scene,x,y,z), pc_voxel_id [M] i32, point_order [M],
     voxel_point_start [V+1], max_coord [3 ints], dropped, level_counts [n_levels ints]) after ONE host read, or None when
     a cell index did not fit the packed keys (>= 1024 cells along an axis: the caller takes voxelize() instead)."""
-    return voxelize_scenes_finish(voxelize_scenes_begin(points, feats, seg_offsets, voxel_size, n_levels))
+    got = voxelize_scenes_finish(voxelize_scenes_begin(points, feats, seg_offsets, voxel_size, n_levels, sorted_form))
+    if got is None and not sorted_form:  # (stats[5] = 2: the batch's grid does not fit the sort-free form's bitmap)
+        got = voxelize_scenes_finish(voxelize_scenes_begin(points, feats, seg_offsets, voxel_size, n_levels, True))
+    return got
 
 
 # ---------------------------------------------------------------------------------------------------- BP

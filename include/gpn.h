@@ -110,7 +110,16 @@ int gpn_voxelize_ex(const float* points, const float* feats, const int64_t* seg_
  *   [5] != 0: a cell index >= 1024 occurred (results incomplete: use gpn_voxelize_ex with the true extent),
  *   [8 + l] rows of stride-2 level l + 1 below the voxel set (= gpn_rulebook_level_counts), l < n_levels.
  * indices4 [M,4] i32 = (segment, x, y, z) per voxel; the other outputs as gpn_voxelize_ex; same order, same means. */
+/* round 5: gpn_voxelize_scenes runs WITHOUT a sort (BASELINE.json "hash-table voxelization"): cell occupancy in a bitmap laid out in
+ * (segment, x, y, z) order over the batch's grid (cells per axis reduced on the device), voxel id = popcount rank of the cell's bit,
+ * points grouped by a counting placement + an ascending sort of every voxel's own few points.  Bit-identical outputs.  stats[5] = 2:
+ * the batch's grid exceeds the bitmap (2^27 cells) - like stats[5] = 1 (a cell index >= 1024) the caller takes another path:
+ * gpn_voxelize_scenes_sorted (the stable radix sort of 10-bit-per-axis packed keys; same contract, same workspace query). */
 size_t gpn_voxelize_scenes_ws_bytes(int64_t M, int C, int64_t S, int n_levels);
+int gpn_voxelize_scenes_sorted(const float* points, const float* feats, const int64_t* seg_offsets, int64_t M, int C, int64_t S,
+                               const float* voxel_size_host, int n_levels, float* voxel_feats, int32_t* indices4,
+                               int32_t* pc_voxel_id, int32_t* point_order, int32_t* voxel_point_start, int64_t* stats, void* ws,
+                               size_t ws_bytes, gpn_stream_t stream);
 int gpn_voxelize_scenes(const float* points, const float* feats, const int64_t* seg_offsets, int64_t M, int C, int64_t S,
                         const float* voxel_size_host, int n_levels, float* voxel_feats, int32_t* indices4,
                         int32_t* pc_voxel_id, int32_t* point_order, int32_t* voxel_point_start, int64_t* stats, void* ws,

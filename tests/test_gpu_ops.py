@@ -173,6 +173,40 @@ def test_scene_batch_voxelisation_with_one_host_read(H, cuda):
     assert out[5] is None and out[0].shape[0] > 3900 and max(out[2]) > 1024
 
 
+@pytest.mark.parametrize("case", ["bench", "ragged", "heavy", "dropped", "one_point"])
+def test_sort_free_scene_voxelisation_equals_the_sorting_form(H, cuda, case):
+    """gpn_voxelize_scenes (round 5: occupancy bitmap in key order + popcount ranks + counting placement, no sort) against
+    gpn_voxelize_scenes_sorted (stable radix sort of packed keys; pinned to the oracle through the per-call path): voxel order,
+    point -> voxel map, the points-by-voxel CSR (ascending point order inside a voxel, dropped points last), ordered means,
+    extent, dropped count and the coarse levels' row counts - all EQUAL.  Cases: the bench's batch, ragged scene sizes, voxels
+    holding hundreds of points, points that are dropped (NaN coordinates), a one-point scene."""
+    rng = np.random.default_rng({"bench": 1, "ragged": 2, "heavy": 3, "dropped": 4, "one_point": 5}[case])
+    counts = {"bench": [20000] * 8, "ragged": [3000, 1, 4500, 777, 12000], "heavy": [6000, 6000], "dropped": [5000, 4000, 3000],
+              "one_point": [1]}[case]
+    M = sum(counts)
+    xyz = rng.uniform(-0.5, 0.5, (M, 3)).astype(np.float32)
+    if case == "heavy":
+        xyz[::2] = np.round(xyz[::2] * 4) / 4 + 0.003   # a few hundred points per voxel on a coarse lattice
+    if case == "dropped":
+        xyz[rng.choice(M, 37, replace=False), rng.integers(0, 3, 37)] = np.nan
+    xyz = torch.from_numpy(xyz).to(cuda)
+    feats = torch.cat([xyz.nan_to_num(0.0), torch.from_numpy(rng.uniform(0, 1, (M, 3)).astype(np.float32)).to(cuda)], 1)
+    offsets = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int64, device=cuda)
+    a = H.voxelize_scenes(xyz, feats, offsets, [0.01] * 3, 5, sorted_form=True)
+    b = H.voxelize_scenes(xyz, feats, offsets, [0.01] * 3, 5)
+    assert a is not None and b is not None
+    names = ("voxel_feats", "indices", "pc_voxel_id", "point_order", "voxel_point_start")
+    for name, x, y in zip(names, a[:5], b[:5]):
+        assert x.shape == y.shape and x.dtype == y.dtype, name
+        assert torch.equal(x, y), name
+    assert list(a[5]) == list(b[5]) and a[6] == b[6] and list(a[7]) == list(b[7]), (a[5:], b[5:])
+    if case == "dropped":
+        assert a[6] == 37 and int((b[2] < 0).sum()) == 37
+    if case == "heavy":
+        sizes = torch.diff(b[4])
+        assert int(sizes.max()) > 40
+
+
 # ------------------------------------------------------------------------------------------------ C
 CONV_SHAPES = [(16, 16), (32, 32), (48, 48), (64, 64), (80, 80), (96, 96), (112, 112), (32, 16), (64, 32), (96, 48),
                (128, 64), (160, 80), (192, 96), (16, 32), (96, 112)]
