@@ -184,7 +184,7 @@ struct WgradReduceJob {
   int64_t elems;
   int S, K, cin, cout, oki, few;
 };
-int wgrad_slices(int K, int cin, int cout, int64_t n_dst, bool device_counted = false);
+int wgrad_slices(int K, int cin, int cout, int64_t n_dst);
 int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream,
                    const int64_t* n_dst_dev = nullptr);
 WgradReduceJob wgrad_reduce_job(const float* partial, int S, int K, int cin, int cout, int flags, float* dW);

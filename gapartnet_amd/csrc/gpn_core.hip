@@ -31,7 +31,7 @@ ProfSlot g_prof[GPN_K_COUNT];
 const char* kEntryPoints[] = {
     "gpn_voxelize", "gpn_voxelize_ws_bytes", "gpn_rulebook_subm3", "gpn_rulebook_subm3_ws_bytes",
     "gpn_rulebook_down", "gpn_rulebook_down_ws_bytes", "gpn_rulebook_down_lists",
-    "gpn_rulebook_down_lists_ws_bytes", "gpn_rulebook_level_counts", "gpn_rulebook_identity", "gpn_rulebook_level_counts_ws_bytes", "gpn_voxelize_ex", "gpn_voxelize_scenes", "gpn_voxelize_scenes_sorted", "gpn_voxelize_scenes_ws_bytes", "gpn_spconv_pack_weights", "gpn_spconv_fwd", "gpn_spconv_fwd_ws_bytes", "gpn_spconv_fwd_ordered", "gpn_rulebook_tile_order_ws_bytes", "gpn_rulebook_tile_order", "gpn_spconv_tiles_min_tiles", "gpn_spconv_direct_split", "gpn_spconv_fwd_w", "gpn_spconv_fwd_w_ws_bytes", "gpn_spconv_wgrad", "gpn_spconv_wgrad_stretch",
+    "gpn_rulebook_down_lists_ws_bytes", "gpn_rulebook_level_counts", "gpn_rulebook_identity", "gpn_rulebook_level_counts_ws_bytes", "gpn_voxelize_ex", "gpn_voxelize_scenes", "gpn_voxelize_scenes_sorted", "gpn_voxelize_scenes_ws_bytes", "gpn_spconv_pack_weights", "gpn_spconv_fwd", "gpn_spconv_fwd_ws_bytes", "gpn_spconv_fwd_ordered", "gpn_rulebook_tile_order_ws_bytes", "gpn_rulebook_tile_order", "gpn_spconv_tiles_min_tiles", "gpn_spconv_direct_split", "gpn_spconv_fwd_w", "gpn_spconv_fwd_w_ws_bytes", "gpn_spconv_wgrad",
     "gpn_spconv_wgrad_ws_bytes", "gpn_gather_rows", "gpn_scatter_rows_csr", "gpn_bn_ws_bytes", "gpn_bn_fwd_train", "gpn_bn_fwd_eval", "gpn_bn_bwd", "gpn_net_ws_bytes", "gpn_net_bn_fusion", "gpn_net_wgrad_group", "gpn_net_forward", "gpn_linear_supported", "gpn_linear_fwd", "gpn_linear_bwd_ws_bytes", "gpn_linear_bwd", "gpn_net_backward", "gpn_net_forward_pair", "gpn_net_backward_pair", "gpn_point_losses_ws_bytes", "gpn_point_losses_fwd", "gpn_point_losses_fwd_metrics", "gpn_point_losses_bwd", "gpn_score_loss", "gpn_npcs_loss_fwd", "gpn_npcs_loss_bwd", "gpn_ball_query", "gpn_ball_query_grid_ws_bytes", "gpn_ball_query_grid", "gpn_ccl",
     "gpn_ccl_ws_bytes", "gpn_segmented_reduce", "gpn_segmented_maxpool_fwd", "gpn_segmented_maxpool_bwd",
     "gpn_instance_iou", "gpn_nms", "gpn_nms_ws_bytes", "gpn_pn2_ball_query", "gpn_pn2_group_points",

@@ -611,7 +611,7 @@ class WgradWorker {
           }
           return GPN_OK;
         }
-        const int S = gpn::wgrad_slices(j0.K, j0.cin, j0.cout, gpn::plan_rows(j0.n_dst, j0.rows), j0.rows.dev != nullptr);
+        const int S = gpn::wgrad_slices(j0.K, j0.cin, j0.cout, gpn::plan_rows(j0.n_dst, j0.rows));
         const size_t bytes = gpn::align_up((size_t)S * elems * sizeof(float));
         if (used + n_sets * bytes > room || n_pending + n_sets > gpn::kWgradReduceJobs) flush();
         if (n_sets * bytes > ws_bytes_ || !ws_) {

@@ -19,8 +19,6 @@
 //  * gather_rows / scatter_rows_csr: features[pc_voxel_id] and its transpose as an ordered CSR sum (deterministic).
 #include <cstdlib>
 
-#include <atomic>
-
 #include "gpn_common.h"
 #include "spconv_pack.h"
 
@@ -287,11 +285,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const ReduceBatc
   else wgrad_reduce_tree(q.partial, q.S, q.elems, q.K, q.cin, q.cout, q.oki, q.dW, blk);
 }
 
-bool wgrad_stretch_shape(int K, int cin, int cout, int64_t n_dst);
-int stretch_tiles(int cin, int cout, int64_t n_dst);
-int wgrad_splits(int K, int cin, int cout, int64_t n_dst, bool stretch_ok = true) {
-  if (stretch_ok && wgrad_stretch_shape(K, cin, cout, n_dst))  // one partial per destination stretch
-    return (int)gpn::cdiv(gpn::cdiv(n_dst, GPN_TILE_ROWS), stretch_tiles(cin, cout, n_dst));
+int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
   const int ct_tiles = cin / 16;
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int cig = (ct_tiles + CT - 1) / CT;
@@ -335,197 +329,6 @@ int launch_wgrad(const gpn::WgradSets& sets, int K, int64_t n_dst, int cin, int 
   const int dealt = (S >= 8 && S % 8 == 0) ? 1 : 0;  // slices dealt to the XCDs (round 4: -10 % per layer at the two large levels)
   const dim3 grid = dealt ? dim3((unsigned)(K * S * n_z)) : dim3(K, S, n_z);
   hipLaunchKernelGGL((spconv_wgrad_lds_kernel<CT, NT>), grid, dim3(256), 0, stream, sets, n_tiles, cin, K, S, cig, n_z, dealt, n_dev);
-  GPN_CHECK_LAUNCH();
-  return GPN_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// wgrad, DESTINATION-STRETCH form (round 5): the LDS staging of per-rule feature tiles BASELINE.json names, for the SubM k = 3
-// layers of the large levels.  The pair-list kernel above gathers both rows of every pair, tap by tap: at the 80k-row level
-// 229 MB per 32 -> 32 layer out of L2 / the Infinity Cache for 28 MB of operands (every row ~11 times as a source and ~11 times
-// as a destination), which is what it waits for and what it costs the dgrad chain running beside it.  Here a workgroup owns a
-// STRETCH of consecutive destination rows (a multiple of the 32-row tiles the pair lists are indexed by):
-//   * its rows of dout are contiguous: staged into LDS once, coalesced;
-//   * the pairs of a tap whose destination lies in the stretch are one contiguous piece of that tap's list, and - rows being in
-//     (scene, x, y, z) order - their SOURCE rows are a nearly dense window: for the nine taps of one dx the windows coincide up
-//     to a few y-lines.  So per dx group ONE window of `in` (stretch + a few dozen rows) is staged, coalesced, and the nine
-//     taps contract out of LDS: lane (i, g) reads channel i of pair g's rows (the MFMA operand layout of the kernel above);
-//   * all 27 taps' accumulators stay in registers (wave w owns taps w, w + 4, ...): one [K, cin, cout] partial per stretch.
-// Bytes per 32 -> 32 layer at the 80k-row level: ~4 x 10 MB of staging + 2 x 28 MB of partials instead of 229 + 8.  A window that
-// does not fit (rows not in key order, a pathological scene) is read from global memory instead - same sums.  Deterministic:
-// fixed pair order per (stretch, tap), fixed-order slice sums (wgrad_reduce_*).  Shapes: cin, cout in {16, 32}, K = 27,
-// exactly-sized row counts; everything else takes the pair-list kernel.
-#ifndef GPN_STRETCH_WAVES
-#define GPN_STRETCH_WAVES 8
-#endif
-#ifndef GPN_STRETCH_SHRINK
-#define GPN_STRETCH_SHRINK 1  // divides the stretch / window capacities (more workgroups per CU, more partials)
-#endif
-template <int CI, int CO>
-struct StretchCfg {
-  static constexpr int PA = LdsPitch<CI * 16>::value, PB = LdsPitch<CO * 16>::value;
-  static constexpr int NW = GPN_STRETCH_WAVES, TPW = (27 + NW - 1) / NW;  // waves per workgroup, taps per wave
-  // rows of a stretch / of a source window that fit ~142 KB of LDS together (one workgroup per CU)
-  static constexpr int RMAX = ((CI == 1 && CO == 1) ? 640 : (CI == 2 && CO == 2) ? 320 : 512) / GPN_STRETCH_SHRINK;
-  static constexpr int WCAP = ((CI == 1 && CO == 1) ? 768 : (CI == 2 && CO == 2) ? 416 : (CI == 2 ? 576 : 640)) / GPN_STRETCH_SHRINK;
-  static constexpr size_t lds_bytes = ((size_t)RMAX * PB + (size_t)WCAP * PA) * sizeof(float);
-};
-
-template <int CI, int CO>
-__global__ __launch_bounds__(64 * GPN_STRETCH_WAVES) void spconv_wgrad_stretch_kernel(const gpn::WgradSets sets, int64_t n_rows,
-                                                                                      int64_t n_tiles32, int tiles_per_stretch) {
-  using Cfg = StretchCfg<CI, CO>;
-  constexpr int PA = Cfg::PA, PB = Cfg::PB, CIN = CI * 16, COUT = CO * 16, K = 27, NW = Cfg::NW, TPW = Cfg::TPW, NT = 64 * NW;
-  __shared__ __attribute__((aligned(16))) float sB[Cfg::RMAX * PB];
-  __shared__ __attribute__((aligned(16))) float sA[Cfg::WCAP * PA];
-  __shared__ int32_t s_a[K], s_b[K], s_lo[K], s_hi[K];
-  const int set = blockIdx.y;
-  const float* __restrict__ in = sets.s[set].in;
-  const float* __restrict__ dout = sets.s[set].dout;
-  const int32_t* __restrict__ pair_src = sets.s[set].pair_src;
-  const int32_t* __restrict__ pair_dst = sets.s[set].pair_dst;
-  const int32_t* __restrict__ tile_off = sets.s[set].tile_off;
-  float* __restrict__ partial = sets.s[set].partial;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i16 = lane & 15, g = lane >> 4;
-  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_stretch;
-  const int64_t t1 = t0 + tiles_per_stretch < n_tiles32 ? t0 + tiles_per_stretch : n_tiles32;
-  const int64_t r0 = t0 * GPN_TILE_ROWS;
-  const int64_t r1 = t1 * GPN_TILE_ROWS < n_rows ? t1 * GPN_TILE_ROWS : n_rows;
-  if (tid < K) {  // this stretch's piece of every tap's pair list, and the source rows it spans (sources ascend inside a tap)
-    const int32_t a = tile_off[(int64_t)tid * (n_tiles32 + 1) + t0], b = tile_off[(int64_t)tid * (n_tiles32 + 1) + t1];
-    s_a[tid] = a, s_b[tid] = b;
-    s_lo[tid] = a < b ? pair_src[a] : 0x7fffffff;
-    s_hi[tid] = a < b ? pair_src[b - 1] : -1;
-  }
-  {  // the stretch's rows of dout -> LDS
-    const int n4 = (int)(r1 - r0) * (COUT / 4);
-    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(dout + r0 * COUT);
-    for (int e = tid; e < n4; e += NT) {
-      const int row = e / (COUT / 4), c4 = e - row * (COUT / 4);
-      *reinterpret_cast<f32x4*>(sB + row * PB + 4 * c4) = src[e];
-    }
-  }
-  f32x4 acc[TPW][CI][CO];
-#pragma unroll
-  for (int jj = 0; jj < TPW; ++jj)
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-      for (int co = 0; co < CO; ++co) acc[jj][ci][co] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-#pragma unroll
-  for (int dxg = 0; dxg < 3; ++dxg) {
-    int32_t w0 = 0x7fffffff, w1 = -1;
-    for (int t = 0; t < 9; ++t) {  // (uniform: every thread reads the same nine entries)
-      w0 = min(w0, s_lo[dxg * 9 + t]);
-      w1 = max(w1, s_hi[dxg * 9 + t]);
-    }
-    w1 += 1;
-    // (first / last source of every piece: the exact span when the rows are in key order.  A window that does not fit is cut)
-    const uint32_t win = w0 < w1 ? (uint32_t)min(w1 - w0, (int32_t)Cfg::WCAP) : 0u;
-    if (win) {
-      const int n4 = (int)win * (CIN / 4);
-      const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(in + (int64_t)w0 * CIN);
-      for (int e = tid; e < n4; e += NT) {
-        const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
-        *reinterpret_cast<f32x4*>(sA + row * PA + 4 * c4) = src[e];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int jj = 0; jj < TPW; ++jj) {
-      const int k = wave + NW * jj;
-      if (k >= K || k / 9 != dxg) continue;  // (uniform per wave)
-      const int32_t a = s_a[k], b = s_b[k];
-      if (a >= b) continue;
-      int32_t pn = a + lane;
-      pn = pn < b ? pn : b - 1;
-      int32_t src_n = pair_src[pn], dst_n = pair_dst[pn];
-      for (int32_t p0 = a; p0 < b; p0 += 64) {
-        const int32_t src = src_n, dst = dst_n;
-        if (p0 + 64 < b) {  // the next 64 pairs' indices are on their way while these are contracted
-          pn = p0 + 64 + lane;
-          pn = pn < b ? pn : b - 1;
-          src_n = pair_src[pn], dst_n = pair_dst[pn];
-        }
-        // (a source outside the staged window - rows not in key order, a window that did not fit - is read from global memory)
-        const bool staged = (uint32_t)(src - w0) < win;
-        const int32_t so = staged ? (src - w0) * PA : -1 - src;
-        const int32_t dof = (dst - (int32_t)r0) * PB;
-        const int n_here = b - p0 < 64 ? b - p0 : 64;
-        const int groups = (n_here + 3) >> 2;
-        for (int grp0 = 0; grp0 < groups; grp0 += 4) {  // four groups of four pairs in flight
-          float bv[4][CO], av[4][CI];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int sl = (grp0 + u) * 4 + g;  // (< 64: groups <= 16)
-            const int32_t so_g = __shfl(so, sl & 63, 64), do_g = __shfl(dof, sl & 63, 64);
-            const bool valid = sl < n_here;
-#pragma unroll
-            for (int co = 0; co < CO; ++co) bv[u][co] = sB[do_g + co * 16 + i16];
-#pragma unroll
-            for (int ci = 0; ci < CI; ++ci) {
-              float v;
-              if (so_g >= 0) v = sA[so_g + ci * 16 + i16];
-              else v = in[(int64_t)(-1 - so_g) * CIN + ci * 16 + i16];
-              av[u][ci] = valid ? v : 0.f;
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-              for (int co = 0; co < CO; ++co)
-                acc[jj][ci][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][ci], bv[u][co], acc[jj][ci][co], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();  // (the next group's window overwrites sA)
-  }
-  // partial[stretch][k][ci][co]: D[row = 4g + r][col = i16] of every (ci, co) tile
-#pragma unroll
-  for (int jj = 0; jj < TPW; ++jj) {
-    const int k = wave + NW * jj;
-    if (k >= K) continue;
-    float* __restrict__ pb = partial + ((int64_t)blockIdx.x * K + k) * (int64_t)(CIN * COUT);
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-      for (int co = 0; co < CO; ++co)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pb[(ci * 16 + 4 * g + r) * COUT + co * 16 + i16] = acc[jj][ci][co][r];
-  }
-}
-
-// which layers take the destination-stretch kernel, and with how many stretches (= slices of the partial buffer)
-constexpr int64_t kStretchMinRows = 16384;
-int stretch_rmax(int cin, int cout) {
-  return cin == 16 && cout == 16 ? StretchCfg<1, 1>::RMAX : cin == 32 && cout == 32 ? StretchCfg<2, 2>::RMAX : StretchCfg<2, 1>::RMAX;
-}
-int env_wgrad_stretch() {  // env GPN_WGRAD_STRETCH (0: the pair-list kernel everywhere)
-  const char* e = getenv("GPN_WGRAD_STRETCH");
-  return e ? atoi(e) : 1;
-}
-std::atomic<int> g_wgrad_stretch{env_wgrad_stretch()};
-bool wgrad_stretch_shape(int K, int cin, int cout, int64_t n_dst) {
-  return g_wgrad_stretch.load(std::memory_order_relaxed) != 0 && K == 27 && (cin == 16 || cin == 32) && (cout == 16 || cout == 32) && n_dst >= kStretchMinRows;
-}
-int stretch_tiles(int cin, int cout, int64_t n_dst) {  // 32-row tiles per stretch: ~one stretch per CU, within the LDS budget
-  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
-  int64_t m = gpn::cdiv(n_tiles, 256 * GPN_STRETCH_SHRINK);
-  const int64_t cap = stretch_rmax(cin, cout) / GPN_TILE_ROWS;
-  m = m > cap ? cap : m;
-  return (int)(m < 1 ? 1 : m);
-}
-
-template <int CI, int CO>
-int launch_wgrad_stretch(const gpn::WgradSets& sets, int64_t n_dst, hipStream_t stream) {
-  const int64_t n_tiles = gpn::cdiv(n_dst, GPN_TILE_ROWS);
-  const int m = stretch_tiles(CI * 16, CO * 16, n_dst);
-  const dim3 grid((unsigned)gpn::cdiv(n_tiles, m), (unsigned)sets.n);
-  hipLaunchKernelGGL((spconv_wgrad_stretch_kernel<CI, CO>), grid, dim3(64 * GPN_STRETCH_WAVES), 0, stream, sets, n_dst, n_tiles, m);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -644,12 +447,6 @@ extern "C" int gpn_spconv_pack_weights(const float* W, int K, int cin_w, int cou
   return GPN_OK;
 }
 
-// the destination-stretch weight-gradient kernel on (1, default) / off (0: the pair-list kernel for every layer); on < 0 queries.
-// Returns the previous setting.  Both are deterministic; they differ in the order of the sum over pairs (last bits).
-extern "C" int gpn_spconv_wgrad_stretch(int on) {
-  return on < 0 ? g_wgrad_stretch.load(std::memory_order_relaxed) : g_wgrad_stretch.exchange(on ? 1 : 0, std::memory_order_relaxed);
-}
-
 extern "C" size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_dst) {
   const int S = wgrad_splits(K, cin, cout, n_dst);
   return gpn::align_up((size_t)S * K * cin * cout * sizeof(float));
@@ -657,10 +454,7 @@ extern "C" size_t gpn_spconv_wgrad_ws_bytes(int K, int cin, int cout, int64_t n_
 
 namespace gpn {
 
-int wgrad_slices(int K, int cin, int cout, int64_t n_dst, bool device_counted) {
-  // (a device-counted layer always takes the pair-list kernel: its stretches would have to be laid out for the live row count)
-  return wgrad_splits(K, cin, cout, n_dst, !device_counted);
-}
+int wgrad_slices(int K, int cin, int cout, int64_t n_dst) { return wgrad_splits(K, cin, cout, n_dst); }
 
 // the contraction of sets.n layers of ONE shape (K, n_dst, cin, cout) into their partial[S][K][cin][cout] buffers
 int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cout, int S, hipStream_t stream,
@@ -670,12 +464,6 @@ int wgrad_contract(const WgradSets& sets, int K, int64_t n_dst, int cin, int cou
   const int CT = ct_tiles < 4 ? ct_tiles : 4;
   const int nt = cout / 16;
   gpn::ProfScope prof(GPN_K_SPCONV_WGRAD, stream, 0.0, 0.0);
-  if (!n_dst_dev && wgrad_stretch_shape(K, cin, cout, n_dst) && S == wgrad_splits(K, cin, cout, n_dst)) {
-    if (cin == 16 && cout == 16) return launch_wgrad_stretch<1, 1>(sets, n_dst, stream);
-    if (cin == 32 && cout == 32) return launch_wgrad_stretch<2, 2>(sets, n_dst, stream);
-    if (cin == 32 && cout == 16) return launch_wgrad_stretch<2, 1>(sets, n_dst, stream);
-    return launch_wgrad_stretch<1, 2>(sets, n_dst, stream);
-  }
   switch (CT) {
     case 1: return dispatch_wgrad_nt<1>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);
     case 2: return dispatch_wgrad_nt<2>(nt, sets, K, n_dst, cin, S, stream, n_dst_dev);

@@ -225,12 +225,6 @@ int gpn_spconv_wgrad(const float* in, const float* dout, const int32_t* pair_src
                      int cout, int flags /* GPN_LAYOUT_OKI: write dW as [Cout][K][Cin] */, float* dW, void* ws,
                      size_t ws_bytes, gpn_stream_t stream);
 
-/* round 5: SubM k = 3 layers of >= 16384 rows with 16 / 32 channels on both sides take the DESTINATION-STRETCH contraction
- * (csrc/spconv.hip): a workgroup owns a stretch of destination rows, stages them and - per dx group of nine taps - the window of
- * source rows their pairs reach into LDS, contracts all 27 taps out of LDS with the accumulators in registers, one partial per
- * stretch.  on = 0: the pair-list kernel everywhere; on < 0 queries; returns the previous setting (env GPN_WGRAD_STRETCH). */
-int gpn_spconv_wgrad_stretch(int on);
-
 /* BN — BatchNorm1d over a feature matrix [N, C] fused with the residual add and ReLU that follow it in every block of
  * the reference network (network/backbone.py:40-49 relu(bn(conv(x)) [+ shortcut]); norm_fn = BatchNorm1d(eps=1e-4,
  * momentum=0.1), network/model.py:86).  C % 4 == 0.  res may be NULL; relu = 0/1.

@@ -258,44 +258,6 @@ def test_weight_gradient_kernel_on_every_channel_pair(H, cuda, cin, cout, n_targ
     assert np.abs(host(a) - ref).max() <= 1e-4 * scale, (np.abs(host(a) - ref).max(), scale)
 
 
-@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (32, 16), (16, 32)])
-@pytest.mark.parametrize("order", ["key", "shuffled"])
-def test_destination_stretch_weight_gradient(H, cuda, cin, cout, order):
-    """the destination-stretch contraction (csrc/spconv.hip, round 5: stretch of dout rows + per-dx source window staged in LDS)
-    that the SubM layers of >= 16384 rows with 16 / 32 channels take: against the oracle at 1e-4 of the tensor's scale, against the
-    pair-list kernel it replaces there, bit-reproducible, both layouts.  "shuffled": rows NOT in key order - no source window
-    holds, the kernel's global-memory path computes the same sums."""
-    from gapartnet_amd import _C
-    rng = np.random.default_rng(cin * 31 + cout + len(order))
-    shape = [96, 96, 96]
-    idx = synth.surface_indices(rng, 4, shape, 8000)
-    if order == "shuffled":
-        idx = idx[rng.permutation(idx.shape[0])]
-    N = idx.shape[0]
-    assert N >= 16384, N
-    f = rng.normal(size=(N, cin)).astype(np.float32)
-    g = rng.normal(size=(N, cout)).astype(np.float32)
-    rb_ref = O.rulebook_subm3(idx, shape)
-    rb = H.rulebook_subm3(dev(idx, cuda), shape)
-    ref = O.spconv_wgrad(f, g, rb_ref, N, 27)
-    scale = np.abs(ref).max()
-    L = _C.lib()
-    assert L.gpn_spconv_wgrad_stretch(-1) == 1, "the stretch kernel is the default"
-    a = H.conv_wgrad(dev(f, cuda), dev(g, cuda), rb)
-    b = H.conv_wgrad(dev(f, cuda), dev(g, cuda), rb)
-    assert torch.equal(a, b), "two runs differ"
-    oki = H.conv_wgrad(dev(f, cuda), dev(g, cuda), rb, layout="oki")
-    assert torch.equal(oki.permute(1, 2, 0), a), "[Cout, K, Cin] layout differs"
-    assert np.abs(host(a) - ref).max() <= 1e-4 * scale, (np.abs(host(a) - ref).max(), scale)
-    L.gpn_spconv_wgrad_stretch(0)
-    try:
-        pairs = H.conv_wgrad(dev(f, cuda), dev(g, cuda), rb)
-    finally:
-        L.gpn_spconv_wgrad_stretch(1)
-    # (a different order of the same sums: the last bits may differ)
-    assert (pairs - a).abs().max().item() <= 2e-5 * scale
-
-
 @pytest.mark.parametrize("cin,cout", [(16, 32), (32, 48), (96, 112)])
 def test_down_and_inverse_conv(H, cuda, cin, cout):
     rng = np.random.default_rng(cin + cout)
