@@ -15,7 +15,7 @@ _lib = None
 
 _SIZE_T_FUNCS = (
     "gpn_voxelize_ws_bytes", "gpn_voxelize_scenes_ws_bytes", "gpn_rulebook_subm3_ws_bytes", "gpn_rulebook_down_ws_bytes",
-    "gpn_rulebook_down_lists_ws_bytes", "gpn_rulebook_level_counts_ws_bytes", "gpn_spconv_fwd_ws_bytes", "gpn_spconv_fwd_w_ws_bytes", "gpn_net_ws_bytes", "gpn_linear_bwd_ws_bytes", "gpn_ball_query_grid_ws_bytes", "gpn_point_losses_ws_bytes", "gpn_rulebook_tile_order_ws_bytes", "gpn_bn_ws_bytes", "gpn_spconv_wgrad_ws_bytes", "gpn_ccl_ws_bytes", "gpn_nms_ws_bytes", "gpn_pn2_furthest_point_sampling_ws_bytes", "gpn_pose_fit_ws_bytes", "gpn_proposals_revoxelize_ws_bytes", "gpn_proposals_postprocess_ws_bytes", "gpn_backbone_prepare_arena_bytes",
+    "gpn_rulebook_down_lists_ws_bytes", "gpn_rulebook_level_counts_ws_bytes", "gpn_spconv_fwd_ws_bytes", "gpn_spconv_fwd_w_ws_bytes", "gpn_net_ws_bytes", "gpn_linear_bwd_ws_bytes", "gpn_ball_query_grid_ws_bytes", "gpn_point_losses_ws_bytes", "gpn_rulebook_tile_order_ws_bytes", "gpn_bn_ws_bytes", "gpn_spconv_wgrad_ws_bytes", "gpn_ccl_ws_bytes", "gpn_nms_ws_bytes", "gpn_pn2_furthest_point_sampling_ws_bytes", "gpn_pose_fit_ws_bytes", "gpn_proposals_revoxelize_ws_bytes", "gpn_proposals_postprocess_ws_bytes", "gpn_backbone_prepare_arena_bytes", "gpn_scene_prepare_ws_bytes",
 )
 
 

@@ -39,7 +39,7 @@ const char* kEntryPoints[] = {
     "gpn_pn2_furthest_point_sampling", "gpn_pn2_furthest_point_sampling_ws_bytes",
     "gpn_pn2_furthest_point_sampling_ws", "gpn_pn2_three_nn", "gpn_pn2_knn", "gpn_pn2_three_interpolate",
     "gpn_pn2_three_interpolate_grad", "gpn_proposals_max_proposals", "gpn_proposals_build_ws_bytes", "gpn_proposals_build", "gpn_proposals_voxel_mean",
-    "gpn_proposals_voxel_mean_bwd", "gpn_proposals_revoxelize_ws_bytes", "gpn_proposals_revoxelize", "gpn_proposals_postprocess_ws_bytes", "gpn_proposals_postprocess", "gpn_backbone_prepare_desc_words", "gpn_backbone_prepare_arena_bytes", "gpn_backbone_prepare", "gpn_pose_fit_ws_bytes", "gpn_pose_fit", "gpn_copy_many", "gpn_adam_blocks", "gpn_adam_step", "gpn_adam_step_gated", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get", "gpn_prof_get_launches",
+    "gpn_proposals_voxel_mean_bwd", "gpn_proposals_revoxelize_ws_bytes", "gpn_proposals_revoxelize", "gpn_proposals_postprocess_ws_bytes", "gpn_proposals_postprocess", "gpn_backbone_prepare_desc_words", "gpn_backbone_prepare_arena_bytes", "gpn_backbone_prepare", "gpn_scene_prepare_max_instances", "gpn_scene_prepare_ws_bytes", "gpn_scene_prepare", "gpn_pose_fit_ws_bytes", "gpn_pose_fit", "gpn_copy_many", "gpn_adam_blocks", "gpn_adam_step", "gpn_adam_step_gated", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get", "gpn_prof_get_launches",
     "gpn_rulebook_subm3_dev", "gpn_rulebook_down_dev_ws_bytes", "gpn_rulebook_down_dev", "gpn_rulebook_down_lists_dev", "gpn_rulebook_identity_dev", "gpn_gather_rows_dev", "gpn_scatter_rows_csr_dev", "gpn_proposals_voxel_mean_dev", "gpn_proposals_targets_dev", "gpn_linear_fwd_dev", "gpn_linear_bwd_dev", "gpn_segmented_maxpool_fwd_dev", "gpn_segmented_maxpool_bwd_dev", "gpn_instance_iou_dev", "gpn_score_loss_dev", "gpn_npcs_loss_fwd_dev", "gpn_npcs_loss_bwd_dev",
     "gpn_last_error", "gpn_version"};
 }  // namespace

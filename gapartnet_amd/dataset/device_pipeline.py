@@ -18,6 +18,7 @@ float32 summation by at most an ulp (summed in float64 here); augmented coordina
 3-term float64 dot product.  Every function is plain torch and also runs on CPU tensors (that is how the CPU tests pin
 it against the per-scene functions in dataset/gapartnet.py).
 """
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -125,6 +126,31 @@ def inst_info_batch(points: torch.Tensor, instance_labels: torch.Tensor, sem_lab
     return {"instance_regions": regions, "num_points_per_instance": npi, "instance_sem_labels": isl}
 
 
+# the fused preparation (csrc/sceneprep.hip) for scenes on the GPU; GPN_SCENE_PREPARE=0: the torch formulation below everywhere
+FUSED = os.environ.get("GPN_SCENE_PREPARE", "1") != "0"
+
+
+def scene_offsets(counts: Sequence[int], dev: torch.device) -> torch.Tensor:
+    """[B + 1] int64 row offsets of the scenes on ``dev`` (no host-to-device copy when the scenes have one size)"""
+    if len(set(counts)) == 1:
+        return torch.arange(len(counts) + 1, dtype=torch.int64, device=dev) * int(counts[0])
+    return _upload(torch.as_tensor([0] + list(np.cumsum(counts)), dtype=torch.int64), dev)
+
+
+def _fused_scene_prepare(points, sem, ins, counts, mats, shifts):
+    """-> the outputs of hip_ops.scene_prepare (plus the padded tables under the names inst_info_batch uses), or None when the
+    library's tables do not hold a scene's instances (the caller then runs the torch formulation)"""
+    from .. import hip_ops
+    dev = points.device
+    m = s = None
+    if mats is not None:
+        aug = np.concatenate([np.ascontiguousarray(mats).reshape(len(counts), 9), np.ascontiguousarray(shifts)], axis=1)
+        aug_dev = _upload(torch.from_numpy(aug), dev)  # one small table: 9 + C doubles per scene
+        m = aug_dev[:, :9].contiguous()
+        s = aug_dev[:, 9:].contiguous() if bool((shifts != 0).any()) else None
+    return hip_ops.scene_prepare(points, sem, ins, scene_offsets(counts, dev), m, s)
+
+
 @torch.no_grad()
 def prepare_batch(raw: Sequence[PointCloud], voxel_size: Sequence[float], augmentation: Optional[Dict[str, float]] = None,
                   pyramid_levels: int = 0, voxels: bool = True) -> PointCloudBatch:
@@ -142,21 +168,29 @@ def prepare_batch(raw: Sequence[PointCloud], voxel_size: Sequence[float], augmen
         sem = torch.cat([pc.sem_labels for pc in raw], dim=0)
         ins = torch.cat([pc.instance_labels for pc in raw], dim=0)
         npcs = torch.cat([pc.gt_npcs for pc in raw], dim=0) if raw[0].gt_npcs is not None else None
-    if len(set(counts)) == 1:
-        batch_indices = torch.arange(n_scenes, dtype=torch.int32, device=dev).repeat_interleave(counts[0])
+    mats = shifts = None
+    if augmentation:
+        mats, shifts = draw_augmentation(n_scenes, color_channels=points.shape[1] - 3, **augmentation)
+    fused = _fused_scene_prepare(points, sem, ins, counts, mats, shifts) if dev.type == "cuda" and FUSED else None
+    if fused is not None:  # (csrc/sceneprep.hip: three launches and one host read instead of ~80 launches and four reads)
+        points, batch_indices, ins, info = fused["points"], fused["batch_indices"], fused["instance_labels"], fused
+        num_instances = fused["num_instances"]
     else:
-        batch_indices = torch.repeat_interleave(torch.arange(n_scenes, dtype=torch.int32, device=dev),
-                                                _upload(torch.as_tensor(counts, dtype=torch.int64), dev),
-                                                output_size=sum(counts))
-    ins, k = compact_instance_labels_batch(ins, batch_indices, n_scenes)
-    num_instances = [int(v) for v in k.tolist()]
+        if len(set(counts)) == 1:
+            batch_indices = torch.arange(n_scenes, dtype=torch.int32, device=dev).repeat_interleave(counts[0])
+        else:
+            batch_indices = torch.repeat_interleave(torch.arange(n_scenes, dtype=torch.int32, device=dev),
+                                                    _upload(torch.as_tensor(counts, dtype=torch.int64), dev),
+                                                    output_size=sum(counts))
+        ins, k = compact_instance_labels_batch(ins, batch_indices, n_scenes)
+        num_instances = [int(v) for v in k.tolist()]
     empty = [raw[s].pc_id for s in range(n_scenes) if num_instances[s] == 0]
     if empty:
         raise ValueError(f"scenes without a labelled instance: {empty} (the reference stops in ipdb, dataset/gapartnet.py:69-70)")
-    if augmentation:
-        mats, shifts = draw_augmentation(n_scenes, color_channels=points.shape[1] - 3, **augmentation)
-        points = augment_points(points, batch_indices, mats, shifts)
-    info = inst_info_batch(points, ins, sem, batch_indices, num_instances)
+    if fused is None:
+        if augmentation:
+            points = augment_points(points, batch_indices, mats, shifts)
+        info = inst_info_batch(points, ins, sem, batch_indices, num_instances)
     level_counts = voxel_tensor = pc_voxel_id = csr = None
     if voxels:
         vox = voxelize_scenes(points[:, :3], points, counts, voxel_size, pyramid_levels)

@@ -1027,6 +1027,48 @@ def proposals_postprocess(score_preds, sizes, proposal_offsets, point_indices, p
     return kept_ids[:n_kept], new_offsets[:n_kept + 1], src_row[:n_points]
 
 
+def scene_prepare(points, sem_labels, instance_labels, seg_offsets, mats=None, shifts=None):
+    """Section SP of include/gpn.h: label compaction, augmentation and the per-instance statistics of a batch of RAW scenes in three
+    launches and ONE host read (the instances per scene).  points [N, 3 + C] f32, sem_labels [N] int16 / int32 / int64,
+    instance_labels [N] i32, seg_offsets [B + 1] i64 (device), mats [B, 3, 3] / shifts [B, C] f64 on the device or None.
+    -> dict(points, batch_indices, instance_labels, instance_regions, num_points_per_instance, instance_sem_labels [B, max K],
+    num_instances = [K per scene]) or None when a scene has more distinct ids than the kernel tables hold."""
+    dev = _dev(points, instance_labels)
+    points, instance_labels = _c(points, torch.float32), _c(instance_labels, torch.int32)
+    sem_labels = sem_labels.contiguous()
+    sem_bytes = sem_labels.element_size()
+    assert sem_labels.dtype in (torch.int16, torch.int32, torch.int64), sem_labels.dtype
+    N, W = points.shape
+    B = int(seg_offsets.shape[0]) - 1
+    L = _C.lib()
+    cap = L.gpn_scene_prepare_max_instances()
+    out_points = torch.empty_like(points)
+    batch_indices = torch.empty((N,), dtype=torch.int32, device=dev)
+    ins_out = torch.empty((N,), dtype=torch.int32, device=dev)
+    regions = torch.empty((N, 9), dtype=torch.float32, device=dev)
+    npi = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    isl = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    overflow = torch.empty((1,), dtype=torch.int32, device=dev)
+    k_host = _PINNED_K.pop() if _PINNED_K and _PINNED_K[-1].numel() >= B else torch.empty((max(B, 64),), dtype=torch.int64).pin_memory()
+    ws = _ws(L.gpn_scene_prepare_ws_bytes(i32(B)), dev)
+    check(L.gpn_scene_prepare(ptr(points), ptr(sem_labels), i32(sem_bytes), ptr(instance_labels), ptr(_c(seg_offsets, torch.int64)),
+                              i64(N), i32(W - 3), i32(B), ptr(_c(mats, torch.float64)), ptr(_c(shifts, torch.float64)),
+                              ptr(out_points), ptr(batch_indices), ptr(ins_out), ptr(regions), ptr(npi), ptr(isl), ptr(k_host),
+                              ptr(overflow), ptr(ws), szt(ws.numel()), _stream()), "gpn_scene_prepare")
+    ev = torch.cuda.Event(blocking=True)
+    ev.record()
+    ev.synchronize()  # the preparation's one host read: K per scene, written into pinned memory by the first kernel
+    k = k_host[:B].tolist()
+    _PINNED_K.append(k_host)
+    if min(k) < 0:
+        return None
+    width = max(k)
+    return dict(points=out_points, batch_indices=batch_indices, instance_labels=ins_out, instance_regions=regions,
+                num_points_per_instance=npi[:, :width].contiguous(), instance_sem_labels=isl[:, :width].contiguous(),
+                num_instances=k)
+
+
+_PINNED_K = []
 _PINNED_COUNTS = []
 
 

@@ -580,6 +580,27 @@ int gpn_backbone_prepare(const float* points, const float* feats, const int64_t*
                          int64_t* pinned_stats_host, gpn_stream_t stream);
 
 /* ================================================================================================
+ * SP - the per-scene preparation of RAW scenes for a whole batch (round 5): what the reference's loader workers do per scene in
+ * numpy (dataset/gapartnet.py:55-82) - compact_instance_labels (:134-142), apply_augmentations (:85-120; the random draws stay
+ * on the host, 9 + C doubles per scene come in), generate_inst_info (:145-176) - in three launches.
+ * Inputs: points [N, 3 + C] f32 (scenes back to back, seg_offsets [B + 1] i64 on the device), sem_labels [N] (sem_bytes = 2 / 4 / 8:
+ * int16 / int32 / int64), instance_labels [N] i32 (negative = no instance), mats [B, 3, 3] f64 or NULL (xyz @ M in float64, rounded
+ * once), shifts [B, C] f64 or NULL (colour + shift in float64, rounded once).
+ * Outputs: points_out [N, 3 + C]; batch_indices [N] i32; instance_out [N] i32 (the non-negative ids of every scene renumbered
+ * 0..K-1 ascending; negatives kept); regions [N, 9] f32 = mean | min | max xyz of the point's instance (zeros off-instance; the mean
+ * from an order-independent fixed-point sum, within an ulp of numpy's); num_points_per_instance / instance_sem_labels
+ * [B, gpn_scene_prepare_max_instances()] i32 (count, semantic label of the instance's first point; 0 / -1 past a scene's K);
+ * num_instances_host [B] i64 = K per scene, written by the device into PINNED host memory (or NULL), -1 for a scene with more
+ * distinct ids than the tables hold - *overflow (device) is then 1 and the outputs are not to be used. */
+int gpn_scene_prepare_max_instances(void);
+size_t gpn_scene_prepare_ws_bytes(int B);
+int gpn_scene_prepare(const float* points, const void* sem_labels, int sem_bytes, const int32_t* instance_labels,
+                      const int64_t* seg_offsets, int64_t N, int C, int B, const double* mats, const double* shifts,
+                      float* points_out, int32_t* batch_indices, int32_t* instance_out, float* regions,
+                      int32_t* num_points_per_instance, int32_t* instance_sem_labels, int64_t* num_instances_host,
+                      int32_t* overflow, void* ws, size_t ws_bytes, gpn_stream_t stream);
+
+/* ================================================================================================
  * PP - post-processing of a validation / test step's proposals in one call (round 5): filter_invalid_proposals +
  * apply_nms of the reference (network/grouping_utils.py:159-298, called from network/model.py:667-692, 807-857).
  * Inputs as gpn_proposals_build left them: score_preds [P] f32 (the sigmoid scores), sizes [P] i64, proposal_offsets [P+1] i32,

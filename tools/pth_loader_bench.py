@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--modes", default="per_scene_cpu,device_pipeline,packed_cache")
     args = ap.parse_args()
     from gapartnet_amd.dataset.gapartnet import GAPartNetInst
     from gapartnet_amd.dataset.prefetch import DevicePrefetcher
@@ -61,7 +62,7 @@ def main():
         out["write_s"] = time.perf_counter() - t0
         size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) for f in fs)
         out["mb_per_scene"] = size / (args.scenes + 24) / 1e6
-        for mode in ("per_scene_cpu", "device_pipeline", "packed_cache"):
+        for mode in args.modes.split(","):
             device_pipeline = mode != "per_scene_cpu"
             dm = GAPartNetInst(root, max_points=args.points, train_batch_size=args.batch, val_batch_size=args.batch,
                                test_batch_size=args.batch, num_workers=args.workers, pos_jitter=0.1, color_jitter=0.3,
