@@ -1,12 +1,20 @@
 #!/bin/bash
-# temporary job: fused scene preparation
-cd /root/repo
-mkdir -p gpurun_out/r05s
-timeout 600 python -m pytest tests/test_gpu_sceneprep.py tests/test_golden_loader.py tests/test_gpu_model.py -x -q -m gpu > gpurun_out/r05s/pytest_s.txt 2>&1
-tail -15 gpurun_out/r05s/pytest_s.txt
-for i in 1 2; do
-  for v in 0 1; do
-    GPN_SCENE_PREPARE=$v timeout 600 python tools/pth_loader_bench.py --modes packed_cache,device_pipeline 2>gpurun_out/r05s/pth_$v.err | tail -1 > gpurun_out/r05s/pth_${v}_$i.json
-    echo "fused=$v: $(python -c "import json;d=json.load(open('gpurun_out/r05s/pth_${v}_$i.json'));print({k:round(v,2) for k,v in d.items() if 'with_loader' in k})")"
+# temporary job: proposal sort A/B
+R=/root/repo
+O=$R/gpurun_out/r05p
+mkdir -p $O
+cd $R
+timeout 600 python -m pytest tests/test_gpu_proposals.py tests/test_gpu_sync_free.py tests/test_golden_pipeline.py -x -q -m gpu > $O/pytest.txt 2>&1
+tail -2 $O/pytest.txt
+cp gapartnet_amd/libgpn_hip.so /tmp/lib_onesweep.so
+touch gapartnet_amd/csrc/proposals.hip
+make -C gapartnet_amd/csrc -s -j 16 EXTRA="-DGPN_PROP_SORT_MERGE_LIMIT=1048576" > /dev/null 2>&1
+cp gapartnet_amd/libgpn_hip.so /tmp/lib_merge.so
+: > $O/ab.txt
+for i in 1 2 3; do
+  for v in merge onesweep; do
+    cp /tmp/lib_$v.so gapartnet_amd/libgpn_hip.so
+    echo "$v $(timeout 300 python bench.py --steps 60 --warmup 15 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")" >> $O/ab.txt
   done
 done
+cat $O/ab.txt

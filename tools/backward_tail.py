@@ -9,6 +9,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 qkey = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[qkey], r["Kernel_Name"]) for r in rows))
 adams = [e for e in ev if "adam_kernel" in e[3]]
+# (two optimizer launches per step since round 5 - gated and ungated tensors: the FIRST one of a cluster follows the backward)
+adams = [e for i, e in enumerate(adams) if i == 0 or e[0] - adams[i - 1][1] > 500_000]
 main_q = adams[0][2]
 out = []
 for a in adams[2:]:
