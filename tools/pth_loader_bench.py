@@ -48,20 +48,39 @@ def main():
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--modes", default="per_scene_cpu,device_pipeline,packed_cache")
+    ap.add_argument("--root", default=None, help="(internal) dataset already written here: run the modes in THIS process")
     args = ap.parse_args()
     from gapartnet_amd.dataset.gapartnet import GAPartNetInst
     from gapartnet_amd.dataset.prefetch import DevicePrefetcher
     from gapartnet_amd.smoke import make_model
     from gapartnet_amd.trainer import move_batch
     device = torch.device("cuda:0")
-    root = tempfile.mkdtemp(prefix="gpn_pth_")
     out = {"scenes": args.scenes, "points": args.points, "batch": args.batch, "workers": args.workers}
+    if args.root is None:
+        # the dataset is written once; every mode then runs in a process of its own (a mode measured after another one in the same
+        # process came out 6 - 25 % slower than alone, round 5: allocator / worker-pool state of the earlier mode)
+        import subprocess
+        root = tempfile.mkdtemp(prefix="gpn_pth_")
+        try:
+            t0 = time.perf_counter()
+            write_dataset(root, args.scenes, 8, args.points)
+            out["write_s"] = time.perf_counter() - t0
+            size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) for f in fs)
+            out["mb_per_scene"] = size / (args.scenes + 24) / 1e6
+            for mode in args.modes.split(","):
+                cmd = [sys.executable, os.path.abspath(__file__), "--root", root, "--modes", mode, "--scenes", str(args.scenes),
+                       "--points", str(args.points), "--batch", str(args.batch), "--workers", str(args.workers), "--epochs", str(args.epochs)]
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                if res.returncode != 0:
+                    sys.stderr.write(res.stderr[-2000:])
+                    raise SystemExit(f"mode {mode} failed")
+                out.update({k: v for k, v in json.loads(res.stdout.strip().splitlines()[-1]).items() if "/" in k})
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
+        print(json.dumps(out))
+        return
+    root = args.root
     try:
-        t0 = time.perf_counter()
-        write_dataset(root, args.scenes, 8, args.points)
-        out["write_s"] = time.perf_counter() - t0
-        size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) for f in fs)
-        out["mb_per_scene"] = size / (args.scenes + 24) / 1e6
         for mode in args.modes.split(","):
             device_pipeline = mode != "per_scene_cpu"
             dm = GAPartNetInst(root, max_points=args.points, train_batch_size=args.batch, val_batch_size=args.batch,
@@ -110,7 +129,7 @@ def main():
             out[f"{key}/point_clouds_per_s_with_loader"] = args.batch / float(np.median(times))
             out[f"{key}/steps_timed"] = steps
     finally:
-        shutil.rmtree(root, ignore_errors=True)
+        pass
     print(json.dumps(out))
 
 
