@@ -229,6 +229,33 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __
   }
 }
 
+// eval forward of the executor: the same arithmetic with invstd = 1 / sqrt(running_var + eps) evaluated by the thread for its four
+// channels (the value the separate one-workgroup kernel wrote before - 103 launches of 3.7 us per validation step, round 5);
+// written to save_invstd by the first workgroup for a backward pass over frozen statistics.  Two pointer sets (blockIdx.y):
+// ScoreNet and NPCS-Net in one launch.
+__global__ void bn_apply_eval_kernel(const gpn::BnFwdPtrs pa, const gpn::BnFwdPtrs pb, int64_t total4, int C4, float eps, int relu,
+                                     const int64_t* __restrict__ n_dev) {
+  const gpn::BnFwdPtrs& p = blockIdx.y ? pb : pa;
+  if (n_dev) total4 = gpn::live_rows(n_dev, total4 / C4) * C4;
+  if (blockIdx.x == 0 && p.invstd)
+    for (int c = threadIdx.x; c < 4 * C4; c += blockDim.x) p.invstd[c] = 1.0f / sqrtf(p.running_var[c] + eps);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(t % C4);
+    const f32x4 mu = reinterpret_cast<const f32x4*>(p.running_mean)[c4], var = reinterpret_cast<const f32x4*>(p.running_var)[c4];
+    f32x4 is;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(var[j] + eps);
+    const f32x4 w = reinterpret_cast<const f32x4*>(p.weight)[c4], b = reinterpret_cast<const f32x4*>(p.bias)[c4];
+    f32x4 v = (reinterpret_cast<const f32x4*>(p.x)[t] - mu) * is * w + b;
+    if (p.res) v += reinterpret_cast<const f32x4*>(p.res)[t];
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(p.y)[t] = v;
+  }
+}
+
 // backward finalize: dweight = sum g*xhat, dbias = sum g
 __global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(const double* __restrict__ partial, int blocks, int C,
                                                              float* __restrict__ dweight, float* __restrict__ dbias) {
@@ -735,6 +762,20 @@ int gpn::bn_fwd_eval_rows(const float* x, const float* res, const float* weight,
   const int64_t total4 = N * (C / 4);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(gpn::plan_rows(N, rows) * (C / 4))), dim3(kThreads), 0, stream, x, res, mean, invstd,
                      weight, bias, total4, C / 4, relu, y, rows.dev);
+  GPN_CHECK_LAUNCH();
+  return GPN_OK;
+}
+
+// eval forward over the RUNNING statistics of one or two BatchNorms of the same shape (pb == nullptr: one)
+int gpn::bn_fwd_eval_running(const gpn::BnFwdPtrs& pa, const gpn::BnFwdPtrs* pb, int64_t N, const gpn::DevRows& rows, int C, float eps,
+                             int relu, hipStream_t stream) {
+  GPN_CHECK_ARG(N >= 0 && C >= 4 && C % 4 == 0);
+  if (N == 0) return GPN_OK;
+  GPN_CHECK_ARG(pa.x && pa.weight && pa.bias && pa.running_mean && pa.running_var && pa.y);
+  if (pb) GPN_CHECK_ARG(pb->x && pb->weight && pb->bias && pb->running_mean && pb->running_var && pb->y);
+  const int64_t total4 = N * (C / 4);
+  hipLaunchKernelGGL(bn_apply_eval_kernel, dim3(apply_grid(gpn::plan_rows(N, rows) * (C / 4)), pb ? 2 : 1), dim3(kThreads), 0, stream,
+                     pa, pb ? *pb : pa, total4, C / 4, eps, relu, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

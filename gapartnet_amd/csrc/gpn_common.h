@@ -206,6 +206,8 @@ int bn_fwd_train_rows(const float* x, const float* res, const float* weight, con
                       float* running_var, void* ws, size_t ws_bytes, hipStream_t stream);
 int bn_fwd_eval_rows(const float* x, const float* res, const float* weight, const float* bias, const float* mean,
                      const float* invstd, int64_t N, const DevRows& rows, int C, int relu, float* y, hipStream_t stream);
+int bn_fwd_eval_running(const BnFwdPtrs& pa, const BnFwdPtrs* pb, int64_t N, const DevRows& rows, int C, float eps, int relu,
+                        hipStream_t stream);
 int bn_bwd_rows(const float* x, const float* y, const float* dy, const float* weight, const float* mean, const float* invstd,
                 int64_t N, const DevRows& rows, int C, int relu, int training, float* dx, float* dres, float* dweight,
                 float* dbias, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -105,11 +105,6 @@ __global__ __launch_bounds__(kThreads) void accumulate_kernel(float4* __restrict
   }
 }
 
-__global__ void invstd_kernel(const float* __restrict__ var, float eps, int C, float* __restrict__ invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
-}
-
 // batched weight packing: up to kPackBatch weights per launch, descriptors passed by value in the kernel arguments
 constexpr int kPackBatch = 24;
 struct PackDesc {
@@ -416,24 +411,26 @@ int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const 
       const bool together = pair && nets[1].bns[op.param].eps == bn0.eps && nets[1].bns[op.param].momentum == bn0.momentum;
       if (training && slab_of[0][i] && together) {
         rc = gpn::bn_fwd_train_fused(pp[0], &pp[1], s0.rows, bn0.C, bn0.eps, bn0.momentum, relu, stream, dev_rows(s0));
+      } else if (!training) {  // running statistics: one launch per BatchNorm, or per pair of them
+        for (int t = 0; t < n_nets; ++t)
+          if (!nets[t].bns[op.param].running_mean || !nets[t].bns[op.param].running_var) {
+            gpn::set_error("%s: op %d: eval-mode BatchNorm needs running statistics", who, i);
+            return GPN_ERR_ARG;
+          }
+        if (together) {
+          rc = gpn::bn_fwd_eval_running(pp[0], &pp[1], s0.rows, dev_rows(s0), bn0.C, bn0.eps, relu, stream);
+        } else {
+          for (int t = 0; t < n_nets && rc == GPN_OK; ++t)
+            rc = gpn::bn_fwd_eval_running(pp[t], nullptr, s0.rows, dev_rows(s0), nets[t].bns[op.param].C, nets[t].bns[op.param].eps, relu, stream);
+        }
       } else {
         for (int t = 0; t < n_nets && rc == GPN_OK; ++t) {
           const gpn_net_bn_t& bn = nets[t].bns[op.param];
           if (training && slab_of[t][i]) {
             rc = gpn::bn_fwd_train_fused(pp[t], nullptr, s0.rows, bn.C, bn.eps, bn.momentum, relu, stream, dev_rows(s0));
-          } else if (training) {
+          } else {
             rc = gpn::bn_fwd_train_rows(pp[t].x, pp[t].res, bn.weight, bn.bias, s0.rows, dev_rows(s0), bn.C, bn.eps, bn.momentum, relu,
                                         pp[t].y, bn.save_mean, bn.save_invstd, bn.running_mean, bn.running_var, op_ws, op_ws_bytes, stream);
-          } else {
-            if (!bn.running_mean || !bn.running_var || !bn.save_invstd) {
-              gpn::set_error("%s: op %d: eval-mode BatchNorm needs running statistics", who, i);
-              return GPN_ERR_ARG;
-            }
-            hipLaunchKernelGGL(invstd_kernel, dim3((bn.C + 63) / 64), dim3(64), 0, stream, bn.running_var, bn.eps, bn.C,
-                               bn.save_invstd);
-            GPN_CHECK_LAUNCH();
-            rc = gpn::bn_fwd_eval_rows(pp[t].x, pp[t].res, bn.weight, bn.bias, bn.running_mean, bn.save_invstd, s0.rows,
-                                       dev_rows(s0), bn.C, relu, pp[t].y, stream);
           }
         }
       }
