@@ -13,8 +13,8 @@ adams = [e for e in ev if "adam_kernel" in e[3]]
 adams = [e for i, e in enumerate(adams) if i == 0 or e[0] - adams[i - 1][1] > 500_000]
 main_q = adams[0][2]
 out = []
-for a in adams[2:]:
-    before = [e for e in ev if e[1] <= a[0] and e[0] > a[0] - 30_000_000]
+for prev, a in zip(adams[1:], adams[2:]):
+    before = [e for e in ev if e[1] <= a[0] and e[0] > prev[1]]  # (this step only: since the previous step's optimizer)
     main_prev = max((e for e in before if e[2] == main_q and "adam" not in e[3]), key=lambda e: e[1])
     wg = [e for e in before if "wgrad" in e[3] and e[2] != main_q]
     if not wg:
