@@ -44,3 +44,11 @@ rows = sorted(st.stats.items(), key=lambda kv: -kv[1][2])[:45]
 for (fn, line, name), (cc, nc, tt, ct, callers) in rows:
     short = os.path.relpath(fn, ROOT) if fn.startswith(ROOT) else os.path.basename(fn)
     print(f"{tt / N * 1e3:7.3f} ms/step  {nc / N:7.1f} calls/step  {short}:{line} {name}")
+# who calls the allocator / the small tensor ops (calls per step by caller)
+for wanted in ("torch.empty", "'view'", "'data_ptr'", "'to' of"):
+    for (fn, line, name), (cc, nc, tt, ct, callers) in st.stats.items():
+        if wanted in name:
+            print(f"\ncallers of {name}:")
+            for (cfn, cline, cname), (ccc, cnc, ctt, cct) in sorted(callers.items(), key=lambda kv: -kv[1][1])[:10]:
+                short = os.path.relpath(cfn, ROOT) if cfn.startswith(ROOT) else os.path.basename(cfn)
+                print(f"   {cnc / N:7.1f} calls/step  {ctt / N * 1e3:6.3f} ms/step  {short}:{cline} {cname}")
