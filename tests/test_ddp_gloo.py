@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, schedule, out_dir):
+def _worker(rank, world, port, schedule, out_dir, root_dir="synthetic:8", packed=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -34,8 +34,8 @@ def _worker(rank, world, port, schedule, out_dir):
     backend.use(torch_ops)
 
     model = make_model(schedule, channels=[16, 32], seed=0)
-    dm = GAPartNetInst(root_dir="synthetic:8", max_points=1500, train_batch_size=2, val_batch_size=2, test_batch_size=2,
-                       num_workers=0)
+    dm = GAPartNetInst(root_dir=root_dir, max_points=1500, train_batch_size=2, val_batch_size=2, test_batch_size=2,
+                       num_workers=0, packed_cache=packed)
     seen = []
     orig = model.training_step
 
@@ -128,6 +128,27 @@ def test_four_rank_training_keeps_ranks_identical(tmp_path):
     assert res["params_equal"] and res["finite"] and res["loss"] > 0
     seen = [set(i) for i in res["ids"]]
     assert [len(s) for s in seen] == [2, 2, 2, 2] and len(set().union(*seen)) == 8, "4 disjoint shards of the 8 scenes"
+
+
+def test_two_ranks_train_from_one_packed_cache(tmp_path):
+    """round 5: both ranks open (and, racing, build) the same memory-mapped scene cache over the same ``.pth`` files; the
+    DistributedSampler's shards go through PackedSceneLoader: disjoint scenes per rank, identical parameters after the steps"""
+    from tests.golden.recipe import scene_arrays
+    root = str(tmp_path / "data")
+    for split, n, seed0 in (("train", 8, 100), ("val", 2, 5000), ("test_intra", 2, 6000), ("test_inter", 2, 7000)):
+        d = os.path.join(root, split, "pth")
+        os.makedirs(d)
+        for i in range(n):
+            xyz, rgb, sem, ins, npcs, pix = scene_arrays(seed0 + i, 1500)
+            torch.save((xyz, rgb, sem, ins, npcs, pix), os.path.join(d, f"StorageFurniture_{seed0 + i:05d}_00_{i % 32:03d}.pth"))
+    mp.spawn(_worker, args=(2, _free_port(), (0, 0), str(tmp_path), root, True), nprocs=2, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "result.pt"), weights_only=False)
+    assert res["params_equal"], "ranks diverged: gradients were not all-reduced"
+    assert res["finite"] and res["loss"] > 0
+    a, b = set(res["ids"][0]), set(res["ids"][1])
+    assert len(a) == 4 and len(b) == 4 and not (a & b), "ranks must train on disjoint scene shards"
+    caches = os.listdir(os.path.join(root, ".gpn_cache"))
+    assert len([c for c in caches if c.startswith("train-") and ".tmp" not in c]) == 1, caches
 
 
 def test_every_rank_holds_the_same_file_order_after_setup(tmp_path):
