@@ -86,6 +86,39 @@ class Rulebook:
         return int(self.num_pairs.item())
 
 
+class ArenaRulebook:
+    """A Rulebook whose tables are slices of ONE arena (gpn_backbone_prepare).  The network executor only needs addresses
+    (``ptrs`` = nbr, nbr_p, perm, pair_src, pair_dst, tile_off; 0 = absent) - 28 rulebooks x 7 tables per batch were ~150 tensor
+    views made and ~250 addresses read back per step for that; the views are made when something asks for them (the module-by-
+    module path, the tests), through the same attribute names."""
+    __slots__ = ("_owner", "_spec", "_made", "K", "n_src", "n_dst", "live_src", "live_dst", "ptrs")
+    _FIELDS = ("nbr", "nbr_p", "perm", "pair_src", "pair_dst", "tile_off", "num_pairs")
+
+    def __init__(self, owner, spec, K, n_src, n_dst):
+        self._owner, self._spec, self._made = owner, spec, {}
+        self.K, self.n_src, self.n_dst = K, n_src, n_dst
+        self.live_src = self.live_dst = None
+        base = owner.arena_ptr
+        self.ptrs = tuple(base + spec[f][0] if spec.get(f) is not None else 0 for f in self._FIELDS[:6])
+
+    def __getattr__(self, name):  # (only reached for names that are not slots: the table fields)
+        if name not in ArenaRulebook._FIELDS:
+            raise AttributeError(name)
+        made = self._made
+        if name not in made:
+            ent = self._spec.get(name)
+            t = None
+            if ent is not None:
+                off, count, dtype, shape = ent
+                t = self._owner._view(off, count, dtype)
+                t = t[0] if shape == () else (t.view(*shape) if shape is not None else t)
+            made[name] = t
+        return made[name]
+
+    def pairs_host(self) -> int:
+        return int(self.num_pairs.item())
+
+
 class DevCount:
     """A row count that is still on the device (include/gpn.h section DEV): ``t`` = int64 [1] device tensor (usually a view
     into the counts array of the launch that produced it), ``plan`` = the host's estimate of its value (0 = none; it sizes
@@ -231,6 +264,7 @@ class PreparedBackbone:
         self.device_index = dev.index if dev.index is not None else torch.cuda.current_device()
         self.rc, self.error = None, None
         self._typed = {}
+        self.arena_ptr = self.arena.data_ptr()
 
     def run(self):
         L = _C.lib()
@@ -267,13 +301,14 @@ class PreparedBackbone:
             return None
         # pair-list capacities as gpn_backbone_prepare carved them: 27 n (SubM), the fine row count (stride-2 maps), n (identity)
         cap = 27 * n_dst if K == 27 else (n_dst if K == 1 else max(n_src, n_dst))
-        rb = Rulebook(self._view(o_src, cap, torch.int32), self._view(o_dst, cap, torch.int32),
-                      self._view(o_toff, K * (n_tiles(n_dst) + 1), torch.int32).view(K, -1), K, n_src, n_dst,
-                      self._view(o_np, 1, torch.int64)[0], self._view(o_nbr, K * n_dst + 1, torch.int32))
+        i32 = torch.int32
+        spec = dict(pair_src=(o_src, cap, i32, None), pair_dst=(o_dst, cap, i32, None),
+                    tile_off=(o_toff, K * (n_tiles(n_dst) + 1), i32, (K, -1)), num_pairs=(o_np, 1, torch.int64, ()),
+                    nbr=(o_nbr, K * n_dst + 1, i32, None))
         if o_perm >= 0:
-            rb.perm = self._view(o_perm, (n_dst + 15) // 16 * 16 + 16, torch.int32)
-            rb.nbr_p = self._view(o_nbrp, K * n_dst + 1, torch.int32)
-        return rb
+            spec["perm"] = (o_perm, (n_dst + 15) // 16 * 16 + 16, i32, None)
+            spec["nbr_p"] = (o_nbrp, K * n_dst + 1, i32, None)
+        return ArenaRulebook(self, spec, K, n_src, n_dst)
 
     def wrap(self):
         """-> dict(features, indices, spatial_shape, pc_voxel_id, csr, level_counts, levels = [dict(indices, shape, subm,

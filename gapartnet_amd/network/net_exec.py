@@ -23,6 +23,17 @@ from .. import _C, backend
 from .. import functional as GF
 from ..spconv import pytorch as spconv
 
+
+def rulebook_ptrs(rb):
+    """(nbr, nbr_p, perm, pair_src, pair_dst, tile_off) device addresses of a rulebook, 0 = absent.  Rulebooks cut out of a
+    prepared batch's arena carry them (hip_ops.ArenaRulebook.ptrs: no tensor views are made for the executor's sake)"""
+    p = getattr(rb, "ptrs", None)
+    if p is not None:
+        return p
+    nbr_p, perm = rb.nbr_p, rb.perm
+    return (rb.nbr.data_ptr(), 0 if nbr_p is None else nbr_p.data_ptr(), 0 if perm is None else perm.data_ptr(),
+            rb.pair_src.data_ptr(), rb.pair_dst.data_ptr(), rb.tile_off.data_ptr())
+
 # numpy mirrors of the C structs in include/gpn.h (sizes are checked against the header in tests/test_cabi.py)
 SLOT_DT = np.dtype([("data", "<u8"), ("grad", "<u8"), ("rows", "<i8"), ("channels", "<i4"), ("grad_state", "<i4"),
                     ("rows_dev", "<u8"), ("rows_plan", "<i8")])
@@ -327,11 +338,9 @@ class NetProgram:
                     rb = spconv._identity_rulebook(n, x.features.device)
                     x.indice_dict[ikey] = rb
                 rb_t, rev = rb, 0
-            def opt(t):
-                return 0 if t is None else t.data_ptr()
-            table[i] = (rb.nbr.data_ptr(), rb_t.nbr.data_ptr(), opt(rb.nbr_p), opt(rb.perm), opt(rb_t.nbr_p), opt(rb_t.perm),
-                        rb.pair_src.data_ptr(), rb.pair_dst.data_ptr(), rb.tile_off.data_ptr(), rb.n_src, rb.n_dst, rb.K,
-                        rev)
+            nbr, nbr_p, perm, pair_src, pair_dst, tile_off = rulebook_ptrs(rb)
+            nbr_t, nbr_p_t, perm_t = (nbr, nbr_p, perm) if rb_t is rb else rulebook_ptrs(rb_t)[:3]
+            table[i] = (nbr, nbr_t, nbr_p, perm, nbr_p_t, perm_t, pair_src, pair_dst, tile_off, rb.n_src, rb.n_dst, rb.K, rev)
             objs.append((rb, rb_t))
         return rows, table, objs, levels
 
