@@ -5,8 +5,16 @@ train step).
 One "step" = one full training step of the perception pipeline on one batch of synthetic 20k-point scenes per rank:
 on-device batched voxelisation + collate, sparse U-Net backbone, semantic / offset heads, dual-set clustering
 (ball query + CCL), proposal re-voxelisation, ScoreNet, NPCS-Net, all five losses, backward, Adam.  Inputs (raw point
-clouds + labels) are resident in HBM before the timed region.  Launch: ``python bench.py`` (1 GPU) or
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (one rank per GPU, gradient mean over RCCL).
+clouds + labels) are resident in HBM before the timed region.  Launch: ``python bench.py [--gpus N]`` - with N > 1 and no
+RANK in the environment the script starts itself under ``python -m torch.distributed.run --nproc-per-node N`` (one rank per
+GPU, gradient mean over RCCL); launched that way by somebody else (the driver) it runs as the rank it is told to be.
+
+The timed workload is STATIONARY (round 6): every step is a full training step (forward, backward, gradient exchange, Adam)
+from the SAME seeded parameters - after the optimizer's launch the parameter values are put back (gpn_copy_many: 32 MB in four
+launches, inside the timed region: extra work, never less).  Trained on, the synthetic labels make the proposal stage's load fall from 18k to
+1k points over the first 45 steps (profiles/r05_first_steps.txt), so that runs with different --warmup / --steps timed
+different work; ``--moving`` restores that behaviour, and the line carries the proposal stage's counts of the timed steps
+(``proposal_stage``) either way.
 
 Prints ONE JSON line on rank 0 with the contract fields plus ``roofline`` (dominant kernel, measured with hipEvents
 inside libgpn_hip.so during an extra instrumented step) and ``cpu_baseline`` (the same train step through the CPU
@@ -39,16 +47,34 @@ def parse():
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--schedule", type=str, default="0,0", help="training_schedule; 0,0 = every head active")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--moving", action="store_true",
+                    help="let the parameters train on (rounds 1-5: the proposal stage's load then depends on how many steps preceded)")
     ap.add_argument("--cpu-scenes", type=int, default=3)
     return ap.parse_args()
 
 
-def build_step(model, optimizer, world, device):
+class ParameterSnapshot:
+    """the parameter values at construction, put back (gpn_copy_many: 96 tensors per launch) after every optimizer step: each timed
+    step then does the work of a training step from the same weights (the stationary workload; see the module docstring)"""
+
+    def __init__(self, model):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        with torch.no_grad():
+            self.saved = [p.detach().clone() for p in self.params]
+
+    def restore(self):
+        from gapartnet_amd.optim import _copy_many
+        with torch.no_grad():
+            _copy_many([p.data for p in self.params], self.saved)
+
+
+def build_step(model, optimizer, world, device, moving=False):
     grad_sync = None
     if world > 1 or os.environ.get("GPN_BENCH_FORCE_GRAD_SYNC") == "1":  # the switch: exchange cost measurable on one GPU
         from gapartnet_amd.grad_sync import GradSync
         grad_sync = GradSync(model)
         grad_sync.broadcast_parameters()
+    snapshot = None if moving else ParameterSnapshot(model)
 
     def step(batch, i):
         optimizer.zero_grad(set_to_none=True)
@@ -57,9 +83,28 @@ def build_step(model, optimizer, world, device):
         if grad_sync is not None:
             grad_sync.sync()  # mean of the ranks' gradients: the path's one collective
         optimizer.step()
+        if snapshot is not None:
+            snapshot.restore()
         return loss
     step.grad_sync = grad_sync
     return step
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) started by hand or by a driver that does not wrap it: start the N ranks ourselves -
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...` -
+    and pass their output and exit code through"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs between processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
+    return subprocess.call(cmd, env=env)
 
 
 def kernel_source_fingerprint():
@@ -207,6 +252,15 @@ def conv_levels(lib, overhead_us):
     return head
 
 
+def proposal_summary(plans):
+    rows = [p for p in plans if p]
+    if not rows:
+        return None
+    pts, props, vox = [int(r[1]) for r in rows], [int(r[2]) for r in rows], [int(r[3]) for r in rows]
+    return {"points_per_step": pts, "proposals_per_step": props, "voxels_per_step": vox,
+            "points_min_max": [min(pts), max(pts)], "proposals_min_max": [min(props), max(props)]}
+
+
 def usable_cores() -> int:
     """host cores this process may actually use: the smaller of the scheduler affinity and the cgroup CPU quota (the GPU
     boxes report 256 logical CPUs under a 16-CPU quota; 256 threads there run ~100x slower than 16)"""
@@ -272,6 +326,8 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     torch.set_num_threads(usable_cores())  # torch sizes its CPU pool from the logical CPU count, not from the cgroup quota
     from gapartnet_amd.trainer import init_distributed
     rank, local_rank, world, device = init_distributed("cuda")
@@ -289,7 +345,7 @@ def main():
     schedule = tuple(int(s) for s in args.schedule.split(","))
     model = make_model(schedule).to(device)
     optimizer = model.configure_optimizers()
-    step = build_step(model, optimizer, world, device)
+    step = build_step(model, optimizer, world, device, moving=args.moving)
     # two resident batches per rank (alternated) of distinct synthetic scenes
     pool = [[pc.to(device) for pc in make_batch(args.batch, args.points, seed0=1000 + (2 * rank + j) * args.batch)]
             for j in range(2)]
@@ -306,8 +362,10 @@ def main():
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     cpu0 = time.process_time()  # CPU seconds of every thread of this process (main, weight-gradient helper, runtime threads)
+    plans = []  # the proposal stage's counts as the host learns them (two steps late, never waited for): a list append per step
     for i in range(args.steps):
         step(next(feed), i)
+        plans.append(model._prop_hist[-1] if getattr(model, "_prop_hist", None) else None)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -399,8 +457,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"full pipeline train step (fwd+bwd+Adam), schedule {list(schedule)}, "
                                    f"{args.points}-pt scenes, bs={args.batch}/GPU (BASELINE config 3 per-GPU shape), "
-                                   f"voxel 0.01, random-init weights", "global_batch": world * args.batch,
-                       "points_per_scene": args.points, "parallelism": f"dp{world}"},
+                                   f"voxel 0.01, random-init weights, "
+                                   + ("parameters train on (--moving)" if args.moving else
+                                      "every step from the same seeded parameters (values put back by copy launches after Adam, inside the timed region)"),
+                       "global_batch": world * args.batch, "points_per_scene": args.points, "parallelism": f"dp{world}"},
+            # what the proposal stage saw in the timed steps (rank 0; counts reach the host two steps late): clustered points,
+            # proposals, proposal voxels - per step, so that a reader can see whether the timed work was stationary
+            "proposal_stage": proposal_summary(plans),
             "roofline": roof,
             # what a rank asks of the host: CPU milliseconds per step summed over its threads (rank 0's), and the cores it may
             # run on - at N ranks per node the node needs about N x cpu_ms_per_step / ms_per_step cores for this rate

@@ -57,6 +57,7 @@ def lib():
         _lib.gpn_spconv_tiles_min_tiles.argtypes = [i64t]
         _lib.gpn_spconv_tiles_min_tiles.restype = i64t
         _lib.gpn_spconv_direct_split.argtypes = [i64t, i64t]
+        _lib.gpn_spconv_msplit.argtypes = [i32t, i32t, i32t]
     return _lib
 
 

@@ -165,6 +165,11 @@ bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout);
 int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
                         int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream,
                         const DevRows& rows = DevRows());
+// the masked tap-split kernel (spconv_msplit.hip, round 6): k = 27 / 8 layers below the masked-tile kernel's size
+bool spconv_msplit_supported(int K, int64_t n_dst, int cin, int cout);
+int spconv_msplit_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
+                         int cin, int cout, int accumulate, const ConvStats& stats, float* out, hipStream_t stream,
+                         const DevRows& rows = DevRows());
 // weight-gradient contraction and its (batched) slice sums (spconv.hip); used by gpn_spconv_wgrad and the network executor
 constexpr int kWgradReduceJobs = 24;
 constexpr int kWgradSets = 4;

@@ -31,7 +31,7 @@ ProfSlot g_prof[GPN_K_COUNT];
 const char* kEntryPoints[] = {
     "gpn_voxelize", "gpn_voxelize_ws_bytes", "gpn_rulebook_subm3", "gpn_rulebook_subm3_ws_bytes",
     "gpn_rulebook_down", "gpn_rulebook_down_ws_bytes", "gpn_rulebook_down_lists",
-    "gpn_rulebook_down_lists_ws_bytes", "gpn_rulebook_level_counts", "gpn_rulebook_identity", "gpn_rulebook_level_counts_ws_bytes", "gpn_voxelize_ex", "gpn_voxelize_scenes", "gpn_voxelize_scenes_sorted", "gpn_voxelize_scenes_ws_bytes", "gpn_spconv_pack_weights", "gpn_spconv_fwd", "gpn_spconv_fwd_ws_bytes", "gpn_spconv_fwd_ordered", "gpn_rulebook_tile_order_ws_bytes", "gpn_rulebook_tile_order", "gpn_spconv_tiles_min_tiles", "gpn_spconv_direct_split", "gpn_spconv_fwd_w", "gpn_spconv_fwd_w_ws_bytes", "gpn_spconv_wgrad",
+    "gpn_rulebook_down_lists_ws_bytes", "gpn_rulebook_level_counts", "gpn_rulebook_identity", "gpn_rulebook_level_counts_ws_bytes", "gpn_voxelize_ex", "gpn_voxelize_scenes", "gpn_voxelize_scenes_sorted", "gpn_voxelize_scenes_ws_bytes", "gpn_spconv_pack_weights", "gpn_spconv_fwd", "gpn_spconv_fwd_ws_bytes", "gpn_spconv_fwd_ordered", "gpn_rulebook_tile_order_ws_bytes", "gpn_rulebook_tile_order", "gpn_spconv_tiles_min_tiles", "gpn_spconv_direct_split", "gpn_spconv_msplit", "gpn_spconv_fwd_w", "gpn_spconv_fwd_w_ws_bytes", "gpn_spconv_wgrad",
     "gpn_spconv_wgrad_ws_bytes", "gpn_gather_rows", "gpn_scatter_rows_csr", "gpn_bn_ws_bytes", "gpn_bn_fwd_train", "gpn_bn_fwd_eval", "gpn_bn_bwd", "gpn_net_ws_bytes", "gpn_net_bn_fusion", "gpn_net_wgrad_group", "gpn_net_forward", "gpn_linear_supported", "gpn_linear_fwd", "gpn_linear_bwd_ws_bytes", "gpn_linear_bwd", "gpn_net_backward", "gpn_net_forward_pair", "gpn_net_backward_pair", "gpn_point_losses_ws_bytes", "gpn_point_losses_fwd", "gpn_point_losses_fwd_metrics", "gpn_point_losses_bwd", "gpn_score_loss", "gpn_npcs_loss_fwd", "gpn_npcs_loss_bwd", "gpn_ball_query", "gpn_ball_query_grid_ws_bytes", "gpn_ball_query_grid", "gpn_ccl",
     "gpn_ccl_ws_bytes", "gpn_segmented_reduce", "gpn_segmented_maxpool_fwd", "gpn_segmented_maxpool_bwd",
     "gpn_instance_iou", "gpn_nms", "gpn_nms_ws_bytes", "gpn_pn2_ball_query", "gpn_pn2_group_points",
@@ -39,7 +39,7 @@ const char* kEntryPoints[] = {
     "gpn_pn2_furthest_point_sampling", "gpn_pn2_furthest_point_sampling_ws_bytes",
     "gpn_pn2_furthest_point_sampling_ws", "gpn_pn2_three_nn", "gpn_pn2_knn", "gpn_pn2_three_interpolate",
     "gpn_pn2_three_interpolate_grad", "gpn_proposals_max_proposals", "gpn_proposals_build_ws_bytes", "gpn_proposals_build", "gpn_proposals_voxel_mean",
-    "gpn_proposals_voxel_mean_bwd", "gpn_proposals_revoxelize_ws_bytes", "gpn_proposals_revoxelize", "gpn_proposals_postprocess_ws_bytes", "gpn_proposals_postprocess", "gpn_backbone_prepare_desc_words", "gpn_backbone_prepare_arena_bytes", "gpn_backbone_prepare", "gpn_scene_prepare_max_instances", "gpn_scene_prepare_ws_bytes", "gpn_scene_prepare", "gpn_pose_fit_ws_bytes", "gpn_pose_fit", "gpn_copy_many", "gpn_adam_blocks", "gpn_adam_step", "gpn_adam_step_gated", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get", "gpn_prof_get_launches",
+    "gpn_proposals_voxel_mean_bwd", "gpn_proposals_revoxelize_ws_bytes", "gpn_proposals_revoxelize", "gpn_proposals_postprocess_ws_bytes", "gpn_proposals_postprocess", "gpn_proposals_postprocess_lds_proposals", "gpn_backbone_prepare_desc_words", "gpn_backbone_prepare_arena_bytes", "gpn_backbone_prepare", "gpn_scene_prepare_max_instances", "gpn_scene_prepare_ws_bytes", "gpn_scene_prepare", "gpn_pose_fit_ws_bytes", "gpn_pose_fit", "gpn_copy_many", "gpn_adam_blocks", "gpn_adam_step", "gpn_adam_step_gated", "gpn_prof_enable", "gpn_prof_bracket_overhead_us", "gpn_prof_reset", "gpn_prof_get", "gpn_prof_get_launches",
     "gpn_rulebook_subm3_dev", "gpn_rulebook_down_dev_ws_bytes", "gpn_rulebook_down_dev", "gpn_rulebook_down_lists_dev", "gpn_rulebook_identity_dev", "gpn_gather_rows_dev", "gpn_scatter_rows_csr_dev", "gpn_proposals_voxel_mean_dev", "gpn_proposals_targets_dev", "gpn_linear_fwd_dev", "gpn_linear_bwd_dev", "gpn_segmented_maxpool_fwd_dev", "gpn_segmented_maxpool_bwd_dev", "gpn_instance_iou_dev", "gpn_score_loss_dev", "gpn_npcs_loss_fwd_dev", "gpn_npcs_loss_bwd_dev",
     "gpn_last_error", "gpn_version"};
 }  // namespace

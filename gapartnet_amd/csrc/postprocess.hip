@@ -19,6 +19,8 @@
 //   * ONE compaction: ids of the kept proposals (ascending), their new CSR offsets, and the source row of every kept proposal
 //     point; the caller re-indexes whatever fields it needs with index_select - no host read until it wants the two counts.
 // Row counts may be device counters (gpn::DevRows convention): P / M are then bounds.
+#include <atomic>
+
 #include "gpn_common.h"  // first: pulls <cstring> ahead of the HIP/rocPRIM headers
 
 #include <rocprim/rocprim.hpp>
@@ -114,20 +116,20 @@ __global__ __launch_bounds__(kThreads) void pp_neighbours_kernel(const unsigned 
   }
 }
 
-// one workgroup: the NMS rounds, then the compaction tables.  status[] lives in LDS (one byte per proposal of the bound:
-// 128 KiB of the CU's 160 - the bound of 8 x 20k-point scenes is 64 000 proposals).
+// one workgroup: the NMS rounds, then the compaction tables.  status[] (one byte per LIVE proposal) lives in LDS - 128 KiB of the
+// CU's 160; the bound of 8 x 20k-point scenes is 64 000 proposals - or, when a step has more live proposals than that, in the
+// workspace (`status_ws`, one byte per proposal of the bound: the workgroup's own global memory, ordered by its barriers).  Which
+// of the two is decided from the device count, never from the bound: a validation step of 32 scenes has a bound of 256 001
+// proposals (round 5 rejected it on the host) and a few hundred live ones.
 constexpr int kNmsThreads = 1024;
-constexpr int64_t kMaxProposals = 128 * 1024;
-__global__ __launch_bounds__(kNmsThreads) void pp_nms_kernel(const unsigned char* __restrict__ flag, const int32_t* __restrict__ rank,
-                                                             const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg,
-                                                             const int64_t* __restrict__ sizes, int64_t P,
-                                                             const int64_t* __restrict__ p_dev, const int32_t* __restrict__ overflow,
-                                                             int32_t* __restrict__ kept_ids, int32_t* __restrict__ new_offsets,
-                                                             int64_t* __restrict__ counts) {
-  __shared__ unsigned char status[kMaxProposals];
-  __shared__ int s_left;
-  __shared__ long long s_part[kNmsThreads][2];
-  const int64_t live = gpn::live_rows(p_dev, P);
+constexpr int64_t kLdsProposals = 128 * 1024;
+
+template <class Status>
+__device__ __forceinline__ void nms_rounds(Status status, int& s_left, long long (*s_part)[2], const unsigned char* __restrict__ flag,
+                                           const int32_t* __restrict__ rank, const int32_t* __restrict__ nbr,
+                                           const int32_t* __restrict__ deg, const int64_t* __restrict__ sizes, const int64_t live,
+                                           const int32_t* __restrict__ overflow, int32_t* __restrict__ kept_ids,
+                                           int32_t* __restrict__ new_offsets, int64_t* __restrict__ counts) {
   const int tid = threadIdx.x;
   for (int64_t p = tid; p < live; p += kNmsThreads) status[p] = flag[p] ? kUndecided : kOut;
   __syncthreads();
@@ -188,6 +190,23 @@ __global__ __launch_bounds__(kNmsThreads) void pp_nms_kernel(const unsigned char
     }
 }
 
+__global__ __launch_bounds__(kNmsThreads) void pp_nms_kernel(const unsigned char* __restrict__ flag, const int32_t* __restrict__ rank,
+                                                             const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg,
+                                                             const int64_t* __restrict__ sizes, int64_t P,
+                                                             const int64_t* __restrict__ p_dev, const int32_t* __restrict__ overflow,
+                                                             unsigned char* status_ws, int64_t lds_proposals,
+                                                             int32_t* __restrict__ kept_ids, int32_t* __restrict__ new_offsets,
+                                                             int64_t* __restrict__ counts) {
+  __shared__ unsigned char status[kLdsProposals];
+  __shared__ int s_left;
+  __shared__ long long s_part[kNmsThreads][2];
+  const int64_t live = gpn::live_rows(p_dev, P);
+  if (live <= lds_proposals)  // (uniform)
+    nms_rounds<unsigned char*>(status, s_left, s_part, flag, rank, nbr, deg, sizes, live, overflow, kept_ids, new_offsets, counts);
+  else  // (volatile: every access goes to memory - the waves of this workgroup exchange decisions through these bytes)
+    nms_rounds<volatile unsigned char*>(status_ws, s_left, s_part, flag, rank, nbr, deg, sizes, live, overflow, kept_ids, new_offsets, counts);
+}
+
 // src_row[new_offsets[j] + t] = offsets[kept_ids[j]] + t: a wave per kept proposal
 __global__ __launch_bounds__(kThreads) void pp_rows_kernel(const int32_t* __restrict__ kept_ids, const int32_t* __restrict__ new_offsets,
                                                            const int32_t* __restrict__ offsets, const int64_t* __restrict__ counts,
@@ -205,6 +224,7 @@ struct PpWs {
   unsigned char* flag;
   float *key, *skey;
   int32_t *ids, *order, *rank, *nbr, *deg, *overflow;
+  unsigned char* status;  // the NMS kernel's status bytes when a step has more live proposals than its LDS table holds
   void* prim;
   size_t prim_bytes, total;
 };
@@ -217,6 +237,7 @@ PpWs carve(void* ws, int64_t P) {
   o.key = w.take<float>(n), o.skey = w.take<float>(n);
   o.ids = w.take<int32_t>(n), o.order = w.take<int32_t>(n), o.rank = w.take<int32_t>(n);
   o.nbr = w.take<int32_t>(n * kMaxNbr), o.deg = w.take<int32_t>(n), o.overflow = w.take<int32_t>(1);
+  o.status = w.take<unsigned char>(n);
   size_t tmp = 0;
   (void)rocprim::radix_sort_pairs_desc(nullptr, tmp, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
                                        n, 0u, 32u, (hipStream_t) nullptr);
@@ -227,6 +248,15 @@ PpWs carve(void* ws, int64_t P) {
 }
 
 }  // namespace
+
+// live proposals up to which the NMS kernel keeps its status bytes in LDS (default = the table's size; tests lower it to run the
+// workspace form on small inputs)
+std::atomic<int64_t> g_lds_proposals{kLdsProposals};
+
+extern "C" int64_t gpn_proposals_postprocess_lds_proposals(int64_t n) {
+  if (n < 0) return g_lds_proposals.load(std::memory_order_relaxed);
+  return g_lds_proposals.exchange(n > kLdsProposals ? kLdsProposals : n, std::memory_order_relaxed);
+}
 
 extern "C" size_t gpn_proposals_postprocess_ws_bytes(int64_t P) { return carve(nullptr, P).total; }
 
@@ -243,11 +273,6 @@ extern "C" int gpn_proposals_postprocess(const float* score_preds, const int64_t
     return GPN_OK;
   }
   GPN_CHECK_ARG(score_preds && sizes && proposal_offsets && point_indices && proposal_indices && member_slot && kept_ids && src_row);
-  if (P > kMaxProposals) {
-    gpn::set_error("gpn_proposals_postprocess: a bound of %lld proposals exceeds the %lld the in-LDS status table holds", (long long)P,
-                   (long long)kMaxProposals);
-    return GPN_ERR_ARG;
-  }
   PpWs o = carve(ws, P);
   if (!ws || ws_bytes < o.total) {
     gpn::set_error("gpn_proposals_postprocess: workspace too small (%zu needed, %zu given)", o.total, ws_bytes);
@@ -269,7 +294,7 @@ extern "C" int gpn_proposals_postprocess(const float* score_preds, const int64_t
                      iou_threshold, o.nbr, o.deg, o.overflow);
   GPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pp_nms_kernel, dim3(1), dim3(kNmsThreads), 0, stream, o.flag, o.rank, o.nbr, o.deg, sizes, P, p_dev, o.overflow,
-                     kept_ids, new_offsets, counts);
+                     o.status, g_lds_proposals.load(std::memory_order_relaxed), kept_ids, new_offsets, counts);
   GPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pp_rows_kernel, dim3(gpn::dev_grid(gpn::cdiv(P, kThreads / 64), gpn::cdiv(Pp, kThreads / 64), true, 1, 256)), dim3(kThreads), 0,
                      stream, kept_ids, new_offsets, proposal_offsets, counts, src_row);

@@ -470,6 +470,14 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
 // SP-th of the taps with the same register rings, leave their accumulators in LDS, and the unit's first wave adds them in
 // wave order and stores (plus the BatchNorm sums): SP x the waves, chains 1 / SP as long, one launch, fixed summation order
 // (per wave: taps ascending, two-level as in the direct kernel; then (((p0 + p1) + p2) + p3)) => deterministic.
+// GPN_SPLIT_TRACE (tools/probes/msplit_trace.py; off in the product): every wave of the tap-split kernel records when it started, had
+// its table entries, finished its stage loop, passed the barrier and finished (s_memrealtime, 100 MHz), and where it ran
+#ifndef GPN_SPLIT_TRACE
+#define GPN_SPLIT_TRACE 0
+#endif
+#if GPN_SPLIT_TRACE
+__device__ unsigned long long* g_split_trace = nullptr;  // [waves][10]
+#endif
 template <int KT, int CB, int SP, bool DEV>
 __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                                                const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
@@ -496,6 +504,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   // (one workgroup's units as a lambda with ONE call site per instantiation, see the direct kernel; `more` = another round
   // follows, uniform per workgroup)
   auto run_wg = [&](const int64_t wg, const bool more) {
+#if GPN_SPLIT_TRACE
+  const unsigned long long tr0 = wall_clock64();
+#endif
   const int64_t unit = wg * UPW + wave / SP;
   const int part = wave % SP;
   const int tap0 = part * TP;
@@ -523,6 +534,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   auto tap_idx = [&](int j) -> int32_t { return (row_ok && tap0 + j < KT) ? ireg[j % DI] : -1; };
 #pragma unroll
   for (int u = 0; u < DI; ++u) ireg[u] = load_idx(u);
+#if GPN_SPLIT_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long tr1 = wall_clock64();
+#endif
   f32x4 areg[D], breg[D];
   auto issue = [&](int s, int slot) {  // s = local tap * CB + cb: compile-time after unrolling
     const int j = s / CB, cb = s - j * CB;
@@ -592,9 +607,16 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
     if (j + DI < TP) ireg[j % DI] = load_idx(j + DI);
     asm volatile("" ::: "memory");
   }
+#if GPN_SPLIT_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long tr2 = wall_clock64();
+#endif
   // the unit's partial sums -> its first wave, added in wave order
   if (part != 0) red[wave][lane] = acc;
   __syncthreads();
+#if GPN_SPLIT_TRACE
+  const unsigned long long tr3 = wall_clock64();
+#endif
   if (part == 0 && active) {
 #pragma unroll
   for (int q = 1; q < SP; ++q) acc += red[wave + q][lane];
@@ -622,6 +644,19 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
   if (st_fwd) gpn::stat_add<false>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
   else if (st_bwd) gpn::stat_add<true>(stats.slab, cout, (int)(tile & stats.slot_mask), (int)col, g, gpn::stat_reduce_g(s0), gpn::stat_reduce_g(s1));
   }
+#if GPN_SPLIT_TRACE
+  if (g_split_trace && blockIdx.y == 0 && active) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long tr4 = wall_clock64();
+    if (lane == 0) {
+      unsigned long long* t = g_split_trace + ((size_t)unit * SP + part) * 10;
+      t[0] = tr0, t[1] = tr1, t[2] = tr1, t[3] = tr2, t[4] = tr3, t[5] = tr4, t[6] = (unsigned long long)TP;
+      t[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+      t[8] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+      t[9] = (unsigned long long)blockIdx.x;
+    }
+  }
+#endif
   if (more) __syncthreads();  // another round: `red` is rewritten
   };
   if constexpr (!DEV) {
@@ -733,9 +768,17 @@ extern "C" int gpn_spconv_direct_split(int64_t split4_below_units, int64_t split
   return GPN_OK;
 }
 
+#if GPN_SPLIT_TRACE
+extern "C" int gpn_probe_split_trace(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_split_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" size_t gpn_spconv_fwd_ws_bytes(int K, int64_t n_dst, int cin, int cout) {
   if (n_dst <= 0 || cin < 16 || cout < 16) return 0;
-  if (gpn::spconv_tiles_supported(K, n_dst, cin, cout) || use_direct(K, n_dst, cin, cout)) return 0;
+  if (gpn::spconv_tiles_supported(K, n_dst, cin, cout) || gpn::spconv_msplit_supported(K, n_dst, cin, cout) || use_direct(K, n_dst, cin, cout))
+    return 0;
   const FwdPlan p = plan_fwd(K, n_dst, cin, cout);
   return p.splits > 1 ? gpn::align_up((size_t)p.splits * n_dst * cout * sizeof(float)) : 0;
 }
@@ -750,7 +793,8 @@ extern "C" int gpn_spconv_fwd_ordered(const float* in, const float* packed_w, co
 // out = conv (accumulate == 0) or out += conv (the network executor's second gradient of a slot: same value as staging the
 // conv's result and adding it with a separate launch, which is what it replaces)
 bool gpn::spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout) {
-  return n_dst > 0 && (gpn::spconv_tiles_supported(K, n_dst, cin, cout) || use_direct(K, n_dst, cin, cout));
+  return n_dst > 0 && (gpn::spconv_tiles_supported(K, n_dst, cin, cout) || gpn::spconv_msplit_supported(K, n_dst, cin, cout) ||
+                       use_direct(K, n_dst, cin, cout));
 }
 
 // which kernel a layer takes when its row count is a device counter: decided from the host's plan (the layer must fit the
@@ -762,7 +806,8 @@ static bool dev_rows_take_direct(int K, int64_t n_bound, int cin, int cout) { re
 
 bool gpn::spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout, const gpn::DevRows& rows) {
   if (!rows.dev) return gpn::spconv_fwd_accumulates_stats(K, n_dst, cin, cout);
-  return n_dst > 0 && (dev_rows_take_tiles(K, n_dst, gpn::plan_rows(n_dst, rows), cin, cout) || dev_rows_take_direct(K, n_dst, cin, cout));
+  return n_dst > 0 && (dev_rows_take_tiles(K, n_dst, gpn::plan_rows(n_dst, rows), cin, cout) ||
+                       gpn::spconv_msplit_supported(K, n_dst, cin, cout) || dev_rows_take_direct(K, n_dst, cin, cout));
 }
 
 int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, const int32_t* nbr_p, const int32_t* perm,
@@ -780,6 +825,10 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
   if (tiles) {  // the masked-tile kernel (spconv_tiles.hip): every layer of >= 16 tiles
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout, gpn::prof_shape_tag(K, n_dst, cin, cout, stats.twin.in != nullptr));
     return gpn::spconv_tiles_launch(in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, cout, accumulate, stats, out, stream, rows);
+  }
+  if (gpn::spconv_msplit_supported(K, n_dst, cin, cout)) {  // the masked tap-split kernel (spconv_msplit.hip): every k = 27 / 8 layer below that
+    gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout, gpn::prof_shape_tag(K, n_dst, cin, cout, stats.twin.in != nullptr));
+    return gpn::spconv_msplit_launch(in, packed_w, nbr_p ? nbr_p : nbr, perm, K, n_dst, cin, cout, accumulate, stats, out, stream, rows);
   }
   if (rows.dev ? dev_rows_take_direct(K, n_dst, cin, cout) : use_direct(K, n_dst, cin, cout)) {
     gpn::ProfScope prof(GPN_K_SPCONV_FWD, stream, 0.0, 4.0 * (double)n_dst * cout, gpn::prof_shape_tag(K, n_dst, cin, cout, stats.twin.in != nullptr));

@@ -257,7 +257,7 @@ class GAPartNetInst(LightningDataModule):
             from .packed_cache import PackedSceneLoader, PackedScenes
             split = os.path.basename(os.path.dirname(os.path.dirname(dataset.all_paths[0]))) if dataset.all_paths else "empty"
             cache_dir = self.cache_dir or os.path.join(str(self.root_dir), ".gpn_cache")
-            scenes = PackedScenes.open(dataset.all_paths, cache_dir, split, num_workers=self.num_workers)
+            scenes = PackedScenes.open(dataset.all_paths, cache_dir, split, num_workers=self.num_workers, max_points=dataset.max_points)
             where = {p: i for i, p in enumerate(dataset.all_paths)}
             return PackedSceneLoader(scenes, batch_size, shuffle and sampler is None, drop_last, sampler=sampler,
                                      index_map=[where[p] for p in dataset.pc_paths])

@@ -40,7 +40,8 @@ def _digest(paths: Sequence[str]) -> str:
     h = hashlib.sha256()
     for p in paths:
         st = os.stat(p)
-        h.update(f"{os.path.basename(p)}\0{st.st_size}\0{int(st.st_mtime)}\n".encode())
+        # (nanosecond mtime: a file rewritten within the same second at the same size must not find the old cache)
+        h.update(f"{os.path.basename(p)}\0{st.st_size}\0{st.st_mtime_ns}\n".encode())
     return h.hexdigest()[:16]
 
 
@@ -80,12 +81,21 @@ class PackedScenes:
         return len(self.names)
 
     @staticmethod
-    def open(paths: Sequence[str], cache_dir: str, split: str, num_workers: int = 0) -> "PackedScenes":
+    def open(paths: Sequence[str], cache_dir: str, split: str, num_workers: int = 0, max_points: Optional[int] = None) -> "PackedScenes":
+        """``max_points``: the dataset's bound on a scene's size (GAPartNetDataset applies it per scene through ``downsample``,
+        dataset/gapartnet.py:43-46, which raises on a larger scene): checked here for every scene of the cache, so that an
+        oversized scene is reported when the loader is made instead of entering a batch silently"""
         paths = list(paths)
         directory = os.path.join(cache_dir, f"{split}-{_digest(paths)}")
         if not os.path.exists(os.path.join(directory, "meta.json")):
             PackedScenes._build(paths, directory, num_workers)
-        return PackedScenes(directory)
+        scenes = PackedScenes(directory)
+        if max_points is not None and len(scenes):
+            counts = np.diff(scenes.offsets)
+            worst = int(counts.argmax())
+            if int(counts[worst]) > max_points:
+                raise AssertionError((scenes.names[worst], int(counts[worst]), max_points))
+        return scenes
 
     @staticmethod
     def _build(paths, directory, num_workers):

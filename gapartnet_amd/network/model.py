@@ -49,13 +49,8 @@ class _PendingKept:
 
     def resolve(self):
         kept = GAPartNet._kept_from(self.proposals, self.handle.result())
-        if kept is None:
-            if self.proposals.dev_counts is not None:
-                raise RuntimeError("post-processing fell back to the torch formulation on a device-counted step")
-            p = self.model._post_process(self.proposals)
-            kept = Instances(score_preds=p.score_preds, pt_sem_classes=p.pt_sem_classes, batch_indices=p.batch_indices,
-                             instance_sem_labels=p.instance_sem_labels, ious=p.ious, proposal_offsets=p.proposal_offsets,
-                             valid_mask=p.valid_mask)
+        if kept is None:  # a neighbour table inside the kernel overflowed: the torch formulation on the live rows
+            kept = self.model._post_process_kept_torch(self.proposals)
         self.model = self.proposals = self.handle = None
         return kept
 
@@ -683,6 +678,42 @@ class GAPartNet(LightningModule):
         proposals.pt_sem_classes = proposals.sem_preds[proposals.proposal_offsets[:-1].long()]
         return proposals
 
+    @staticmethod
+    def _sliced_to_live_sizes(proposals: Instances) -> Instances:
+        """device-counted proposals (every tensor at its bound, the live counts on the device) as exactly-sized ones: two host
+        reads - only the fallback of the fused post-processing takes this path"""
+        dev = proposals.dev_counts
+        if dev is None:
+            return proposals
+        m_bound, p_bound = int(proposals.point_indices.shape[0]), int(proposals.score_preds.shape[0])
+        M, P = int(dev["M"].t.item()), int(dev["P"].t.item())
+
+        def pts(t):
+            return t[:M] if (t is not None and t.shape[0] == m_bound) else t
+
+        def props(t):
+            return t[:P] if (t is not None and t.shape[0] == p_bound) else t
+
+        return Instances(
+            valid_mask=proposals.valid_mask, valid_indices=proposals.valid_indices, sorted_indices=pts(proposals.sorted_indices),
+            point_indices=pts(proposals.point_indices), pt_xyz=pts(proposals.pt_xyz), batch_indices=pts(proposals.batch_indices),
+            proposal_offsets=proposals.proposal_offsets[:P + 1], proposal_indices=pts(proposals.proposal_indices),
+            num_points_per_proposal=props(proposals.num_points_per_proposal), sem_preds=pts(proposals.sem_preds),
+            score_preds=props(proposals.score_preds), npcs_preds=pts(proposals.npcs_preds), sem_labels=pts(proposals.sem_labels),
+            instance_labels=pts(proposals.instance_labels), instance_sem_labels=proposals.instance_sem_labels,
+            num_points_per_instance=proposals.num_points_per_instance, gt_npcs=pts(proposals.gt_npcs),
+            npcs_valid_mask=pts(proposals.npcs_valid_mask), ious=props(proposals.ious))
+
+    def _post_process_kept_torch(self, proposals: Instances) -> Instances:
+        """what validation_step keeps of a step's proposals through the torch formulation (``_post_process``): the path of the
+        oracle backend and of the unfused proposal stage, and the FALLBACK of the fused call when a proposal shares points with
+        more proposals than its kernel tables hold (64 distinct / 32 above the IoU threshold) - also on a device-counted step,
+        whose tensors are cut to their live sizes first (round 5 raised there: an aborted validation instead of a slower one)"""
+        p = self._post_process(self._sliced_to_live_sizes(proposals))
+        return Instances(score_preds=p.score_preds, pt_sem_classes=p.pt_sem_classes, batch_indices=p.batch_indices,
+                         instance_sem_labels=p.instance_sem_labels, ious=p.ious, proposal_offsets=p.proposal_offsets,
+                         valid_mask=p.valid_mask)
+
     def _post_process_kept(self, proposals: Instances, defer: bool = False):
         """what validation_step keeps of ``_post_process(proposals)`` - score filter, NMS, re-indexed fields - through ONE library
         call (gpn_proposals_postprocess, csrc/postprocess.hip: flags, one sort, sparse intersections through the proposal
@@ -738,12 +769,7 @@ class GAPartNet(LightningModule):
             # queued: defer_validation_outputs; a direct call gets its proposals back at once, as the reference's does)
             kept = self._post_process_kept(proposals, defer=self.defer_validation_outputs) if fast else None
             if kept is None:
-                if proposals.dev_counts is not None:
-                    raise RuntimeError("post-processing fell back to the torch formulation on a device-counted step")
-                p = self._post_process(proposals)
-                kept = Instances(score_preds=p.score_preds, pt_sem_classes=p.pt_sem_classes, batch_indices=p.batch_indices,
-                                 instance_sem_labels=p.instance_sem_labels, ious=p.ious,
-                                 proposal_offsets=p.proposal_offsets, valid_mask=p.valid_mask)
+                kept = self._post_process_kept_torch(proposals)
         self._stash(dataloader_idx, (pc_ids, sem_seg, kept))
         return pc_ids, sem_seg, kept
 

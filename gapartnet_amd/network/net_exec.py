@@ -389,8 +389,8 @@ class NetProgram:
         PERSISTENT pair of this device is handed out - created once, overwritten by every backward pass - under an explicit
         contract (round 5; it replaces reference-count heuristics): every hand-out is a generation, and the pair is reused
         only when the previous generation was RELEASED by whoever consumed the gradients (``release_gradients()``: called by
-        FusedAdam.step / .zero_grad, the Trainer and bench.py's loop after the optimizer step; ``net_exec.release_gradients
-        (model)`` for any other loop).  Without a release the previous pair is retired - it stays alive, untouched, with
+        FusedAdam.step / .zero_grad - bench.py's loop runs on that - and by the Trainer after ``optimizer.step()`` whatever the
+        optimizer; ``net_exec.release_gradients(model)`` for any other loop).  Without a release the previous pair is retired - it stays alive, untouched, with
         whoever holds its views - and a new one is made: correct for any training loop, one allocation per pass slower.
         After a release the views are overwritten in place by the next backward pass, exactly like ``.grad`` tensors under
         ``zero_grad(set_to_none=False)``: clone what you keep."""

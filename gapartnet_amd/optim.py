@@ -57,7 +57,13 @@ class FusedAdam(torch.optim.Adam):
         # step whose proposal count was never read on the host
         self._gated = frozenset()
         self._gate_fn = None
-        self._gate_skipped = None  # device int64 [1]: steps the gate suppressed (the gated tensors' step number lags by it)
+        # steps the gate suppressed, counted on the device PER TABLE of gated tensors (the tensors of a table step - or sit out -
+        # together; their step number lags by the table's count): parameter -> int64 [1] device tensor shared by its table.
+        # (Round 5 kept ONE counter for all gated tables: with training_schedule [5, 10] ScoreNet and NPCS-Net start at different
+        # epochs, are two tables, and every step without proposals was counted twice - and charged to tensors that had not
+        # started yet.)
+        self._skip_ctr = {}
+        self._gate_open = None
 
     def set_gate(self, params, gate_fn):
         """``params`` take part in a step only if the device counter ``gate_fn()`` points at is non-zero (gpn_adam_step_gated);
@@ -73,17 +79,27 @@ class FusedAdam(torch.optim.Adam):
         self._snap.clear()
 
     # ---------------------------------------------------------------------------------------------- state (de)serialisation
+    def _fold_skips(self, params=None):
+        """the host-side step counts take over the steps the gate suppressed (a host read per counter: checkpoints and table
+        rebuilds only); the counters of the given parameters (default: all) are retired - for EVERY parameter that shares them"""
+        ctrs = {}
+        for p, c in self._skip_ctr.items():
+            ctrs.setdefault(id(c), (c, []))[1].append(p)
+        wanted = None if params is None else {id(self._skip_ctr[p]) for p in params if p in self._skip_ctr}
+        for key, (c, plist) in ctrs.items():
+            if wanted is not None and key not in wanted:
+                continue
+            skipped = int(c.item())
+            for p in plist:
+                self._nstep[p] -= skipped
+                del self._skip_ctr[p]
+
     def _sync_step_tensors(self):
-        skipped = int(self._gate_skipped.item()) if self._gate_skipped is not None else 0  # (a host read: checkpoints only)
+        self._fold_skips()
         for p, n in self._nstep.items():
             st = self.state.get(p)
             if st:
-                st["step"] = torch.tensor(float(n - skipped if p in self._gated else n), dtype=torch.float32)
-        if skipped:  # the host-side counts take the suppressed steps over, the device counter starts again
-            for p in self._nstep:
-                if p in self._gated:
-                    self._nstep[p] -= skipped
-            self._gate_skipped.zero_()
+                st["step"] = torch.tensor(float(n), dtype=torch.float32)
 
     def state_dict(self):
         self._sync_step_tensors()
@@ -218,6 +234,8 @@ class FusedAdam(torch.optim.Adam):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             self._nstep.setdefault(p, int(st["step"]))
+        if self._skip_ctr:  # tensors are regrouped: their true step counts first (a table's tensors share one skip counter)
+            self._fold_skips(params)
         by_step = {}
         for p in params:
             by_step.setdefault((self._nstep[p], p in self._gated), []).append(p)
@@ -300,8 +318,8 @@ class FusedAdam(torch.optim.Adam):
                 # counts of the time it was built, and some of its tensors may have sat out steps since (round 5: a batch
                 # without proposals, then one with - the cached table gave ScoreNet / NPCS-Net the backbone's step number,
                 # i.e. the wrong bias corrections, for the rest of the run)
-                nstep = self._nstep
-                if any(len({nstep[p] for p in plist}) > 1 for _t, _f, _b, plist, _pin in tables):
+                nstep, ctr_of = self._nstep, self._skip_ctr
+                if any(len({(nstep[p], id(ctr_of.get(p))) for p in plist}) > 1 for _t, _f, _b, plist, _pin in tables):
                     tables = self._build(group, [p for p in group["params"] if p.grad is not None])
                     sets[sig] = tables
             self._last_sig[gi] = sig
@@ -316,14 +334,18 @@ class FusedAdam(torch.optim.Adam):
             for table, first, blocks, plist, _pinned in tables:
                 n = nstep[plist[0]] + 1
                 gate_ptr = skip_ptr = None
-                if plist[0] in self._gated and (gate is not None or self._gate_skipped is not None):
-                    # (once a step was suppressed the gated tensors' step number lags: every later launch goes through the
-                    # gated entry point, with an always-open gate when this step has none)
-                    if self._gate_skipped is None:
-                        self._gate_skipped = torch.zeros((1,), dtype=torch.int64, device=dev)
+                ctr = self._skip_ctr.get(plist[0]) if plist[0] in self._gated else None
+                if plist[0] in self._gated and (gate is not None or ctr is not None):
+                    # (once a step was suppressed the table's step number lags: every later launch goes through the gated entry
+                    # point, with an always-open gate when this step has none)
+                    if ctr is None:
+                        ctr = torch.zeros((1,), dtype=torch.int64, device=dev)
+                        for p in plist:
+                            self._skip_ctr[p] = ctr
+                    if self._gate_open is None:
                         self._gate_open = torch.ones((1,), dtype=torch.int64, device=dev)
                     g_t, g_i = gate if gate is not None else (self._gate_open, 0)
-                    gate_ptr, skip_ptr = g_t.data_ptr() + 8 * int(g_i), self._gate_skipped.data_ptr()
+                    gate_ptr, skip_ptr = g_t.data_ptr() + 8 * int(g_i), ctr.data_ptr()
                 _C.check(L.gpn_adam_step_gated(ctypes.c_void_p(table.data_ptr()), ctypes.c_void_p(first.data_ptr()), len(plist), blocks,
                                                ctypes.c_double(group["lr"]), ctypes.c_double(beta1), ctypes.c_double(beta2),
                                                ctypes.c_double(group["eps"]), ctypes.c_int64(n), ctypes.c_void_p(gate_ptr),

@@ -211,6 +211,9 @@ class Trainer:
                 aug = getattr(datamodule, "aug", None) if getattr(datamodule, "device_pipeline", False) else None
                 # batch i+1 prepared while batch i trains (raw scenes are also augmented there, per batch, on the GPU)
                 feed = DevicePrefetcher(train_dataloaders, model, self.device, augmentation=aug)
+            from .network.net_exec import release_gradients
+            from .optim import FusedAdam
+            acknowledges = isinstance(optimizer, FusedAdam)
             for batch_idx, batch in enumerate(feed):
                 if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
                     break
@@ -221,6 +224,11 @@ class Trainer:
                 if grad_sync is not None:
                     grad_sync.sync()
                 optimizer.step()
+                # the step has consumed the sparse U-Nets' gradients: their persistent buffers may be overwritten by the next
+                # backward pass (network/net_exec.py, gradient hand-over contract).  FusedAdam acknowledges that itself; an
+                # optimizer from a configure_optimizers override does not, and would cost an allocation per step without this
+                if not acknowledges:
+                    release_gradients(model)
                 self.global_step += 1
             metrics = log.reduce(self.device)
             metrics["epoch_time_s"] = time.time() - t0

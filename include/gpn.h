@@ -216,6 +216,12 @@ int64_t gpn_spconv_tiles_min_tiles(int64_t min_tiles);
 /* layers with few (16-row tile, 16-column tile) units run the direct kernel in a tap-split form (2 or 4 waves per unit,
  * partial sums added in LDS in wave order; csrc/spconv_fwd.hip): thresholds in units, negative = unchanged, 0 = never. */
 int gpn_spconv_direct_split(int64_t split4_below_units, int64_t split2_below_units);
+/* kernel selection knob (round 6): k = 27 / 8 layers below the masked-tile kernel's size run on the masked tap-split kernel
+ * (csrc/spconv_msplit.hip: a workgroup per row tile, its waves own tap ranges, dead taps skipped); mode 0 hands them back to the
+ * direct kernel, mode < 0 leaves the setting.  force_nt (1 - 4, a divisor of the layer's column tiles) / force_sp (4 or 9) fix the
+ * column tiles per workgroup / the waves per row tile for every layer instead of the built-in table (0 = table, < 0 = unchanged):
+ * measurement and test knob.  Returns the previous mode. */
+int gpn_spconv_msplit(int mode, int force_nt, int force_sp);
 size_t gpn_spconv_fwd_w_ws_bytes(int K, int64_t n_dst, int cin, int cout);
 int gpn_spconv_fwd_w(const float* in, const float* W, int K, int cin_w, int cout_w, int pack_flags, const int32_t* nbr,
                      int64_t n_dst, float* out, void* ws, size_t ws_bytes, gpn_stream_t stream);
@@ -618,6 +624,10 @@ int gpn_proposals_postprocess(const float* score_preds, const int64_t* sizes, co
                               int64_t P, const int64_t* p_dev, int64_t p_plan, float score_threshold, int64_t min_points,
                               float iou_threshold, int32_t* kept_ids, int32_t* new_offsets, int64_t* src_row, int64_t* counts,
                               void* ws, size_t ws_bytes, gpn_stream_t stream);
+/* The NMS kernel keeps one status byte per LIVE proposal in LDS up to n proposals (default and maximum 131072) and in the
+ * workspace beyond - any bound P is accepted (round 5 rejected bounds above 131072: 32 scenes of 20k points).  n < 0 queries;
+ * returns the previous value.  Tests lower it to run the workspace form on small inputs. */
+int64_t gpn_proposals_postprocess_lds_proposals(int64_t n);
 
 /* ================================================================================================
  * O — the optimizer step.  GAPartNet.configure_optimizers (network/model.py:1051-1055): torch.optim.Adam(lr) over every

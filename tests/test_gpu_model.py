@@ -460,19 +460,28 @@ def test_device_prefetcher_iterated_twice_without_a_host_sync(cuda):
 
 
 @pytest.mark.gpu
-def test_two_rank_bench_shares_one_device(cuda):
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_two_rank_bench_shares_one_device(cuda, launcher):
     """bench.py's multi-rank path (GradSync over the executor's flat gradient buffers, device prefetcher, per-rank scene shards,
     max-over-ranks timing) with two ranks time-slicing ONE GPU over gloo (GPN_DIST_SHARE_DEVICE): the code path the driver
-    runs at N = 2/4/8 over RCCL, minus the performance"""
+    runs at N = 2/4/8 over RCCL, minus the performance.  "self": the plain command `python bench.py --gpus 2` - no RANK in the
+    environment, the script starts its ranks itself (round 6; before, that command died on an assertion); "torchrun": wrapped in
+    `python -m torch.distributed.run` by the caller, as the driver's contract says."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GPN_DIST_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "2", "--points", "6000", "--no-cpu-baseline"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    bench = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--points", "6000",
+             "--no-cpu-baseline"]
+    if launcher == "self":
+        cmd = [sys.executable] + bench
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29533"] + bench
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -480,6 +489,7 @@ def test_two_rank_bench_shares_one_device(cuda):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["config"]["global_batch"] == 4
+    assert res["distributed"]["world_size"] == 2
     ex = res["grad_exchange"]  # 4 steps x (3 U-Nets reduced in place in the executor's buffer + the heads via one cat)
     assert ex["steps"] == 4 and ex["in_place"] >= ex["steps"] and ex["flattened"] >= ex["steps"], ex
 

@@ -322,11 +322,13 @@ def test_masked_tile_kernel_fwd_dgrad(H, cuda, tiles_everywhere, cin, cout):
     assert torch.equal(outs[0], outs[1]) and torch.equal(dins[0], dins[1]), "the tile order must not change a bit"
     prev = _C.lib().gpn_spconv_tiles_min_tiles(1 << 40)  # the (unsplit) direct kernel on the same inputs
     _C.lib().gpn_spconv_direct_split(0, 0)
+    _C.lib().gpn_spconv_msplit(0, -1, -1)
     try:
         assert torch.equal(outs[0], H.conv_fwd_ordered(dev(f, cuda), dev(W, cuda), rb))
     finally:
         _C.lib().gpn_spconv_tiles_min_tiles(prev)
         _C.lib().gpn_spconv_direct_split(12000, 0)
+        _C.lib().gpn_spconv_msplit(1, -1, -1)
 
 
 @pytest.mark.parametrize("ways", [2, 4])
@@ -337,6 +339,7 @@ def test_tap_split_direct_kernel(H, cuda, ways, cin, cout):
     from gapartnet_amd import _C
     big = 1 << 40
     _C.lib().gpn_spconv_direct_split(big if ways == 4 else 0, big if ways == 2 else 0)
+    _C.lib().gpn_spconv_msplit(0, -1, -1)  # (round 6: these layers are the masked tap-split kernel's by default, tests/test_gpu_msplit.py)
     try:
         rng = np.random.default_rng(cin + 3 * cout + ways)
         shape = [40, 40, 40]
@@ -360,6 +363,7 @@ def test_tap_split_direct_kernel(H, cuda, ways, cin, cout):
             assert np.allclose(down, O.spconv_fwd(f, W8, d["fwd"], d["out_indices"].shape[0]), atol=FP_TOL, rtol=1e-4)
     finally:
         _C.lib().gpn_spconv_direct_split(12000, 0)
+        _C.lib().gpn_spconv_msplit(1, -1, -1)
 
 
 def test_masked_tile_kernel_down_inverse_and_ragged_tail(H, cuda, tiles_everywhere):

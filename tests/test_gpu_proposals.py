@@ -240,3 +240,79 @@ def test_validation_step_without_a_host_read_equals_the_blocking_step(cuda):
                 assert torch.allclose(x, y, rtol=1e-5, atol=1e-6), name  # (kernel variants follow the plan: last bits)
             else:
                 assert torch.equal(x, y), name
+
+
+def test_post_processing_with_the_status_bytes_in_the_workspace(cuda):
+    """round 6: the NMS kernel's status table is sized by the LIVE proposal count - LDS up to 131072, the
+    workspace beyond - and any bound is accepted.  Here: the workspace form (threshold lowered to 0) equals the LDS form field
+    by field, and a validation-sized bound above 131072 (32 scenes x 20k points: 256 001) with a few hundred live proposals no
+    longer returns GPN_ERR_ARG."""
+    import ctypes
+    from gapartnet_amd import _C, hip_ops as H
+    L = _C.lib()
+    L.gpn_proposals_postprocess_lds_proposals.argtypes = [ctypes.c_int64]
+    L.gpn_proposals_postprocess_lds_proposals.restype = ctypes.c_int64
+    model = _eval_model(cuda)
+    model.sync_free_proposals = False
+    model.val_score_threshold, model.val_min_num_points_per_proposal, model.val_nms_iou_threshold = 0.0, 0, 0.3
+    batch = [pc.to(cuda) for pc in make_batch(4, 20000, seed0=21300)]
+    with torch.no_grad():
+        _, _, proposals, _ = model._training_or_validation_step(batch, 0, "val", want_npcs_preds=False)
+        ref = model._post_process_kept(proposals)
+        prev = L.gpn_proposals_postprocess_lds_proposals(0)
+        try:
+            ws_form = model._post_process_kept(proposals)
+        finally:
+            L.gpn_proposals_postprocess_lds_proposals(prev)
+    assert prev == 131072
+    for name in KEPT_FIELDS:
+        assert torch.equal(getattr(ref, name), getattr(ws_form, name)), name
+    # the same proposals inside buffers of a 256 001-proposal bound, the live count on the device
+    P = int(proposals.score_preds.shape[0])
+    bound = 256001
+    pad = lambda t, n, fill=0: torch.cat([t, torch.full((n - t.shape[0],) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=t.device)])
+    live = torch.tensor([P], dtype=torch.int64, device=cuda)
+    out = H.proposals_postprocess(pad(proposals.score_preds, bound), pad(proposals.num_points_per_proposal, bound),
+                                  pad(proposals.proposal_offsets, bound + 1), proposals.point_indices, proposals.proposal_indices,
+                                  proposals.member_slot, 0.0, 0, 0.3, rows=H.DevCount(live, P))
+    assert out is not None
+    ids, new_offsets, src_row = out
+    assert torch.equal(new_offsets, ref.proposal_offsets) and ids.shape[0] == ref.score_preds.shape[0]
+    assert torch.equal(proposals.score_preds.index_select(0, ids), ref.score_preds)
+
+
+@pytest.mark.parametrize("defer", [False, True])
+def test_validation_step_falls_back_when_a_neighbour_table_overflows(cuda, monkeypatch, defer):
+    """round 6: a proposal that shares points with more proposals than the post-processing kernel's tables
+    hold makes the fused call report an overflow; a device-counted validation step then cuts its tensors to their live sizes and
+    runs the torch formulation (round 5 raised).  The overflow is forced here (the call's result replaced by the overflow answer);
+    what the step keeps must equal the fused call's."""
+    from gapartnet_amd import hip_ops as H
+    batches = [[pc.to(cuda) for pc in make_batch(4, 20000, seed0=1500 + 10 * j)] for j in range(2)]
+    kept = {}
+    for forced in (False, True):
+        model = _eval_model(cuda)
+        model.sync_free_proposals = True
+        model.defer_validation_outputs = defer
+        if forced:
+            real = H.proposals_postprocess
+
+            def overflowing(*a, defer=False, **kw):
+                out = real(*a, defer=defer, **kw)
+                if defer:
+                    out.result = lambda: None
+                    return out
+                return None
+            monkeypatch.setattr(H, "proposals_postprocess", overflowing)
+        with torch.no_grad():
+            for i, batch in enumerate(batches):
+                model.validation_step(batch, i, 0)
+            model._resolve_pending_outputs()
+        if forced:
+            monkeypatch.undo()
+        assert model._prop_pending, "the second step ran device-counted"
+        kept[forced] = list(model.validation_step_outputs[0])
+    for (_, _, a), (_, _, b) in zip(kept[False], kept[True]):
+        for name in KEPT_FIELDS:
+            x, y = getattr(a, name), getattr(b, name)
+            assert x.shape == y.shape and torch.equal(x, y), name

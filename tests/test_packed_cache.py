@@ -49,6 +49,17 @@ def test_every_scene_comes_out_of_the_cache_as_the_file_loader_returns_it(pth_ro
     # a changed file list is another cache
     other = PackedScenes.open(ds.all_paths[:-1], str(tmp_path / "cache"), "train")
     assert other.directory != scenes.directory and len(other) == 10
+    # the dataset's max_points bound holds for the cache too (the per-file loader raises in downsample(); round 5's cache did not look)
+    assert PackedScenes.open(ds.all_paths, str(tmp_path / "cache"), "train", max_points=800).directory == scenes.directory
+    with pytest.raises(AssertionError):
+        PackedScenes.open(ds.all_paths, str(tmp_path / "cache"), "train", max_points=599)
+    # a file rewritten in place (same name, same size, a later nanosecond) is another cache
+    st = os.stat(ds.all_paths[0])
+    os.utime(ds.all_paths[0], ns=(st.st_atime_ns, st.st_mtime_ns + 1000))
+    try:
+        assert PackedScenes.open(ds.all_paths, str(tmp_path / "cache"), "train").directory != scenes.directory
+    finally:
+        os.utime(ds.all_paths[0], ns=(st.st_atime_ns, st.st_mtime_ns))
 
 
 @pytest.mark.parametrize("drop_last", [True, False])
