@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--schedule", type=str, default="0,0", help="training_schedule; 0,0 = every head active")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lib-knobs", type=str, default="",
+                    help="library switches for A/B runs, e.g. msplit=0,bn_fusion=0,wgrad_group=1,tiles_min_tiles=1000000 "
+                         "(the library reads no environment variables; these call its knob entry points)")
     ap.add_argument("--moving", action="store_true",
                     help="let the parameters train on (rounds 1-5: the proposal stage's load then depends on how many steps preceded)")
     ap.add_argument("--cpu-scenes", type=int, default=3)
@@ -252,6 +255,26 @@ def conv_levels(lib, overhead_us):
     return head
 
 
+def apply_lib_knobs(spec: str):
+    """--lib-knobs name=value,...: the library's measurement switches (include/gpn.h), all of them entry points"""
+    import ctypes
+    from gapartnet_amd import _C
+    lib = _C.lib()
+    for item in filter(None, (spec or "").split(",")):
+        name, _, value = item.partition("=")
+        v = int(value)
+        if name == "msplit":
+            lib.gpn_spconv_msplit(v, -1, -1)
+        elif name == "bn_fusion":
+            lib.gpn_net_bn_fusion(v)
+        elif name == "wgrad_group":
+            lib.gpn_net_wgrad_group(v)
+        elif name == "tiles_min_tiles":
+            lib.gpn_spconv_tiles_min_tiles(ctypes.c_int64(v))
+        else:
+            raise SystemExit(f"--lib-knobs: unknown switch {name!r}")
+
+
 def proposal_summary(plans):
     rows = [p for p in plans if p]
     if not rows:
@@ -341,6 +364,7 @@ def main():
     from gapartnet_amd import _C, functional as GF
     from gapartnet_amd.smoke import make_batch, make_model
     _C.lib()  # fail loudly if the HIP extension is missing
+    apply_lib_knobs(args.lib_knobs)
 
     schedule = tuple(int(s) for s in args.schedule.split(","))
     model = make_model(schedule).to(device)

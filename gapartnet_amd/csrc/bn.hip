@@ -843,13 +843,7 @@ int gpn::bn_bwd_rows(const float* x, const float* y, const float* dy, const floa
 // shapes whose BatchNorm can run as an apply pass over sums a conv launch accumulated.  Any row count since round 3 (the
 // small levels too: an apply launch is 4.8 us where the single-launch small-matrix form is 8.7 forward / 14 backward);
 // env GPN_BN_FUSE_MIN_ROWS restores a lower bound (1025 = the round-2 behaviour)
-bool gpn::bn_two_pass(int64_t N, int C) {
-  static const int64_t min_rows = [] {
-    const char* e = getenv("GPN_BN_FUSE_MIN_ROWS");
-    return (int64_t)(e ? atoll(e) : 1);
-  }();
-  return N >= min_rows && N >= 1 && C % 4 == 0 && C <= kFoldMaxC;
-}
+bool gpn::bn_two_pass(int64_t N, int C) { return N >= 1 && C % 4 == 0 && C <= kFoldMaxC; }
 
 int gpn::bn_fwd_train_fused(const gpn::BnFwdPtrs& p, const gpn::BnFwdPtrs* twin, int64_t N, int C, float eps, float momentum,
                             int relu, hipStream_t stream, const gpn::DevRows& rows) {

@@ -105,6 +105,19 @@ inline int stat_slot_count(int64_t rows) {
 // A second, independent problem of the same shape over the same rulebook, computed by the workgroups with blockIdx.y == 1
 // of the SAME launch (the executor's paired passes over two structurally identical networks, net.hip): its operand /
 // result / BatchNorm-sum pointers.  in == nullptr: none.
+// An eval-mode BatchNorm (+ residual add, + ReLU) applied by the conv launch that produces its input, in the epilogue (round 6:
+// an inference pass - running statistics, no backward pass to follow - has no BatchNorm launches at all).  Per output element
+// exactly the arithmetic of the stand-alone pass (bn.hip, bn_apply_eval_kernel): ((v - mean) * (1 / sqrt(var + eps))) * weight +
+// bias, then + res, then max(0, .) - the same bits.  mean == nullptr: none.
+struct ConvAffine {
+  const float* mean = nullptr;
+  const float* var = nullptr;
+  const float* weight = nullptr;
+  const float* bias = nullptr;
+  const float* res = nullptr;  // [rows, cout] residual, or nullptr
+  float eps = 0.f;
+  int relu = 0;
+};
 struct ConvTwin {
   const float* in = nullptr;
   const float* packed = nullptr;
@@ -114,6 +127,7 @@ struct ConvTwin {
   const float* y = nullptr;
   const float* mean = nullptr;
   const float* invstd = nullptr;
+  ConvAffine ep;  // the second problem's BatchNorm (eps and relu are the first one's)
 };
 struct ConvStats {
   unsigned long long* slab = nullptr;  // [kStatSlots][4][C] fixed-point words (the first slot_mask + 1 sets used), zeroed by the caller
@@ -123,8 +137,24 @@ struct ConvStats {
   const float* mean = nullptr;
   const float* invstd = nullptr;
   int relu = 0;
+  ConvAffine ep;  // an inference pass's BatchNorm on the conv's output (never together with a slab)
   ConvTwin twin;  // (rides with the sums: both are "what else this launch does", and every launch path already carries this struct)
 };
+#ifdef __HIPCC__
+// the four per-column constants of a ConvAffine, and its application to one output element e = row * cout + col
+struct AffineCol {
+  float mu, is, w, b;
+};
+__device__ __forceinline__ AffineCol affine_col(const ConvAffine& ep, uint32_t col) {
+  return AffineCol{ep.mean[col], 1.0f / sqrtf(ep.var[col] + ep.eps), ep.weight[col], ep.bias[col]};
+}
+__device__ __forceinline__ float affine_apply(const ConvAffine& ep, const AffineCol& c, float v, uint32_t e) {
+  v = (v - c.mu) * c.is * c.w + c.b;
+  if (ep.res) v += ep.res[e];
+  if (ep.relu) v = v > 0.f ? v : 0.f;
+  return v;
+}
+#endif
 // pointer sets of the BatchNorm apply passes; a launch takes two and its workgroups pick by blockIdx.y (twin launches as above)
 struct BnFwdPtrs {
   const float* x = nullptr;
@@ -160,6 +190,8 @@ int spconv_fwd_into(const float* in, const float* packed_w, const int32_t* nbr, 
 // true if a conv of this shape runs on a kernel whose epilogue can accumulate ConvStats (masked-tile or direct kernel)
 bool spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout);
 bool spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout, const DevRows& rows);
+// true if a conv of this shape runs on a kernel whose epilogue can apply a ConvAffine (an inference pass's BatchNorm)
+bool spconv_fwd_applies_affine(int K, int64_t n_dst, int cin, int cout, const DevRows& rows);
 // the masked-tile kernel (spconv_tiles.hip): which shapes it takes, and its launch
 bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout);
 int spconv_tiles_launch(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,

@@ -30,16 +30,13 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// BatchNorm sums in the conv epilogues (bn_stats.h) on / off: env GPN_BN_FUSE=0 or gpn_net_bn_fusion(0) restores the separate
-// statistics launches (A/B measurements, and the tests that compare the two forms)
-// (the environment readers of this file are NAMED functions: hipcc numbers the lambdas of namespace-scope initialisers per
-// anonymous-namespace block, so a lambda in a second block got the mangled name - and, at link time, the body - of the first
-// block's: a knob that silently read another knob's variable)
-int env_bn_fusion() {
-  const char* e = getenv("GPN_BN_FUSE");
-  return e ? atoi(e) : 1;
-}
-std::atomic<int> g_bn_fusion{env_bn_fusion()};
+// BatchNorm in the conv launches - training: the sums in the conv / dgrad epilogues (bn_stats.h); inference: the whole BatchNorm
+// (gpn::ConvAffine) - on / off: gpn_net_bn_fusion(0) restores the separate launches (A/B measurements, and the tests that compare
+// the two forms).  (Round 6: no environment readers are left in the library - every switch is an entry point that a test flips.
+// Round 3's trap, for the record: hipcc numbers the lambdas of namespace-scope initialisers per anonymous-namespace block, so a
+// lambda in a second block got the mangled name - and, at link time, the body - of the first block's: a knob that silently read
+// another knob's variable.)
+std::atomic<int> g_bn_fusion{1};
 
 // dst[r, 0:ca] = a[r, :], dst[r, ca:ca+cb] = b[r, :]   (float4 granularity; channel counts are multiples of 4).  Two pointer
 // sets per launch, picked by blockIdx.y (paired passes, see NetSet below)
@@ -134,12 +131,7 @@ inline int64_t plan_of(const gpn_net_slot_t& s) { return gpn::plan_rows(s.rows, 
 
 // partials of the layers whose slice sums are batched into one launch: at most this much (they are written and read back
 // within a few launches - the bound keeps them inside the 256 MB memory-side cache)
-size_t env_wgrad_batch_bytes() {  // env GPN_WGRAD_BATCH_MB
-  const char* e = getenv("GPN_WGRAD_BATCH_MB");
-  const long long mb = e ? atoll(e) : 96;
-  return (size_t)(mb < 1 ? 1 : mb) << 20;
-}
-const size_t kWgradBatchBytes = env_wgrad_batch_bytes();
+constexpr size_t kWgradBatchBytes = (size_t)96 << 20;
 
 struct Need {
   size_t tmp = 0;     // gradient staging buffer (largest slot that can receive a second gradient)
@@ -324,8 +316,15 @@ struct NetSet {
 };
 
 int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const NetSet* nets, int n_nets, int n_slots,
-                     const gpn_net_rulebook_t* rbs, int n_rbs, int n_convs, int n_bns, int training, void* ws, size_t ws_bytes,
+                     const gpn_net_rulebook_t* rbs, int n_rbs, int n_convs, int n_bns, int mode, void* ws, size_t ws_bytes,
                      hipStream_t stream) {
+  // mode: 0 = eval (running statistics), 1 = training (batch statistics), GPN_NET_INFERENCE = eval and no backward pass follows
+  const int training = mode == 1 ? 1 : 0;
+  const bool inference = mode == GPN_NET_INFERENCE;
+  if (mode != 0 && mode != 1 && mode != GPN_NET_INFERENCE) {
+    gpn::set_error("%s: training must be 0, 1 or GPN_NET_INFERENCE", who);
+    return GPN_ERR_ARG;
+  }
   int rc = GPN_OK;
   for (int t = 0; t < n_nets; ++t) {
     rc = check_program(who, ops, n_ops, nets[t].slots, n_slots, rbs, n_rbs, nets[t].convs, n_convs, nets[t].bns, n_bns);
@@ -373,8 +372,34 @@ int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const 
     }
   }
   const bool pair = n_nets == 2;
+  // inference (running statistics, no backward pass to follow): a BatchNorm that directly follows a conv - the only reader of the
+  // conv's output, the conv on a kernel with the affine epilogue - is applied by that conv's launch (gpn::ConvAffine: the same
+  // arithmetic per element, the same bits) and has no launch of its own; the conv's own output slot stays unwritten.
+  // folded[i] != 0: BN op i was applied by CONV op i - 1.
+  std::vector<char> folded(n_ops, 0);
+  if (inference && g_bn_fusion.load(std::memory_order_relaxed)) {
+    std::vector<int> readers(n_slots, 0);
+    for (int i = 0; i < n_ops; ++i) {
+      readers[ops[i].src0]++;
+      if (ops[i].src1 >= 0) readers[ops[i].src1]++;
+    }
+    for (int i = 0; i + 1 < n_ops; ++i) {
+      const gpn_net_op_t &cv_op = ops[i], &bn_op = ops[i + 1];
+      if (cv_op.kind != GPN_NET_CONV || bn_op.kind != GPN_NET_BN || bn_op.src0 != cv_op.dst || readers[cv_op.dst] != 1) continue;
+      if (bn_op.src1 == cv_op.dst || bn_op.dst == cv_op.src0) continue;
+      const gpn_net_rulebook_t& rb = rbs[cv_op.rulebook];
+      const gpn_net_conv_t& cv = nets[0].convs[cv_op.param];
+      bool ok = gpn::spconv_fwd_applies_affine(rb.K, rb.n_dst, cv.cin, cv.cout, dev_rows(nets[0].slots[cv_op.dst]));
+      for (int t = 0; t < n_nets; ++t) {
+        const gpn_net_bn_t& bn = nets[t].bns[bn_op.param];
+        ok = ok && bn.running_mean && bn.running_var && bn.eps == nets[0].bns[bn_op.param].eps;
+      }
+      if (ok) folded[i + 1] = 1;
+    }
+  }
   for (int i = 0; i < n_ops; ++i) {
     const gpn_net_op_t& op = ops[i];
+    if (folded[i]) continue;  // (applied by the conv before it)
     for (int t = 0; t < n_nets; ++t)
       if (!nets[t].slots[op.src0].data || !nets[t].slots[op.dst].data) {
         gpn::set_error("%s: op %d: null activation pointer", who, i);
@@ -393,7 +418,30 @@ int net_forward_impl(const char* who, const gpn_net_op_t* ops, int n_ops, const 
         st.twin.out = nets[1].slots[op.dst].data;
         st.twin.slab = slab_of[1][i];
       }
-      rc = gpn::spconv_fwd_into(s0.data, packed_of[0][i], rb.nbr, rb.nbr_p, rb.perm, rb.K, rb.n_dst, cv.cin, cv.cout, d.data, 0, st,
+      float* out = d.data;
+      if (i + 1 < n_ops && folded[i + 1]) {  // this launch also applies the BatchNorm behind it, into that BatchNorm's output slot
+        const gpn_net_op_t& bo = ops[i + 1];
+        auto affine = [&](int t) {
+          const gpn_net_bn_t& bn = nets[t].bns[bo.param];
+          gpn::ConvAffine a;
+          a.mean = bn.running_mean, a.var = bn.running_var, a.weight = bn.weight, a.bias = bn.bias;
+          a.res = bo.src1 >= 0 ? nets[t].slots[bo.src1].data : nullptr;
+          a.eps = bn.eps, a.relu = (bo.flags & GPN_NET_RELU) ? 1 : 0;
+          return a;
+        };
+        for (int t = 0; t < n_nets; ++t)
+          if (!nets[t].slots[bo.dst].data || (bo.src1 >= 0 && !nets[t].slots[bo.src1].data)) {
+            gpn::set_error("%s: op %d: null activation pointer", who, i + 1);
+            return GPN_ERR_ARG;
+          }
+        st.ep = affine(0);
+        out = nets[0].slots[bo.dst].data;
+        if (pair) {
+          st.twin.ep = affine(1);
+          st.twin.out = nets[1].slots[bo.dst].data;
+        }
+      }
+      rc = gpn::spconv_fwd_into(s0.data, packed_of[0][i], rb.nbr, rb.nbr_p, rb.perm, rb.K, rb.n_dst, cv.cin, cv.cout, out, 0, st,
                                 op_ws, op_ws_bytes, stream, dev_rows(d));
     } else if (op.kind == GPN_NET_BN) {
       const int relu = (op.flags & GPN_NET_RELU) ? 1 : 0;
@@ -479,25 +527,16 @@ namespace {
 // waits) off the thread that issues the dgrad / BatchNorm chain shortens the host side of the pass by about a third.
 // Protocol: the caller publishes jobs (plain structs) through an atomic counter while the pass runs; the worker spins
 // on the counter during a pass and sleeps on a condition variable between passes.
-// layers per weight-gradient contraction launch (1 ... gpn::kWgradSets; env GPN_WGRAD_GROUP, gpn_net_wgrad_group()).  1 = only
+// layers per weight-gradient contraction launch (1 ... gpn::kWgradSets; gpn_net_wgrad_group()).  1 = only
 // the two networks of a paired pass share a launch (what every measurement of round 3 ran: the knob was unreadable, see the
 // note at env_bn_fusion).  First measurement, round 4 (tools/wgrad_group_ab.sh, profiles/r04_wgrad_group_ab.txt): the grouped
 // path is bit-equal (48 executor / paired-pass / golden tests at 4), 90 -> 67 launches per step on the weight-gradient stream,
 // step time 8.79 / 8.78 / 8.72 ms mean of three interleaved runs at 1 / 2 / 4 - inside the noise, fewer launches for the helper
 // thread to issue: default 4.
-int env_wgrad_group() {
-  const char* e = getenv("GPN_WGRAD_GROUP");
-  const int v = e ? atoi(e) : 4;
-  return v < 1 ? 1 : (v > gpn::kWgradSets ? gpn::kWgradSets : v);
-}
-std::atomic<int> g_wgrad_group{env_wgrad_group()};
+std::atomic<int> g_wgrad_group{4};
 std::atomic<int>& wgrad_group_setting() { return g_wgrad_group; }
 
-int64_t env_wgrad_group_rows() {  // only layers with fewer rows than this share a launch (env GPN_WGRAD_GROUP_ROWS)
-  const char* e = getenv("GPN_WGRAD_GROUP_ROWS");
-  return (int64_t)(e ? atoll(e) : 16384);
-}
-const int64_t g_wgrad_group_rows = env_wgrad_group_rows();
+constexpr int64_t g_wgrad_group_rows = 16384;  // only layers with fewer rows than this share a launch
 
 struct WgradJob {
   const float* in;

@@ -781,11 +781,7 @@ extern "C" int gpn_proposals_build(const float* points, int point_stride, const 
   hipLaunchKernelGGL(prop_scale_points_kernel, dim3(grid_of(T2)), dim3(kThreads), 0, stream, pt_xyz_p, proposal_indices, counts,
                      o.mean, o.scale, o.shift, T2, o.scaled);
   GPN_CHECK_LAUNCH();
-  static const bool revox_enabled = [] {  // GPN_PROPOSALS_REVOX=0: the sort-based voxeliser (A/B switch)
-    const char* e = getenv("GPN_PROPOSALS_REVOX");
-    return e ? atoi(e) != 0 : true;
-  }();
-  if (revox_enabled && revox_fits(fullscale)) {
+  if (revox_fits(fullscale)) {
     int rc = revoxelize(o.scaled, proposal_offsets, counts, T2, P_ub, fullscale, o.vc3, o.vseg, pc_voxel_id, point_order,
                         voxel_point_start, o.rv_nvox, o.rv_nout, o.rv_vbase, o.rv_kbase, o.rv_obase, stream);
     if (rc) return rc;

@@ -296,20 +296,9 @@ int wgrad_splits(int K, int cin, int cout, int64_t n_dst) {
   // (profiles/r03_findings.md): rows per slice 32 / 64 / 128 / 384 / 768 / 1536 -> 9.43 / 9.5 / 8.9 / 9.0 / 9.4 / 9.95 ms per
   // step; partial cap 2 / 3 / 4 / 6 / 8 / 16 MB -> 10.3 / 9.8 / 9.1 / 9.7 / 9.3 / 9.5 ms in single runs (box noise +-0.3), and
   // 4 MB (with the thread-per-element reduce up to 64 slices) 9.32 vs 9.16 ms for 8 MB in an interleaved same-box A/B.
-  // env: GPN_WGRAD_TARGET_WGS, GPN_WGRAD_ROWS_PER_SLICE, GPN_WGRAD_PARTIAL_MB
-  static const int64_t target_wgs = [] {
-    const char* e = getenv("GPN_WGRAD_TARGET_WGS");
-    return (int64_t)(e ? atoll(e) : 4096);
-  }();
-  static const int64_t partial_mb = [] {
-    const char* e = getenv("GPN_WGRAD_PARTIAL_MB");
-    return (int64_t)(e ? atoll(e) : 4);
-  }();
+  // (the three constants were environment switches until round 6; the sweeps above are their record)
+  constexpr int64_t target_wgs = 4096, partial_mb = 4, rows_per_slice = 128;
   int64_t S = target_wgs / ((int64_t)K * cig);
-  static const int64_t rows_per_slice = [] {
-    const char* e = getenv("GPN_WGRAD_ROWS_PER_SLICE");
-    return (int64_t)(e ? atoll(e) : 128);
-  }();
   const int64_t cap = n_dst / rows_per_slice;
   if (S > cap) S = cap;
   const int64_t mem_cap = (partial_mb << 20) / ((int64_t)K * cin * cout * 4);

@@ -288,7 +288,8 @@ int dispatch_cw(const FwdPlan& p, const float* in, const float* packed, const in
 #ifndef GPN_DIRECT_D
 #define GPN_DIRECT_D 4
 #endif
-template <int KT, int CB, bool DEV>  // DEV: the row count is a device counter (gpn::DevRows), units walked with a grid stride
+// EP: an inference pass's BatchNorm in the epilogue (gpn::ConvAffine; instantiated for the k = 1 layers, which have no other kernel)
+template <int KT, int CB, bool DEV, bool EP>  // DEV: the row count is a device counter (gpn::DevRows), units walked with a grid stride
 __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                                                 const int32_t* __restrict__ nbr, int64_t n_dst, int nt_total,
                                                                 int64_t units, size_t packed_bytes,
@@ -299,6 +300,11 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
     in = stats.twin.in, packed = stats.twin.packed, out = stats.twin.out;
     stats.slab = stats.twin.slab, stats.x = stats.twin.x, stats.y = stats.twin.y, stats.mean = stats.twin.mean,
     stats.invstd = stats.twin.invstd;
+    if constexpr (EP) {
+      const float eps = stats.ep.eps;
+      const int relu = stats.ep.relu;
+      stats.ep = stats.twin.ep, stats.ep.eps = eps, stats.ep.relu = relu;
+    }
   }
   constexpr int S = KT * CB;
   constexpr int D = S >= GPN_DIRECT_D ? GPN_DIRECT_D : S;  // prefetch depth in stages
@@ -425,6 +431,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
   // store; BatchNorm column sums of the tile when the launch carries a slab (bn_stats.h)
   const bool st_fwd = stats.slab != nullptr && stats.x == nullptr;
   double s0 = 0.0, s1 = 0.0;
+  gpn::AffineCol ac;
+  if constexpr (EP) ac = gpn::affine_col(stats.ep, col);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + 4 * g + r;
@@ -432,6 +440,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_direct_kernel(const float* __r
       const uint32_t e = (uint32_t)orow[r] * (uint32_t)cout + col;
       float v = acc[r];
       if (accumulate) v += out[e];  // (a second gradient of the same rows, added in place)
+      if constexpr (EP) v = gpn::affine_apply(stats.ep, ac, v, e);  // an inference pass's BatchNorm [+ residual] [+ ReLU]
       out[e] = v;
       if (st_fwd) {
         s0 += (double)v;
@@ -672,20 +681,18 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(const float* __re
 // (profiles/r03_conv_split.txt, us per launch unsplit / 2-way / 4-way): 487 rows 192->96 48 / 18 / 11, 1.8k rows 160->80
 // 67 / 28 / 22, 6.9k rows 64->64 23.2 / 23.4 / 21.1, 25k rows 96->48 75 / 75 / 71, 80k rows 32->32 58.8 / 59.0 / 57.5: the
 // 4-way form never loses, the 2-way form never wins over it => 4-way for every layer the direct kernel takes.
-// env GPN_DIRECT_SPLIT4_UNITS / GPN_DIRECT_SPLIT2_UNITS, or gpn_spconv_direct_split().
+// gpn_spconv_direct_split() changes the thresholds (tests, measurements).
 constexpr int64_t kSplit4Units = 12000, kSplit2Units = 0;
-std::atomic<int64_t> g_split4_units{[] {
-  const char* e = getenv("GPN_DIRECT_SPLIT4_UNITS");
-  return (int64_t)(e ? atoll(e) : kSplit4Units);
-}()};
-std::atomic<int64_t> g_split2_units{[] {
-  const char* e = getenv("GPN_DIRECT_SPLIT2_UNITS");
-  return (int64_t)(e ? atoll(e) : kSplit2Units);
-}()};
+std::atomic<int64_t> g_split4_units{kSplit4Units};
+std::atomic<int64_t> g_split2_units{kSplit2Units};
 
 template <int KT, int CB, int SP>
 int launch_split(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int64_t n_dst, int nt_total,
                  int accumulate, const gpn::ConvStats& stats, float* out, hipStream_t stream, const gpn::DevRows& rows) {
+  if (stats.ep.mean) {
+    gpn::set_error("gpn_spconv_fwd: the direct kernel's tap-split form has no BatchNorm epilogue");
+    return GPN_ERR_ARG;
+  }
   const int64_t units = gpn::cdiv(n_dst, 16) * nt_total;
   const int64_t plan_units = gpn::cdiv(gpn::plan_rows(n_dst, rows), 16) * nt_total;
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
@@ -713,11 +720,27 @@ int launch_direct(const float* in, const float* packed, const int32_t* nbr, cons
   }
   const size_t packed_bytes = (size_t)KT * CB * nt_total * 1024;
   const dim3 grid(gpn::dev_grid(gpn::cdiv(units, 4), gpn::cdiv(plan_units, 4), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1);
+  if constexpr (KT == 1) {
+    if (stats.ep.mean) {  // (an inference pass: the BatchNorm behind the k = 1 conv in the epilogue)
+      if (rows.dev)
+        hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB, true, true>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
+                           packed_bytes, perm, accumulate, stats, out, rows.dev);
+      else
+        hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB, false, true>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
+                           packed_bytes, perm, accumulate, stats, out, rows.dev);
+      GPN_CHECK_LAUNCH();
+      return GPN_OK;
+    }
+  }
+  if (stats.ep.mean) {
+    gpn::set_error("gpn_spconv_fwd: the direct kernel applies a BatchNorm in its epilogue for k = 1 layers only");
+    return GPN_ERR_ARG;
+  }
   if (rows.dev)
-    hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB, true>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
+    hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB, true, false>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
                        packed_bytes, perm, accumulate, stats, out, rows.dev);
   else
-    hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB, false>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
+    hipLaunchKernelGGL((spconv_fwd_direct_kernel<KT, CB, false, false>), grid, dim3(256), 0, stream, in, packed, nbr, n_dst, nt_total, units,
                        packed_bytes, perm, accumulate, stats, out, rows.dev);
   GPN_CHECK_LAUNCH();
   return GPN_OK;
@@ -797,6 +820,16 @@ bool gpn::spconv_fwd_accumulates_stats(int K, int64_t n_dst, int cin, int cout) 
                        use_direct(K, n_dst, cin, cout));
 }
 
+// true if a conv of this shape runs on a kernel whose epilogue can apply a gpn::ConvAffine (an inference pass's BatchNorm): the
+// masked-tile and the masked tap-split kernel, and the direct kernel for k = 1
+bool gpn::spconv_fwd_applies_affine(int K, int64_t n_dst, int cin, int cout, const gpn::DevRows& rows) {
+  if (n_dst <= 0) return false;
+  const bool tiles = rows.dev ? (gpn::spconv_tiles_supported(K, n_dst, cin, cout) && gpn::spconv_tiles_supported(K, gpn::plan_rows(n_dst, rows), cin, cout))
+                              : gpn::spconv_tiles_supported(K, n_dst, cin, cout);
+  if (tiles || gpn::spconv_msplit_supported(K, n_dst, cin, cout)) return true;
+  return K == 1 && (rows.dev ? use_direct(K, std::max<int64_t>(n_dst, 256), cin, cout) : use_direct(K, n_dst, cin, cout));
+}
+
 // which kernel a layer takes when its row count is a device counter: decided from the host's plan (the layer must fit the
 // 32-bit offsets at its bound), never the lock-step kernel - that one sizes partial outputs from the row count
 static bool dev_rows_take_tiles(int K, int64_t n_bound, int64_t n_plan, int cin, int cout) {
@@ -841,8 +874,8 @@ int gpn::spconv_fwd_into(const float* in, const float* packed_w, const int32_t* 
     gpn::set_error("gpn_spconv_fwd: a layer whose row count is a device counter must fit the masked-tile / direct kernels (K = %d, %d -> %d channels)", K, cin, cout);
     return GPN_ERR_ARG;
   }
-  if (stats.slab || stats.twin.slab) {
-    gpn::set_error("gpn_spconv_fwd: this shape runs on a kernel without a BatchNorm-sum epilogue (see spconv_fwd_accumulates_stats)");
+  if (stats.slab || stats.twin.slab || stats.ep.mean) {
+    gpn::set_error("gpn_spconv_fwd: this shape runs on a kernel without a BatchNorm epilogue (see spconv_fwd_accumulates_stats / spconv_fwd_applies_affine)");
     return GPN_ERR_ARG;
   }
   if (stats.twin.in) {  // the lock-step kernel takes one problem per launch

@@ -74,8 +74,20 @@ constexpr int ms_ring_taps(int CB, int NT, int max_tp) {
   return st > max_tp ? max_tp : st;
 }
 
-template <int CB, int NT, int SP, bool DEV>
-__global__ __launch_bounds__(SP * 64) void spconv_msplit_kernel(const float* __restrict__ in, const float* __restrict__ packed,
+// waves per SIMD asked of the register allocator per instantiation: the shapes whose register count sits a few registers above an
+// allocation step (100 against 96 for 48 -> 48 channels with three column tiles per wave: 5 instead of 4 waves per SIMD for two
+// spilled dwords outside the tap loop).  GPN_MSPLIT_OCC_HINTS=0 builds without (measurement).
+#ifndef GPN_MSPLIT_OCC_HINTS
+#define GPN_MSPLIT_OCC_HINTS 1
+#endif
+constexpr int ms_occ(int CB, int NT, int SP, bool DEV) {
+  if (!GPN_MSPLIT_OCC_HINTS || DEV) return 1;
+  if (SP == 4 && CB == 3 && NT == 3) return 5;
+  return 1;
+}
+#define GPN_MSPLIT_OCC __attribute__((amdgpu_waves_per_eu(ms_occ(CB, NT, SP, DEV))))
+template <int CB, int NT, int SP, bool DEV, bool EP>
+__global__ __launch_bounds__(SP * 64) GPN_MSPLIT_OCC void spconv_msplit_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                                                 const int32_t* __restrict__ nbr, const int32_t* __restrict__ perm,
                                                                 int K, int64_t n_dst, int n_tiles, int n_units, int nt_total,
                                                                 int col_groups, size_t packed_bytes, int accumulate,
@@ -85,6 +97,11 @@ __global__ __launch_bounds__(SP * 64) void spconv_msplit_kernel(const float* __r
     in = stats.twin.in, packed = stats.twin.packed, out = stats.twin.out;
     stats.slab = stats.twin.slab, stats.x = stats.twin.x, stats.y = stats.twin.y, stats.mean = stats.twin.mean,
     stats.invstd = stats.twin.invstd;
+    if constexpr (EP) {
+      const float eps = stats.ep.eps;
+      const int relu = stats.ep.relu;
+      stats.ep = stats.twin.ep, stats.ep.eps = eps, stats.ep.relu = relu;
+    }
   }
   constexpr int MAXTP = (kMaxTaps + SP - 1) / SP;  // taps of a wave at K = 27
   constexpr int NI = (MAXTP + 3) / 4;              // table loads of the prologue (4 taps x 16 rows each)
@@ -290,12 +307,15 @@ __global__ __launch_bounds__(SP * 64) void spconv_msplit_kernel(const float* __r
       for (int q = 1; q < SP; ++q) v4 += red[q][nt][lane];
       const uint32_t col = (uint32_t)((nt0 + nt) * 16 + i16);
       double s0 = 0.0, s1 = 0.0;
+      gpn::AffineCol ac;
+      if constexpr (EP) ac = gpn::affine_col(stats.ep, col);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if ((int64_t)tile * 16 + 4 * g + r < n_dst) {
           const uint32_t e = (uint32_t)orow[r] * (uint32_t)cout + col;
           float v = v4[r];
           if (accumulate) v += out[e];  // (a second gradient of the same rows, added in place)
+          if constexpr (EP) v = gpn::affine_apply(stats.ep, ac, v, e);  // an inference pass's BatchNorm [+ residual] [+ ReLU]
           out[e] = v;
           if (st_fwd) {
             s0 += (double)v;
@@ -343,10 +363,7 @@ __global__ __launch_bounds__(SP * 64) void spconv_msplit_kernel(const float* __r
 
 // ---- selection ---------------------------------------------------------------------------------------------------------------------
 // mode: 0 = off (the direct kernel of spconv_fwd.hip keeps these layers), 1 = on.  force_nt / force_sp: 0 = the table below.
-std::atomic<int> g_mode{[] {
-  const char* e = getenv("GPN_CONV_MSPLIT");
-  return e ? atoi(e) : 1;
-}()};
+std::atomic<int> g_mode{1};
 std::atomic<int> g_force_nt{0}, g_force_sp{0};
 // layers of at least this many column tiles take nine waves per row tile.  Never, by measurement (profiles/r06_conv_msplit_sweep.txt:
 // nine waves of three taps lose to four waves of seven at every level, 27.4 against 21.7 us at 7k rows x 64 channels, 7.3 against
@@ -401,12 +418,17 @@ int launch_msplit(const float* in, const float* packed, const int32_t* nbr, cons
   const int64_t plan_units = gpn::cdiv(gpn::plan_rows(n_dst, rows), 16) * col_groups;
   const size_t packed_bytes = (size_t)K * CB * nt_total * 1024;
   const dim3 grid(gpn::dev_grid(n_units, plan_units, rows.dev != nullptr, 8, 512), stats.twin.in ? 2 : 1);
-  if (rows.dev)
-    hipLaunchKernelGGL((spconv_msplit_kernel<CB, NT, SP, true>), grid, dim3(SP * 64), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
-                       n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev);
-  else
-    hipLaunchKernelGGL((spconv_msplit_kernel<CB, NT, SP, false>), grid, dim3(SP * 64), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
-                       n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev);
+#define GPN_MS_LAUNCH(DEVV, EPV)                                                                                                      \
+  hipLaunchKernelGGL((spconv_msplit_kernel<CB, NT, SP, DEVV, EPV>), grid, dim3(SP * 64), 0, stream, in, packed, nbr, perm, K, n_dst, \
+                     n_tiles, n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev)
+  if (stats.ep.mean) {  // (an inference pass: the BatchNorm behind the conv in the epilogue)
+    if (rows.dev) GPN_MS_LAUNCH(true, true);
+    else GPN_MS_LAUNCH(false, true);
+  } else {
+    if (rows.dev) GPN_MS_LAUNCH(true, false);
+    else GPN_MS_LAUNCH(false, false);
+  }
+#undef GPN_MS_LAUNCH
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }

@@ -98,7 +98,7 @@ constexpr int cfg_slots(int CB, int R, int NT) {  // operand slots of the tap lo
 
 // DEV = false: one unit per wave, the grid is exactly the launch (straight-line).  DEV = true: the row count is a device
 // counter (gpn::DevRows: n_dst is the buffers' bound, the grid a guess) and the waves walk the units of their XCD's eighth.
-template <int CB, int NT, int R, bool DEV>
+template <int CB, int NT, int R, bool DEV, bool EP>
 __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restrict__ in, const float* __restrict__ packed,
                                                            const int32_t* __restrict__ nbr, const int32_t* __restrict__ perm,
                                                            int K, int64_t n_dst, int n_tiles, int n_units, int nt_total,
@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
     in = stats.twin.in, packed = stats.twin.packed, out = stats.twin.out;
     stats.slab = stats.twin.slab, stats.x = stats.twin.x, stats.y = stats.twin.y, stats.mean = stats.twin.mean,
     stats.invstd = stats.twin.invstd;
+    if constexpr (EP) {
+      const float eps = stats.ep.eps;
+      const int relu = stats.ep.relu;
+      stats.ep = stats.twin.ep, stats.ep.eps = eps, stats.ep.relu = relu;
+    }
   }
   constexpr int RW = R * 16;        // rows of a wave
   constexpr int TPI = 64 / RW;      // taps covered by one table load of the prologue
@@ -374,12 +379,15 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
       for (int nt = 0; nt < NT; ++nt) {
         const uint32_t col = (uint32_t)((nt0 + nt) * 16 + i16);
         double s0 = 0.0, s1 = 0.0;
+        gpn::AffineCol ac;
+        if constexpr (EP) ac = gpn::affine_col(stats.ep, col);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if ((int64_t)tile * 16 + 4 * g + r < n_dst) {
             const uint32_t e = (uint32_t)orow[t][r] * (uint32_t)cout + col;
             float v = acc[t][nt][r];
             if (accumulate) v += out[e];  // (a second gradient of the same rows, added in place)
+            if constexpr (EP) v = gpn::affine_apply(stats.ep, ac, v, e);  // an inference pass's BatchNorm [+ residual] [+ ReLU]
             out[e] = v;
             if (st_fwd) {
               s0 += (double)v;
@@ -442,25 +450,9 @@ __global__ __launch_bounds__(256) void spconv_tiles_kernel(const float* __restri
   }
 }
 
-std::atomic<int64_t> g_min_tiles{[] {
-  const char* e = getenv("GPN_TILES_MIN_TILES");
-  return (int64_t)(e ? atoll(e) : 4096);
-}()};
+std::atomic<int64_t> g_min_tiles{4096};  // (gpn_spconv_tiles_min_tiles changes it: tests, measurements)
 
-int tiles_mode() {  // GPN_CONV_TILES=0: off (the direct kernel of spconv_fwd.hip runs instead; A/B switch for measurements)
-  static const int mode = [] {
-    const char* e = getenv("GPN_CONV_TILES");
-    return e ? atoi(e) : 1;
-  }();
-  return mode;
-}
-int min_waves() {  // a launch takes as many column tiles per wave as still leave this many waves
-  static const int v = [] {
-    const char* e = getenv("GPN_TILES_MIN_WAVES");
-    return e ? atoi(e) : 1536;
-  }();
-  return v;
-}
+constexpr int kMinWaves = 1536;  // a launch takes as many column tiles per wave as still leave this many waves
 
 template <int CB, int NT>
 int launch_tiles(const float* in, const float* packed, const int32_t* nbr, const int32_t* perm, int K, int64_t n_dst,
@@ -473,12 +465,17 @@ int launch_tiles(const float* in, const float* packed, const int32_t* nbr, const
   const int64_t plan_units = gpn::cdiv(gpn::cdiv(gpn::plan_rows(n_dst, rows), 16), R) * col_groups;
   const size_t packed_bytes = (size_t)K * CB * nt_total * 1024;
   const dim3 grid(gpn::dev_grid(gpn::cdiv(n_units, 4), gpn::cdiv(plan_units, 4), rows.dev != nullptr, 8), stats.twin.in ? 2 : 1);
-  if (rows.dev)
-    hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R, true>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
-                       n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev);
-  else
-    hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R, false>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles,
-                       n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev);
+#define GPN_TILES_LAUNCH(DEVV, EPV)                                                                                                   \
+  hipLaunchKernelGGL((spconv_tiles_kernel<CB, NT, R, DEVV, EPV>), grid, dim3(256), 0, stream, in, packed, nbr, perm, K, n_dst, n_tiles, \
+                     n_units, nt_total, col_groups, packed_bytes, accumulate, stats, out, rows.dev)
+  if (stats.ep.mean) {  // (an inference pass: the BatchNorm behind the conv in the epilogue)
+    if (rows.dev) GPN_TILES_LAUNCH(true, true);
+    else GPN_TILES_LAUNCH(false, true);
+  } else {
+    if (rows.dev) GPN_TILES_LAUNCH(true, false);
+    else GPN_TILES_LAUNCH(false, false);
+  }
+#undef GPN_TILES_LAUNCH
   GPN_CHECK_LAUNCH();
   return GPN_OK;
 }
@@ -492,7 +489,7 @@ int launch_tiles(const float* in, const float* packed, const int32_t* nbr, const
 // gives 512 waves), else one.
 int cols_per_wave(int64_t n_tiles, int nt_total) {
   for (int d = nt_total < 7 ? nt_total : 7; d >= 1; --d)
-    if (nt_total % d == 0 && n_tiles * (nt_total / d) >= min_waves()) return d;
+    if (nt_total % d == 0 && n_tiles * (nt_total / d) >= kMinWaves) return d;
   return (nt_total % 2 == 0 && n_tiles * (nt_total / 2) >= 512) ? 2 : 1;
 }
 
@@ -527,7 +524,6 @@ int dispatch_cols(int NT, const float* in, const float* packed, const int32_t* n
 namespace gpn {
 
 bool spconv_tiles_supported(int K, int64_t n_dst, int cin, int cout) {
-  if (tiles_mode() == 0) return false;
   if (!(K >= 1 && K <= kMaxTaps) || cin % 16 || cout % 16) return false;
   // 32-bit byte offsets: source rows (at most 8 n_dst of them, for a stride-2 conv), output rows, the neighbour table
   if (n_dst * (int64_t)8 * std::max(cin, cout) * 4 >= ((int64_t)1 << 31) || (int64_t)K * n_dst * 4 >= ((int64_t)1 << 31)) return false;
@@ -562,8 +558,8 @@ extern "C" int gpn_probe_tiles_trace(void* buf) {
 #endif
 
 // smallest layer (in 16-row tiles) the masked-tile kernel takes; smaller ones run on the direct / lock-step kernels of
-// spconv_fwd.hip.  min_tiles < 0 only queries.  Returns the previous value.  (Default 4096, env GPN_TILES_MIN_TILES; tests
-// and tools lower it to run the kernel on small inputs.)
+// spconv_fwd.hip.  min_tiles < 0 only queries.  Returns the previous value.  (Default 4096; tests and tools lower it to run the
+// kernel on small inputs, or raise it past every layer to keep the kernel away.)
 extern "C" int64_t gpn_spconv_tiles_min_tiles(int64_t min_tiles) {
   return min_tiles < 0 ? g_min_tiles.load(std::memory_order_relaxed) : g_min_tiles.exchange(min_tiles, std::memory_order_relaxed);
 }

@@ -126,8 +126,9 @@ def inst_info_batch(points: torch.Tensor, instance_labels: torch.Tensor, sem_lab
     return {"instance_regions": regions, "num_points_per_instance": npi, "instance_sem_labels": isl}
 
 
-# the fused preparation (csrc/sceneprep.hip) for scenes on the GPU; GPN_SCENE_PREPARE=0: the torch formulation below everywhere
-FUSED = os.environ.get("GPN_SCENE_PREPARE", "1") != "0"
+# the fused preparation (csrc/sceneprep.hip) for scenes on the GPU; False: the torch formulation below everywhere (what
+# tests/test_gpu_sceneprep.py compares it with)
+FUSED = True
 
 
 def scene_offsets(counts: Sequence[int], dev: torch.device) -> torch.Tensor:

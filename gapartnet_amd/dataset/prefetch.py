@@ -72,7 +72,7 @@ class DevicePrefetcher:
         # holding its kernels back until the backbone has run; from a packed cache 812 - 856 -> 690 - 720 point-clouds/s
         # (profiles/r05_findings.md): a second launching host thread beside the training thread costs more than the 1.3 ms of
         # preparation it takes off it, as round 4's Python worker did.
-        self.native = (os.environ.get("GPN_PREFETCH_NATIVE", "1") != "0") if native is None else native
+        self.native = True if native is None else bool(native)
 
     def _program(self):
         backbone = getattr(self.model, "backbone", None)

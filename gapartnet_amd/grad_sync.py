@@ -66,10 +66,9 @@ class GradSync:
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._buckets: Optional[List[List[int]]] = None
         self.stats = {"in_place": 0, "flattened": 0, "skipped": 0, "steps": 0, "host_ms": 0.0}
-        self._verify_always = os.environ.get("GPN_GRAD_SYNC_VERIFY") == "1"
         self._verified = {}  # id(program) -> [slice-by-slice walks of the whole-buffer shortcut done, on which buffer]
         # (gloo has no coalescing: its buckets go one call each, as before)
-        self._coalesce = self.backend == "nccl" and os.environ.get("GPN_GRAD_SYNC_NO_COALESCE") != "1"
+        self._coalesce = self.backend == "nccl"
 
     # ------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
@@ -104,7 +103,7 @@ class GradSync:
 
     # steps on which the whole-buffer shortcut is verified gradient by gradient (then it is trusted: the aliasing is a
     # property of how the step is written - zero_grad(set_to_none=True), no tied parameters, no gradient hooks - and does not
-    # change from step to step); GPN_GRAD_SYNC_VERIFY=1 keeps the full walk on every step
+    # change from step to step); a larger VERIFY_STEPS keeps the full walk for longer
     VERIFY_STEPS = 3
 
     def _executor_flat(self, prog, grads, total) -> Optional[torch.Tensor]:
@@ -125,7 +124,7 @@ class GradSync:
         seen = self._verified.setdefault(id(prog), [0, 0])  # [full walks done, base address they were done on]
         if seen[1] != base:
             seen[0], seen[1] = 0, base
-        if seen[0] < self.VERIFY_STEPS or self._verify_always:
+        if seen[0] < self.VERIFY_STEPS:
             seen[0] += 1
             ptr = base
             for g in grads:

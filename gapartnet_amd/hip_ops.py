@@ -364,8 +364,8 @@ import os as _os
 # and a permuted table per rulebook; levels below 4096 tiles run on the direct kernel and keep voxel order.
 # (round 4: also level 2 of the bench - 25k rows, direct / split kernel through `perm`: 8.17 / 8.23 / 8.14 -> 8.10 / 8.10 / 8.09 ms
 # per step in three interleaved same-box runs, profiles/r04_findings.md; 4096 gave nothing more)
-TILE_ORDER_MIN_ROWS = int(_os.environ.get("GPN_TILE_ORDER_MIN_ROWS", 16384))
-TILE_ORDER_BLOCK = int(_os.environ.get("GPN_TILE_ORDER_BLOCK", 16384))
+TILE_ORDER_MIN_ROWS = 16384  # (module attributes: tests and tools set them to order small inputs)
+TILE_ORDER_BLOCK = 16384
 
 
 def _with_tile_order(rb: "Rulebook") -> "Rulebook":
@@ -386,7 +386,6 @@ def tile_order(nbr, K, n):
     return perm, nbr_p
 
 
-_CHECK_LEVEL_COUNTS = _os.environ.get("GPN_CHECK_LEVEL_COUNTS") == "1"
 
 
 def rulebook_identity(n, device, rows_dev: Optional[DevCount] = None) -> Rulebook:
@@ -435,8 +434,6 @@ def rulebook_down(indices, spatial_shape, batch_size, n_out=None):
                               ptr(f2c), ptr(tap), ptr(nout), ptr(ws), szt(ws.numel()), _stream()),
           "gpn_rulebook_down")
     No = int(nout.item()) if n_out is None else int(n_out)
-    if n_out is not None and _CHECK_LEVEL_COUNTS:  # debug aid: the caller's count against the one this call computed (a host read)
-        assert int(nout.item()) == No, f"rulebook_down: caller passed n_out={No}, the level has {int(nout.item())} rows"
     cap = max(N, 1)
     fs = torch.empty((cap,), dtype=torch.int32, device=dev)
     fd = torch.empty((cap,), dtype=torch.int32, device=dev)

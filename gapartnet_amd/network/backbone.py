@@ -108,7 +108,7 @@ class SparseUNet(nn.Module):
             # unwritten rows behind it without any error
             raise RuntimeError("SparseUNet.forward: the input's row count is a device counter (sync-free proposal stage); that "
                                "form runs on the native layer-program executor only (use_native_executor, HIP backend, uniform "
-                               "BatchNorm training flags) - set GPN_PROPOSALS_SYNC=1 or model.sync_free_proposals = False")
+                               "BatchNorm training flags) - set model.sync_free_proposals = False")
         if self.stem is not None:
             x = self.stem(x)
         return self.ublock(x)

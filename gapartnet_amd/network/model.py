@@ -114,8 +114,8 @@ class GAPartNet(LightningModule):
         # Training steps issue the proposal stage and everything behind it WITHOUT reading its sizes back (include/gpn.h section
         # DEV): buffers at their bounds, counts on the device, the previous step's counts (copied to pinned memory, taken over
         # without waiting) as the plan that sizes grids.  The first step of a run - no plan yet - and evaluation steps read the
-        # counts as before.  GPN_PROPOSALS_SYNC=1 (or the attribute) restores the blocking read for every step.
-        self.sync_free_proposals = os.environ.get("GPN_PROPOSALS_SYNC", "0") != "1"
+        # counts as before.  The attribute set to False restores the blocking read for every step (tests/test_gpu_sync_free.py).
+        self.sync_free_proposals = True
         self._prop_plan = None       # [Q, M, P, V, dropped, runs, coarse] of the latest step whose counts have arrived
         self._prop_pending = []      # (pinned int64 [8], event) of counts still on their way
         self._prop_hist = []         # the last few plans (floor of the next one: a step without proposals must not shrink the grids)
@@ -414,8 +414,9 @@ class GAPartNet(LightningModule):
     # ScoreNet and NPCS-Net read the same proposal grid and have the same structure: with both switched on, their U-Nets run
     # as PAIRED passes of the native executor (network/net_exec.run_pair: layer i of both networks in one launch per kernel,
     # forward and backward) - same values as one after the other, half the launches of a part of the step where the GPU
-    # waits for the host to issue them.  GPN_NET_PAIR=0 runs them one after the other.
-    pair_proposal_unets = os.environ.get("GPN_NET_PAIR", "1") != "0"
+    # waits for the host to issue them.  The attribute set to False runs them one after the other
+    # (tests/test_gpu_model.py::test_paired_passes_equal_one_network_after_the_other).
+    pair_proposal_unets = True
 
     def forward_proposal_unets(self, voxel_tensor: spconv.SparseConvTensor):
         """(score_unet(x), npcs_unet(x)) in paired passes, or None where that form does not apply"""

@@ -415,7 +415,7 @@ class NetProgram:
             if self.retired_in_a_row == 8:
                 print("[gapartnet_amd] the persistent gradient buffer of a U-Net was replaced on 8 backward passes in a row: "
                       "nobody acknowledges its gradients - call gapartnet_amd.network.net_exec.release_gradients(model) "
-                      "after optimizer.step() (FusedAdam and the Trainer do), or set GPN_NET_AUTOGRAD_PARAMS=1")
+                      "after optimizer.step() (FusedAdam and the Trainer do), or call net_exec.set_autograd_parameters(True)")
         else:
             self.retired_in_a_row = 0
         self.grad_generation += 1
@@ -481,10 +481,10 @@ def _call(fn_name, prog, slots, rb_table, conv_table, bn_table, extra, device):
 #   acknowledgement: NetProgram.release_gradients, see grad_buffer; FusedAdam / the Trainer give it) - a reference kept past
 #   that point sees the next step's gradients, as a ``.grad`` kept past ``zero_grad(set_to_none=False)`` does; (4) parameters with ``requires_grad=False`` get
 #   no gradient and their weight-gradient launches are skipped.  GradSync and FusedAdam build on the flat buffer.
-#   autograd form - ``GPN_NET_AUTOGRAD_PARAMS=1`` or ``set_autograd_parameters(True)``: parameters are autograd inputs,
+#   autograd form - ``set_autograd_parameters(True)``: parameters are autograd inputs,
 #   gradients come back through AccumulateGrad like any other op's (everything of (1)-(2) works; ~3 ms of host time per
 #   training step for the three U-Nets, and no in-place gradient exchange).
-_AUTOGRAD_PARAMS = os.environ.get("GPN_NET_AUTOGRAD_PARAMS") == "1"
+_AUTOGRAD_PARAMS = False
 
 
 def set_autograd_parameters(on: bool) -> bool:
@@ -552,11 +552,23 @@ def _log_forward(prog, rb_objs):
             GF._log(rb, conv.in_channels, conv.out_channels, "fwd")
 
 
+NET_INFERENCE = 2  # include/gpn.h GPN_NET_INFERENCE
+
+
+def _forward_mode(ctx, training) -> int:
+    """gpn_net_forward's `training` argument: 1 = batch statistics; 0 = running statistics; GPN_NET_INFERENCE = running statistics
+    and no backward pass will follow (the op was applied with gradients disabled: autograd asks for no input gradient) - the
+    library then applies every conv's BatchNorm in the conv launch (no BatchNorm launches; the conv's own output is not kept)"""
+    if training:
+        return 1
+    return 0 if any(ctx.needs_input_grad) else NET_INFERENCE
+
+
 def _forward_impl(ctx, features, prog: NetProgram, rt, training):
     rows, rb_table, rb_objs, lvl_dev = rt
     features = features.contiguous()
     out, state = _forward_tables(features, prog, rows, lvl_dev)
-    _call("gpn_net_forward", prog, state[3], rb_table, state[4], state[5], (1 if training else 0,), features.device)
+    _call("gpn_net_forward", prog, state[3], rb_table, state[4], state[5], (_forward_mode(ctx, training),), features.device)
     _log_forward(prog, rb_objs)
     ctx.prog, ctx.rt, ctx.training = prog, rt, training
     ctx.state = state
@@ -673,7 +685,7 @@ class _NetPairFn(torch.autograd.Function):
         out_a, state_a = _forward_tables(features, prog_a, rows, lvl_dev)
         out_b, state_b = _forward_tables(features, prog_b, rows, lvl_dev)
         _call_pair("gpn_net_forward_pair", prog_a, state_a[3], state_b[3], rb_table, state_a[4], state_b[4], state_a[5],
-                   state_b[5], (1 if training else 0,), features.device)
+                   state_b[5], (_forward_mode(ctx, training),), features.device)
         _log_forward(prog_a, rb_objs)
         _log_forward(prog_b, rb_objs)
         ctx.progs, ctx.rt, ctx.training = (prog_a, prog_b), rt, training
@@ -719,7 +731,7 @@ class _NetPairFn(torch.autograd.Function):
 
 
 class _NetFnAutograd(torch.autograd.Function):
-    """the same program with its parameters as autograd inputs (``set_autograd_parameters(True)``, GPN_NET_AUTOGRAD_PARAMS=1,
+    """the same program with its parameters as autograd inputs (``set_autograd_parameters(True)``,
     or any parameter carrying a tensor hook): gradients are returned to autograd from a private buffer, so
     ``torch.autograd.grad``, ``backward(inputs=...)``, hooks and retained gradients behave as for any other op."""
 

@@ -267,8 +267,12 @@ int gpn_scatter_rows_csr(const float* dout, const int32_t* order, const int32_t*
  *   conv     : weight in parameter layout [Cout][K][Cin] (GPN_LAYOUT_OKI) and where its gradient goes
  *   bn       : BatchNorm1d parameters / running stats / saved batch stats / gradients
  *   op       : CONV dst = conv(src0)        | BN dst = act(bn(src0) [+ src1])   | CONCAT dst = [src0 | src1]
- * forward: training != 0 uses batch statistics (saved into save_mean / save_invstd, running stats updated);
- *          training == 0 uses the running statistics (save_invstd receives 1/sqrt(var+eps)).
+ * forward: training == 1 uses batch statistics (saved into save_mean / save_invstd, running stats updated);
+ *          training == 0 uses the running statistics (save_invstd receives 1/sqrt(var+eps));
+ *          training == GPN_NET_INFERENCE (round 6): running statistics, and the caller promises that NO backward pass follows -
+ *          every BatchNorm that directly follows a conv is then applied in that conv launch's epilogue (same arithmetic per
+ *          element, bit-equal outputs; the conv's own output slot and save_invstd stay unwritten): a validation step of the
+ *          full model has no BatchNorm launch left but the proposal networks' first one (network/backbone.py:40-49).
  * backward: slots[].grad of the final slot holds d(loss)/d(output); slots[].grad_state must be 0 everywhere except
  *          slots that already hold a gradient (1).  Gradients of multiply-consumed slots are summed in program order
  *          (reverse), so results are deterministic.  need_input_grad = 0 skips d/d(slot 0). */
@@ -327,6 +331,7 @@ typedef struct gpn_net_bn {
 #define GPN_NET_BN 1
 #define GPN_NET_CONCAT 2
 #define GPN_NET_RELU 1 /* op.flags, BN only */
+#define GPN_NET_INFERENCE 2 /* gpn_net_forward(_pair)'s `training`: eval mode without a backward pass to follow (see above) */
 typedef struct gpn_net_op {
   int32_t kind;
   int32_t src0;

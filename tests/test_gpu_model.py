@@ -495,6 +495,28 @@ def test_two_rank_bench_shares_one_device(cuda, launcher):
 
 
 @pytest.mark.gpu
+def test_bench_with_the_gradient_exchange_forced_on_one_rank(cuda):
+    """GPN_BENCH_FORCE_GRAD_SYNC=1 (one of the three environment switches left, with GPN_DIST_SHARE_DEVICE and GPN_NO_PIN): bench.py
+    brings up a ONE-rank RCCL group and runs the gradient exchange of the multi-GPU path on it - the executor's flat gradient
+    buffers all-reduced in place by the collective library the 8-GPU run uses"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPN_BENCH_FORCE_GRAD_SYNC="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--points", "6000", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["distributed"]["world_size"] == 1 and res["distributed"]["backend"] == "nccl"
+    ex = res["grad_exchange"]
+    assert ex["backend"] == "nccl" and ex["steps"] == 5 and ex["in_place"] >= ex["steps"], ex
+
+
+@pytest.mark.gpu
 def test_training_step_without_any_proposal(cuda):
     """every point predicted as background: clustering has nothing to cluster, the proposal nets do not run, the step
     still produces a finite loss and gradients for the backbone and the point heads only"""
@@ -707,6 +729,100 @@ def test_fused_adam_tensors_that_sit_out_steps_keep_their_own_step_count(cuda):
     for p, q in zip(a, b):
         assert float(opt_a.state[p]["step"]) == float(opt_b.state[q]["step"])
         assert torch.allclose(p, q, rtol=1e-6, atol=2e-7), float((p - q).abs().max())
+
+
+def _bn_launches(lib):
+    import ctypes
+    launches, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    assert lib.gpn_prof_get(6, ctypes.byref(launches), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)) == 0  # GPN_K_BN
+    return int(launches.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("without_stem", [False, True])
+def test_inference_pass_applies_batchnorm_in_the_conv_epilogue(cuda, without_stem):
+    """(round 6) eval mode without a backward pass to follow (GPN_NET_INFERENCE: the executor called with gradients disabled):
+    every BatchNorm behind a conv is applied by that conv's launch - the arithmetic of the stand-alone eval pass per element, so
+    the output is BIT-equal to the eval pass with gradients enabled (which keeps its BatchNorm launches for the backward pass),
+    and the pass has no BatchNorm launch left but a stem norm that follows no conv.  Single and paired passes, masked-tile,
+    masked tap-split and k = 1 kernels (the shortcut convs of the decoder blocks)."""
+    from gapartnet_amd import _C
+    from gapartnet_amd.network import net_exec
+    lib = _C.lib()
+    net, idx, feats, spconv = _unet_case(cuda, without_stem)
+    twin = copy.deepcopy(net)
+    with torch.no_grad():
+        for m in list(net.modules()) + list(twin.modules()):  # non-trivial running statistics and affine parameters
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0.0, 0.3)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0.0, 0.2)
+        for p in twin.parameters():
+            p.mul_(0.7)
+    net.eval(), twin.eval()
+    prev_tiles = lib.gpn_spconv_tiles_min_tiles(256)  # (the largest level of this case on the masked-tile kernel)
+    try:
+        def run(no_grad):
+            lib.gpn_prof_reset(); lib.gpn_prof_enable(1)
+            ctx = torch.no_grad() if no_grad else torch.enable_grad()
+            with ctx:
+                y = net(spconv.SparseConvTensor(feats.clone(), idx, [64, 64, 64], 3)).features
+                single_bn = _bn_launches(lib)
+                lib.gpn_prof_reset()
+                pair = net_exec.run_pair(net, twin, spconv.SparseConvTensor(feats.clone(), idx, [64, 64, 64], 3))
+            torch.cuda.synchronize()
+            pair_bn = _bn_launches(lib)
+            lib.gpn_prof_enable(0)
+            return y.detach(), pair[0].features.detach(), pair[1].features.detach(), single_bn, pair_bn
+
+        y0, a0, b0, n0, m0 = run(False)
+        y1, a1, b1, n1, m1 = run(True)
+    finally:
+        lib.gpn_spconv_tiles_min_tiles(prev_tiles)
+        lib.gpn_prof_enable(0)
+    n_bn = sum(isinstance(m, torch.nn.BatchNorm1d) for m in net.modules())
+    assert n0 == n_bn and m0 == n_bn, (n0, m0, n_bn)                 # eval with a backward to come: a launch per BatchNorm (pair: per pair)
+    assert n1 == (1 if without_stem else 0) and m1 == n1, (n1, m1)   # inference: only a BatchNorm that follows no conv
+    assert torch.equal(y0, y1) and torch.equal(a0, a1) and torch.equal(b0, b1)
+    assert torch.equal(y0, a0), "the pair's first network is the single pass's"
+
+
+def test_gated_adam_counts_skips_per_table(cuda):
+    """(round 6) gated tensors that started at different times - training_schedule [5, 10]: ScoreNet's from epoch 5,
+    NPCS-Net's from epoch 10 - are two device tables; a step the gate suppresses must count ONCE for each, and only against
+    tensors that had started (one shared counter counted it twice and charged it to both).  Against torch.optim.Adam with
+    ``grad = None`` on the suppressed steps (what the reference does on a batch without proposals)."""
+    from gapartnet_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(7)
+    base = [torch.randn(s, generator=g).to(cuda) for s in [(32, 27, 16), (200,), (16, 16), (48,)]]
+    a = [torch.nn.Parameter(t.clone()) for t in base]  # a[0] ungated (backbone), a[1] early gated, a[2], a[3] late gated
+    b = [torch.nn.Parameter(t.clone()) for t in base]
+    opt_a = FusedAdam(a, lr=1e-2)
+    opt_b = torch.optim.Adam(b, lr=1e-2, foreach=False, fused=False)
+    gate = torch.ones((2,), dtype=torch.int64, device=cuda)
+    opt_a.set_gate(a[1:], lambda: (gate, 1))
+    closed_steps = (3, 4, 8)
+    for step in range(11):
+        started = [True, True, step >= 2, step >= 2]
+        gate[1] = 0 if step in closed_steps else 1
+        for i, (p, q) in enumerate(zip(a, b)):
+            if not started[i]:
+                p.grad = q.grad = None
+                continue
+            grad = torch.randn(p.shape, generator=g).to(cuda)
+            # the device-counted step hands the gated tensors a (zero) gradient although nothing ran; the reference leaves None
+            p.grad = grad.clone() if (i == 0 or step not in closed_steps) else torch.zeros_like(p)
+            q.grad = grad.clone() if (i == 0 or step not in closed_steps) else None
+        opt_a.step()
+        opt_b.step()
+        if step == 6:
+            opt_a.state_dict()  # (a checkpoint in the middle: the counters are folded into the host counts and start again)
+    opt_a.state_dict()
+    for i, (p, q) in enumerate(zip(a, b)):
+        assert float(opt_a.state[p]["step"]) == float(opt_b.state[q]["step"]), (i, float(opt_a.state[p]["step"]), float(opt_b.state[q]["step"]))
+        assert torch.allclose(p, q, rtol=1e-6, atol=2e-7), (i, float((p - q).abs().max()))
+        assert torch.allclose(opt_a.state[p]["exp_avg"], opt_b.state[q]["exp_avg"], rtol=1e-6, atol=1e-7), i
 
 
 def test_grouped_weight_gradient_contractions_are_bit_equal(cuda):

@@ -27,7 +27,13 @@ def main():
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--steps", type=int, default=12, help="validation steps per loader and epoch")
     ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--lib-knobs", type=str, default="", help="see bench.py (e.g. bn_fusion=0: BatchNorm launches instead of conv epilogues)")
     args = ap.parse_args()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpn_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    bench.apply_lib_knobs(args.lib_knobs)
     from gapartnet_amd.dataset.prefetch import DevicePrefetcher
     from gapartnet_amd.smoke import make_batch, make_model
     from tests.golden import recipe

@@ -7,7 +7,7 @@ cat, cnt = defaultdict(float), defaultdict(int)
 
 
 def c(n):
-    if 'spconv_fwd' in n or 'spconv_tiles' in n: return 'conv fwd/dgrad'
+    if 'spconv_fwd' in n or 'spconv_tiles' in n or 'spconv_msplit' in n: return 'conv fwd/dgrad'
     if 'tile_order' in n: return 'voxelize/rulebook'
     if 'wgrad' in n: return 'wgrad (+reduce)'
     if 'bn_' in n: return 'batchnorm'

@@ -20,6 +20,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_$c.txt" 2>&1 < /dev/null; fi
 done
 f1=$O/pmc_FETCH_SIZE.txt; f2=$O/pmc_WRITE_SIZE.txt
-if [ -s "$f1" ] && [ -s "$f2" ]; then (cd "$R" && python tools/pmc_traffic.py "$f1" "$f2" "$O/traffic.json" spconv_fwd,spconv_tiles > /dev/null 2>&1); fi
+if [ -s "$f1" ] && [ -s "$f2" ]; then (cd "$R" && python tools/pmc_traffic.py "$f1" "$f2" "$O/traffic.json" spconv_fwd,spconv_tiles,spconv_msplit > /dev/null 2>&1); fi
 cat "$O/gpu_time_by_category.txt" | tail -3; cat "$O/traffic.json" | grep fingerprint
 timeout 40 python -m pytest "$R/tests" -m gpu -q -x -k "paired_passes or native_executor" 2>&1 < /dev/null | tail -1

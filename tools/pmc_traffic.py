@@ -22,7 +22,7 @@ def aggregate(path, prefix):
 
 
 fetch_path, write_path, out = sys.argv[1], sys.argv[2], sys.argv[3]
-prefix = sys.argv[4] if len(sys.argv) > 4 else "spconv_fwd,spconv_tiles"  # comma-separated kernel-name prefixes
+prefix = sys.argv[4] if len(sys.argv) > 4 else "spconv_fwd,spconv_tiles,spconv_msplit"  # comma-separated kernel-name prefixes
 f, n = aggregate(fetch_path, prefix)
 w, n2 = aggregate(write_path, prefix)
 res = {"kernel_prefix": prefix, "launches_profiled": n,

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def category(n):
-    if 'spconv_fwd' in n or 'spconv_tiles' in n: return 'conv fwd/dgrad'
+    if 'spconv_fwd' in n or 'spconv_tiles' in n or 'spconv_msplit' in n: return 'conv fwd/dgrad'
     if 'wgrad' in n: return 'wgrad (+reduce)'
     if 'bn_' in n: return 'batchnorm'
     return None
