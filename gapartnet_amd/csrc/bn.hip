@@ -774,6 +774,7 @@ int gpn::bn_fwd_eval_running(const gpn::BnFwdPtrs& pa, const gpn::BnFwdPtrs* pb,
   GPN_CHECK_ARG(pa.x && pa.weight && pa.bias && pa.running_mean && pa.running_var && pa.y);
   if (pb) GPN_CHECK_ARG(pb->x && pb->weight && pb->bias && pb->running_mean && pb->running_var && pb->y);
   const int64_t total4 = N * (C / 4);
+  gpn::ProfScope prof(GPN_K_BN, stream, 0.0, 4.0 * (double)N * C * (pa.res ? 3 : 2) * (pb ? 2 : 1), rows.dev, N);  // x [+ res] read, y written
   hipLaunchKernelGGL(bn_apply_eval_kernel, dim3(apply_grid(gpn::plan_rows(N, rows) * (C / 4)), pb ? 2 : 1), dim3(kThreads), 0, stream,
                      pa, pb ? *pb : pa, total4, C / 4, eps, relu, rows.dev);
   GPN_CHECK_LAUNCH();

@@ -52,6 +52,10 @@ struct LdsPitch {  // floats per LDS row for W payload floats: pitch % 64 in {16
   static constexpr int value = (W % 64 == 16 || W % 64 == 48) ? W : ((W + 16) % 64 == 16 || (W + 16) % 64 == 48) ? W + 16 : W + 32;
 };
 
+// (Round 6 measured TWO tiles of rows in flight per workgroup - a second register set, indices through a ring of four LDS slots,
+// bit-equal results: slower, 21.9 -> 23.3 us per 16 -> 16 layer at 136k rows, 35.8 -> 38.5 at 32 -> 32, 7.65 - 7.67 -> 7.68 - 7.70 ms
+// per step in three interleaved pairs, profiles/r06_findings.md: the extra 4 (CT + NT) registers cost more residency than the
+// longer prefetch gains.)
 template <int CT, int NT>
 __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
     const gpn::WgradSets sets, int64_t n_tiles, int cin, int K, int S, int cigs, int n_z, int dealt, const int64_t* __restrict__ n_dst_dev) {

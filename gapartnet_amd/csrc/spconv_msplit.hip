@@ -50,6 +50,10 @@ constexpr int kMaxTaps = 27;
 __device__ unsigned long long* g_msplit_trace = nullptr;  // [waves][10]
 #endif
 // operand registers of the tap ring (the ring holds as many tap slots as fit, at least two)
+// GPN_MSPLIT_ABL (measurement builds, wrong results by design): see the two uses in the tap loop
+#ifndef GPN_MSPLIT_ABL
+#define GPN_MSPLIT_ABL 0
+#endif
 #ifndef GPN_MSPLIT_OPERAND_REGS
 #define GPN_MSPLIT_OPERAND_REGS 48
 #endif
@@ -236,6 +240,12 @@ __global__ __launch_bounds__(SP * 64) GPN_MSPLIT_OCC void spconv_msplit_kernel(c
       to_issue -= 1, issued += 1;
       cur_woff = has ? (uint32_t)(k * CB * nt_total + nt0) * 1024u : 0x7ffffc00u - (uint32_t)(CB * nt_total) * 1024u;
       cur_ao = (has ? slab[wave][ls][i16] : kOob) + g16;  // (kOob + g16 stays out of range)
+#if GPN_MSPLIT_ABL & 1  // measurement build: every tap reads tap 0's weight fragments (the weight traffic stays in the L1s)
+      if (has) cur_woff = (uint32_t)nt0 * 1024u;
+#endif
+#if GPN_MSPLIT_ABL & 2  // measurement build: every tap gathers the tile's own rows (no scattered row reads)
+      if (has) cur_ao = (uint32_t)(tile * 16 + i16) * (uint32_t)(cin * 4) + g16;
+#endif
     }
     ra[sl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)cur_ao, cb * 64, 0));
 #pragma unroll

@@ -555,20 +555,32 @@ def _log_forward(prog, rb_objs):
 NET_INFERENCE = 2  # include/gpn.h GPN_NET_INFERENCE
 
 
-def _forward_mode(ctx, training) -> int:
-    """gpn_net_forward's `training` argument: 1 = batch statistics; 0 = running statistics; GPN_NET_INFERENCE = running statistics
-    and no backward pass will follow (the op was applied with gradients disabled: autograd asks for no input gradient) - the
-    library then applies every conv's BatchNorm in the conv launch (no BatchNorm launches; the conv's own output is not kept)"""
+class _Mode(int):
+    """the ``training`` argument of the executor ops: truthy = batch statistics (1); falsy = running statistics - 0, or the
+    INFERENCE form of 0 (``inference`` set) when the op was applied with gradients disabled, i.e. no backward pass can follow:
+    gpn_net_forward is then called with GPN_NET_INFERENCE and applies every conv's BatchNorm in the conv launch (no BatchNorm
+    launches; the conv's own output is not kept).  Decided by the CALLER of ``apply`` (inside ``forward`` autograd has always
+    switched gradients off, and ``needs_input_grad`` reports the inputs' flags whatever the mode)."""
+    inference = False
+
+
+def _mode(training: bool) -> "_Mode":
+    m = _Mode(1 if training else 0)
+    m.inference = (not training) and not torch.is_grad_enabled()
+    return m
+
+
+def _forward_mode(training) -> int:
     if training:
         return 1
-    return 0 if any(ctx.needs_input_grad) else NET_INFERENCE
+    return NET_INFERENCE if getattr(training, "inference", False) else 0
 
 
 def _forward_impl(ctx, features, prog: NetProgram, rt, training):
     rows, rb_table, rb_objs, lvl_dev = rt
     features = features.contiguous()
     out, state = _forward_tables(features, prog, rows, lvl_dev)
-    _call("gpn_net_forward", prog, state[3], rb_table, state[4], state[5], (_forward_mode(ctx, training),), features.device)
+    _call("gpn_net_forward", prog, state[3], rb_table, state[4], state[5], (_forward_mode(training),), features.device)
     _log_forward(prog, rb_objs)
     ctx.prog, ctx.rt, ctx.training = prog, rt, training
     ctx.state = state
@@ -685,7 +697,7 @@ class _NetPairFn(torch.autograd.Function):
         out_a, state_a = _forward_tables(features, prog_a, rows, lvl_dev)
         out_b, state_b = _forward_tables(features, prog_b, rows, lvl_dev)
         _call_pair("gpn_net_forward_pair", prog_a, state_a[3], state_b[3], rb_table, state_a[4], state_b[4], state_a[5],
-                   state_b[5], (_forward_mode(ctx, training),), features.device)
+                   state_b[5], (_forward_mode(training),), features.device)
         _log_forward(prog_a, rb_objs)
         _log_forward(prog_b, rb_objs)
         ctx.progs, ctx.rt, ctx.training = (prog_a, prog_b), rt, training
@@ -826,9 +838,9 @@ def run(unet, x):
             _count_batches(prog.buffers("num_batches_tracked"), x)
     params = prog.params()
     if _AUTOGRAD_PARAMS or any(_has_hooks(p) for p in params):
-        out = _NetFnAutograd.apply(x.features, prog, (rows, rb_table, rb_objs, lvl_dev), training, *params)
+        out = _NetFnAutograd.apply(x.features, prog, (rows, rb_table, rb_objs, lvl_dev), _mode(training), *params)
     else:
-        out = _NetFn.apply(x.features, prog._anchor, prog, (rows, rb_table, rb_objs, lvl_dev), training)
+        out = _NetFn.apply(x.features, prog._anchor, prog, (rows, rb_table, rb_objs, lvl_dev), _mode(training))
     lvl = prog.slot_level[prog.out_slot]
     idx, shape = levels[lvl]
     return _out_tensor(out, idx, shape, x, lvl_dev[lvl] if lvl_dev is not None else None)
@@ -864,7 +876,7 @@ def run_pair(unet_a, unet_b, x):
     if training:
         with torch.no_grad():
             _count_batches(prog_a.buffers("num_batches_tracked") + prog_b.buffers("num_batches_tracked"), x)
-    out_a, out_b = _NetPairFn.apply(x.features, prog_a._anchor, prog_a, prog_b, (rows, rb_table, rb_objs, lvl_dev), training)
+    out_a, out_b = _NetPairFn.apply(x.features, prog_a._anchor, prog_a, prog_b, (rows, rb_table, rb_objs, lvl_dev), _mode(training))
     lvl = prog_a.slot_level[prog_a.out_slot]
     idx, shape = levels[lvl]
     d = lvl_dev[lvl] if lvl_dev is not None else None

@@ -71,6 +71,54 @@ def test_two_rank_ddp_training(tmp_path, schedule):
     assert len(a) == 4 and len(b) == 4 and not (a & b), "ranks must train on disjoint scene shards"
 
 
+def _no_proposal_worker(rank, world, port, out_dir):
+    """rank 1 never has a proposal (its clustering keeps nothing), rank 0 always has: ScoreNet / NPCS-Net run on rank 0 only"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from gapartnet_amd import backend
+    from gapartnet_amd.dataset.gapartnet import GAPartNetInst
+    from gapartnet_amd.smoke import make_model
+    from gapartnet_amd.trainer import Trainer
+    from oracle import torch_ops
+    backend.use(torch_ops)
+    model = make_model((0, 0), channels=[16, 32], seed=0)
+    if rank == 1:
+        model.min_num_points_per_proposal = 10 ** 9  # (a per-rank setting, not a parameter: no cluster survives on this rank)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    runs = []
+    orig = model.score_unet.forward
+    model.score_unet.forward = lambda *a, **k: (runs.append(1), orig(*a, **k))[1]
+    dm = GAPartNetInst(root_dir="synthetic:12", max_points=1500, train_batch_size=2, val_batch_size=2, test_batch_size=2, num_workers=0)
+    trainer = Trainer(max_epochs=1, accelerator="cpu", limit_train_batches=3, enable_checkpointing=False, check_val_every_n_epoch=100,
+                      default_root_dir=out_dir)
+    trainer.fit(model, datamodule=dm, val_dataloaders=None)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    calls = [None] * world
+    dist.all_gather_object(calls, len(runs))
+    moved = {n: bool((p.detach() != before[n]).any()) for n, p in model.named_parameters()}
+    if rank == 0:
+        torch.save({"params_equal": bool(torch.equal(gathered[0], gathered[1])), "score_unet_calls": calls, "finite": bool(torch.isfinite(flat).all()),
+                    "score_moved": any(v for n, v in moved.items() if n.startswith("score_unet.")),
+                    "npcs_moved": any(v for n, v in moved.items() if n.startswith("npcs_unet."))}, os.path.join(out_dir, "noprop.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_without_proposals_for_three_steps(tmp_path):
+    """round-5 review: one rank has no proposal for three steps in a row while the other has some every step.  The rank without
+    skips ScoreNet / NPCS-Net (their gradients stay None there, the reference's behaviour on such a batch); the exchange must
+    count it in with zeros - every rank reduces the same buckets - and both ranks must end with the same parameters, the proposal
+    networks' included, which have moved."""
+    mp.spawn(_no_proposal_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "noprop.pt"), weights_only=False)
+    assert res["score_unet_calls"][0] == 3 and res["score_unet_calls"][1] == 0, res["score_unet_calls"]
+    assert res["params_equal"] and res["finite"], "ranks diverged"
+    assert res["score_moved"] and res["npcs_moved"], "the proposal networks must have been updated on both ranks"
+
+
 class _Toy(torch.nn.Module):
     def __init__(self):
         super().__init__()

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--steps", type=int, default=12, help="validation steps per loader and epoch")
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--lib-knobs", type=str, default="", help="see bench.py (e.g. bn_fusion=0: BatchNorm launches instead of conv epilogues)")
+    ap.add_argument("--ab-bn-fusion", action="store_true",
+                    help="alternate epochs with the BatchNorm in the conv epilogues (inference passes, round 6) and as launches of its "
+                         "own; reports the median step time of each")
     args = ap.parse_args()
     import importlib.util
     spec = importlib.util.spec_from_file_location("gpn_bench", os.path.join(ROOT, "bench.py"))
@@ -47,8 +50,12 @@ def main():
     pools = [[[pc.to(dev) for pc in make_batch(args.batch, args.points, seed0=2000 + 1000 * l + 10 * j)] for j in range(2)]
              for l in range(3)]
     step_ms, end_ms, kept = [], [], 0
+    by_mode = {0: [], 1: []}
+    from gapartnet_amd import _C
     with torch.no_grad():
-        for epoch in range(args.epochs + 1):  # epoch 0 warms up
+        for epoch in range((2 * args.epochs if args.ab_bn_fusion else args.epochs) + 1):  # epoch 0 warms up
+            if args.ab_bn_fusion:
+                _C.lib().gpn_net_bn_fusion(epoch % 2)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for l in range(3):
@@ -67,8 +74,15 @@ def main():
             if epoch > 0:
                 step_ms.append((t1 - t0) / (3 * args.steps) * 1e3)
                 end_ms.append((t2 - t1) * 1e3)
+                by_mode[epoch % 2].append(step_ms[-1])
     step_ms.sort(); end_ms.sort()
     ms = step_ms[len(step_ms) // 2]
+    if args.ab_bn_fusion:
+        _C.lib().gpn_net_bn_fusion(1)
+        med = lambda v: sorted(v)[len(v) // 2]
+        print(json.dumps({"ms_per_validation_step": {"batchnorm_in_conv_epilogues": med(by_mode[1]), "batchnorm_launches": med(by_mode[0])},
+                          "epochs_each": args.epochs, "all": by_mode, "batch": args.batch, "points": args.points}))
+        return
     print(json.dumps({"metric": "point-clouds/sec (20k pts, validation step, eval mode)", "value": args.batch / ms * 1e3,
                       "ms_per_validation_step": ms, "epoch_end_ms": end_ms[len(end_ms) // 2],
                       "steps_per_epoch": 3 * args.steps, "batch": args.batch, "points": args.points,

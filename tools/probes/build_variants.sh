@@ -13,8 +13,9 @@ for spec in "$@"; do
   ( objs=""; skip=""
     for f in ${files//,/ }; do
       b=${f%.hip}
+      vf=""; case $b in spconv_fwd|spconv_tiles|spconv_msplit) vf="-mllvm -amdgpu-mfma-vgpr-form=1";; esac  # (as csrc/Makefile)
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -Wno-unused-value \
-        -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c "$C/$f" -o "$O/${b}_$tag.o" 2>/dev/null
+        $vf "$@" -c "$C/$f" -o "$O/${b}_$tag.o" 2>/dev/null
       objs="$objs $O/${b}_$tag.o"; skip="$skip -e /$b.o"
     done
     rest=$(ls "$C"/_build/*.o | grep -v $skip)
