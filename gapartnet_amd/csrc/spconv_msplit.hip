@@ -427,6 +427,8 @@ int launch_msplit(const float* in, const float* packed, const int32_t* nbr, cons
   const int n_units = n_tiles * col_groups;
   const int64_t plan_units = gpn::cdiv(gpn::plan_rows(n_dst, rows), 16) * col_groups;
   const size_t packed_bytes = (size_t)K * CB * nt_total * 1024;
+  // (an exactly-sized launch as FEWER workgroups that walk the units - 512 ... 1536 workgroups for the 1575 row tiles of the
+  // 25k-row level, the device-counted form's loop: 29.3 - 35 us against 29.5, profiles/r06_conv_msplit_walk.txt - does not pay)
   const dim3 grid(gpn::dev_grid(n_units, plan_units, rows.dev != nullptr, 8, 512), stats.twin.in ? 2 : 1);
 #define GPN_MS_LAUNCH(DEVV, EPV)                                                                                                      \
   hipLaunchKernelGGL((spconv_msplit_kernel<CB, NT, SP, DEVV, EPV>), grid, dim3(SP * 64), 0, stream, in, packed, nbr, perm, K, n_dst, \
@@ -500,6 +502,7 @@ extern "C" int gpn_probe_msplit_trace(void* buf) {
 // the masked tap-split kernel on (1, default) / off (0: the direct kernel of spconv_fwd.hip takes its layers); mode < 0 leaves it.
 // force_nt / force_sp: column tiles per workgroup (1 - 4, must divide the layer's) and waves per row tile (4 or 9) for every layer
 // instead of the built-in table; 0 = the table; < 0 = unchanged.  Returns the previous mode.  (Measurement / test knob.)
+
 extern "C" int gpn_spconv_msplit(int mode, int force_nt, int force_sp) {
   const int prev = g_mode.load(std::memory_order_relaxed);
   if (mode >= 0) g_mode.store(mode ? 1 : 0, std::memory_order_relaxed);

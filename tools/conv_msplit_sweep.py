@@ -86,7 +86,6 @@ def sweep(label, tab, n_src, cin, cout):
             best = min(best, (t, f"nt{nt}/sp{sp}"))
     L.gpn_spconv_msplit(1, 0, 0)
     t_auto = timeit(lambda: conv_call(x, packed, tab, cin, cout, out))
-    flops = 2.0 * K * 0  # (pairs are not counted here: the table is what the kernels walk)
     print(f"{label:>22s} {cin:4d}->{cout:<4d} K={K:<2d} direct-split {t_old:6.1f} | auto {t_auto:6.1f} | best {best[1]} {best[0]:6.1f} | " + "  ".join(cells), flush=True)
 
 
