@@ -1,31 +1,35 @@
 // spconv_msplit.hip — the masked tap-split sparse convolution kernel (forward and dgrad launches) for gfx950 (round 6):
-// every layer BELOW the masked-tile kernel's 4096 row tiles - the U-Net's levels of 25k rows and fewer, the proposal networks.
+// every k = 27 / 8 layer BELOW the masked-tile kernel's 4096 row tiles - the U-Net's levels of 25k rows and fewer, the stride-2 /
+// inverse convs between them, the proposal networks (device-counted rows).
 //
-// Those levels were the direct kernel's (spconv_fwd.hip): one workgroup per (row tile, ONE column tile), its four waves each
+// Those layers were the direct kernel's (spconv_fwd.hip): one workgroup per (row tile, ONE column tile), its four waves each
 // walking a fixed quarter of the 27 taps - dead taps included, as requests that read zeros - with a four-stage operand ring,
-// the first wave adding the four accumulators.  What its launches are made of (tools/probes/msplit_trace.py):
-// a wave is ONE chain of dependent round trips - table entry, then (gathered row piece, weight fragment) per stage, four
-// stages in flight - and a level of a few hundred tiles gives a SIMD one or two such chains, so the launch lasts
-// (stages / 4) x (one L2 / HBM round trip): 14 us for 0.6 us of MFMA work at 489 rows x 96 channels.  At 25k rows the
-// same rows are gathered once per column tile by three different workgroups (different CUs) and every fourth ring slot is a
-// dead tap's.
+// the first wave adding the four accumulators and storing.  What such a launch is made of, wave by wave (tools/probes/
+// msplit_trace.py, profiles/r06_conv_trace_*.txt): at 25k rows x 48 channels four ROUNDS of waves (18 900 waves,
+// 4 400 slots), the same rows gathered by three workgroups on different CUs, every third ring slot a dead tap's; at 489 rows x 96
+// channels one wave per SIMD, a serial chain of 42 stages: 2.2 us of dependent MFMAs and the round trips of a four-stage ring.
 //
 // Here the work of a row tile is cut differently:
-//   * a workgroup owns ONE row tile and NT column tiles (all of them where the level has rows enough to fill the chip that way:
-//     a gathered row piece then feeds NT MFMA column tiles from registers, as in the masked-tile kernel); its SP waves (4, 7, 9
-//     or 14) own the taps [p TP, (p + 1) TP), TP = ceil(K / SP): chains of 2 - 7 taps instead of 27;
+//   * a workgroup owns ONE row tile and NT column tiles (the widest of 4 / 3 / 2 / 1 that leaves 384 workgroups: a gathered row
+//     piece then feeds NT MFMA column tiles from registers, as in the masked-tile kernel); its SP = 4 waves own the taps
+//     [p TP, (p + 1) TP), TP = ceil(K / SP) - the tap ranges of the direct kernel's 4-way form;
 //   * prologue per wave: the table entries of ITS taps for the 16 rows in one or two coalesced loads (lane = (row, tap)),
 //     ballots find the taps any row has, their gather offsets go compacted into the wave's LDS slab - a dead tap costs
 //     nothing afterwards, and the table is read once per row tile and tap instead of once per column tile;
-//   * the tap loop of the masked-tile kernel (spconv_tiles.hip): a ring of operand slots at TAP granularity - all CB input
-//     blocks of a tap (1 + NT requests each) are in flight together, one tap ahead of the MFMAs, counted waits;
+//   * the tap loop: a ring of operand slots at STAGE granularity (stage = one 16-channel input block of one live tap: 1 row
+//     piece + NT weight fragments requested, 4 NT MFMAs), D - 1 stages requested ahead, written out so that every slot index is
+//     a compile-time constant and a slot is refilled in the sub-step after the one that consumed it (counted waits, no copies);
 //   * epilogue: every wave leaves its NT accumulators in LDS; after ONE barrier wave q sums column tiles q, q + SP, ... over the
-//     waves in wave order, stores them and adds the BatchNorm column sums (bn_stats.h) - the stores and the atomics of a row tile
-//     are spread over its waves instead of queued behind one.
+//     waves in wave order, stores them and adds the BatchNorm column sums (bn_stats.h) - or applies an inference pass's
+//     BatchNorm (gpn::ConvAffine) - so the stores and the atomics of a row tile are spread over its waves.
 // Summation order per output element: ascending taps inside a wave (two-level: a tap's CB x 16 products in one MFMA chain, the
 // taps' sums added in fp32), then the waves' sums in wave order.  A tap a row does not have adds exact zeros, so a row's result
-// depends neither on the rows it shares a tile with nor on NT; with SP = 4 it is bit-equal to the direct kernel's 4-way form.
-// Deterministic for every SP.
+// depends neither on the rows it shares a tile with (the tile order) nor on NT, and SP never follows the row count (a
+// device-counted launch and its exactly-sized twin give the same bits): with SP = 4 the result is bit-equal to the direct
+// kernel's 4-way form.  SP = 9 (three taps per wave) is instantiated for the sweep and slower everywhere it was measured.
+// What a launch of THIS kernel waits for (profiles/r06_findings.md): not operand bytes - with the weight fragments served from
+// the L1s and the gathers made local it takes the same time (r06_conv_msplit_ablation.txt) - but its phases in lock-step: all
+// waves of a round read their table entries, then contend for the MFMA pipe, then store.
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -49,7 +53,7 @@ constexpr int kMaxTaps = 27;
 #if GPN_MSPLIT_TRACE
 __device__ unsigned long long* g_msplit_trace = nullptr;  // [waves][10]
 #endif
-// operand registers of the tap ring (the ring holds as many tap slots as fit, at least two)
+// operand registers of the ring (it holds as many whole taps - CB stages of 1 + NT requests - as fit; 96 / 144 measured: no gain)
 // GPN_MSPLIT_ABL (measurement builds, wrong results by design): see the two uses in the tap loop
 #ifndef GPN_MSPLIT_ABL
 #define GPN_MSPLIT_ABL 0
