@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--schedule", type=str, default="0,0", help="training_schedule; 0,0 = every head active")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-validation", action="store_true",
+                    help="skip the validation-step leg (BASELINE config 2 shape: eval mode, bs 4) reported under `validation`")
     ap.add_argument("--lib-knobs", type=str, default="",
                     help="library switches for A/B runs, e.g. msplit=0,bn_fusion=0,wgrad_group=1,tiles_min_tiles=1000000 "
                          "(the library reads no environment variables; these call its knob entry points)")
@@ -253,6 +255,40 @@ def conv_levels(lib, overhead_us):
         head.append(dict(shapes=len(tail), launches=sum(r["launches"] for r in tail),
                          share_of_family_time=sum(r["share_of_family_time"] for r in tail), note="remaining shapes"))
     return head
+
+
+def validation_leg(args, device):
+    """BASELINE.json config 2's shape as a second, smaller measurement in the same line (rank 0, one GPU; round 6: the driver's
+    record then also covers the evaluation path): validation steps of the full pipeline in eval mode, bs 4 x --points, the loop of
+    gapartnet_amd.trainer.Trainer.validate (device prefetcher, the step's one host read deferred by a step), seeded weights with
+    non-trivial BatchNorm statistics (tests/golden/recipe.py; release.ckpt is absent).  tools/eval_bench.py is the long form."""
+    from gapartnet_amd.dataset.prefetch import DevicePrefetcher
+    from gapartnet_amd.smoke import make_batch, make_model
+    from tests.golden import recipe
+    model = make_model((0, 0)).eval()
+    model.load_state_dict(recipe.name_keyed_state(model))
+    model = model.to(device)
+    model._log_sink = lambda name, value, bs, sync: None
+    model.defer_validation_outputs = True
+    batch, steps = 4, 18
+    pool = [[pc.to(device) for pc in make_batch(batch, args.points, seed0=2000 + 10 * j)] for j in range(2)]
+    times = []
+    with torch.no_grad():
+        for epoch in range(4):  # the first one warms up
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i, b in enumerate(DevicePrefetcher((pool[i % 2] for i in range(steps)), model, device)):
+                model.validation_step(b, i, 0)
+            model._resolve_pending_outputs()
+            torch.cuda.synchronize(device)
+            if epoch:
+                times.append((time.perf_counter() - t0) / steps * 1e3)
+            model.validation_step_outputs = [[] for _ in model.validation_step_outputs]
+    ms = sorted(times)[len(times) // 2]
+    return {"metric": "point-clouds/sec (validation step, eval mode)", "value": batch / ms * 1e3, "ms_per_step": ms,
+            "batch": batch, "points_per_scene": args.points, "steps_timed": steps * len(times),
+            "workload": "BASELINE config 2 shape: full pipeline, eval mode, score filter + NMS, bs 4; seeded weights (release.ckpt absent); "
+                        "median of three 18-step loops after one warm-up loop"}
 
 
 def apply_lib_knobs(spec: str):
@@ -501,6 +537,11 @@ def main():
             out["distributed"] = {"world_size": dist.get_world_size(), "rank_reporting": dist.get_rank(),
                                   "backend": dist.get_backend(), "env_world_size": int(os.environ.get("WORLD_SIZE", "1")),
                                   "device": torch.cuda.get_device_name(device)}
+        if world == 1 and not args.no_validation:
+            try:  # (a secondary figure: it must never cost the run its headline)
+                out["validation"] = validation_leg(args, device)
+            except Exception as exc:  # noqa: BLE001
+                out["validation"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
