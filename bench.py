@@ -264,7 +264,11 @@ def validation_leg(args, device):
     non-trivial BatchNorm statistics (tests/golden/recipe.py; release.ckpt is absent).  tools/eval_bench.py is the long form."""
     from gapartnet_amd.dataset.prefetch import DevicePrefetcher
     from gapartnet_amd.smoke import make_batch, make_model
-    from tests.golden import recipe
+    import importlib.util
+    # (loaded by path: a top-level package named `tests` somewhere else on sys.path must not shadow the repo's)
+    spec = importlib.util.spec_from_file_location("gpn_golden_recipe", os.path.join(ROOT, "tests", "golden", "recipe.py"))
+    recipe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(recipe)
     model = make_model((0, 0)).eval()
     model.load_state_dict(recipe.name_keyed_state(model))
     model = model.to(device)
