@@ -8,7 +8,7 @@ O=$R/gpurun_out/final
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python -m pytest "$R/tests" -m gpu -q > "$O/pytest_gpu.txt" 2>&1 < /dev/null; tail -2 "$O/pytest_gpu.txt"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o t -- python "$R/bench.py" --steps 16 --warmup 4 --no-cpu-baseline > "$O/bench_under_rocprof.log" 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o t -- python "$R/bench.py" --steps 16 --warmup 4 --no-cpu-baseline --no-validation > "$O/bench_under_rocprof.log" 2>&1 < /dev/null
 f=$(find /tmp/p1 -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" "$O/kernel_stats.csv"; python "$R/tools/gpu_categories.py" "$f" 21 > "$O/gpu_time_by_category.txt" 2>&1 < /dev/null; (cd "$R" && python tools/profile_summary.py "$f" 21 "$O/profile_summary.json" > /dev/null 2>&1 < /dev/null); fi
 f=$(find /tmp/p1 -name "*kernel_trace.csv" 2>/dev/null | head -1)
@@ -16,11 +16,11 @@ if [ -n "$f" ]; then python "$R/tools/step_sequence.py" "$f" > "$O/step_sequence
 cp "$O/profile_summary.json" "$R/profiles/profile_summary.json" 2>/dev/null
 timeout 240 python "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err" < /dev/null; cut -c1-260 "$O/bench_default.json"
 for i in 1 2 3; do timeout 240 python "$R/bench.py" --no-cpu-baseline > "$O/bench_default_run$i.json" 2> /dev/null < /dev/null; done  # run-to-run spread on this box
-timeout 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/p_sq -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+timeout 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/p_sq -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-validation > /dev/null 2>&1 < /dev/null
 f=$(find /tmp/p_sq -name "*counter_collection.csv" 2>/dev/null | head -1)
 if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_sq.txt" 2>&1 < /dev/null; fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-validation > /dev/null 2>&1 < /dev/null
   f=$(find /tmp/p_$c -name "*counter_collection.csv" 2>/dev/null | head -1)
   if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_$c.txt" 2>&1 < /dev/null; fi
 done

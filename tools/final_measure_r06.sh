@@ -10,7 +10,7 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python -m pytest "$R/tests" -m gpu -q > "$O/pytest_gpu.txt" 2>&1 < /dev/null; tail -2 "$O/pytest_gpu.txt"
 rm -rf /tmp/p1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o t -- python "$R/bench.py" --steps 16 --warmup 4 --no-cpu-baseline > "$O/bench_under_rocprof.log" 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o t -- python "$R/bench.py" --steps 16 --warmup 4 --no-cpu-baseline --no-validation > "$O/bench_under_rocprof.log" 2>&1 < /dev/null
 f=$(find /tmp/p1 -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" "$O/kernel_stats.csv"; python "$R/tools/gpu_categories.py" "$f" 21 > "$O/gpu_time_by_category.txt" 2>&1 < /dev/null; (cd "$R" && python tools/profile_summary.py "$f" 21 "$O/profile_summary.json" > /dev/null 2>&1 < /dev/null); fi
 f=$(find /tmp/p1 -name "*kernel_trace.csv" 2>/dev/null | head -1)
@@ -18,14 +18,14 @@ if [ -n "$f" ]; then python "$R/tools/step_sequence.py" "$f" > "$O/step_sequence
 cp "$O/profile_summary.json" "$R/profiles/profile_summary.json" 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$c
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-validation > /dev/null 2>&1 < /dev/null
   f=$(find /tmp/p_$c -name "*counter_collection.csv" 2>/dev/null | head -1)
   if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_$c.txt" 2>&1 < /dev/null; fi
 done
 f1=$O/pmc_FETCH_SIZE.txt; f2=$O/pmc_WRITE_SIZE.txt
 if [ -s "$f1" ] && [ -s "$f2" ]; then (cd "$R" && python tools/pmc_traffic.py "$f1" "$f2" "$O/traffic.json" spconv_fwd,spconv_tiles,spconv_msplit > /dev/null 2>&1); cp "$O/traffic.json" "$R/profiles/traffic.json"; fi
 rm -rf /tmp/p_sq
-timeout 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/p_sq -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+timeout 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/p_sq -o t -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-validation > /dev/null 2>&1 < /dev/null
 f=$(find /tmp/p_sq -name "*counter_collection.csv" 2>/dev/null | head -1)
 if [ -n "$f" ]; then python "$R/tools/pmc_summary.py" "$f" spconv > "$O/pmc_sq.txt" 2>&1 < /dev/null; fi
 # the bench line: with profiles/profile_summary.json + traffic.json of THESE sources in place (profile_frac / traffic in the line)

@@ -30,6 +30,6 @@ res = {"kernel_prefix": prefix, "launches_profiled": n,
        "traffic_bytes_per_launch": (2.0 * f / n + w / n2) * 1024.0,
        "kernel_source_fingerprint": kernel_source_fingerprint(),
        "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B); separate --pmc passes of "
-               "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline`"}
+               "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-validation`"}
 json.dump(res, open(out, "w"), indent=1)
 print(res)
