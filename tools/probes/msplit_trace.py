@@ -5,7 +5,8 @@ on the bench's levels L2 .. L5 (25k / 7k / 1.9k / 489 rows).  Every wave records
 table entries (direct) / compacted offsets (masked) are there, when its first operands have arrived (masked only), at the end
 of its stage loop, after the workgroup's barrier and at its end, plus HW_ID / XCC_ID.
 
-    tools/probes/build_trace.sh && GPN_PROBE_SO=tools/probes/_build/libgpn_trace.so python tools/probes/msplit_trace.py [--cold]
+    tools/probes/build_variants.sh "trace spconv_fwd.hip,spconv_msplit.hip -DGPN_SPLIT_TRACE=1 -DGPN_MSPLIT_TRACE=1"
+    GPN_PROBE_SO=tools/probes/_build/libgpn_trace.so python tools/probes/msplit_trace.py [--cold]
 """
 import ctypes
 import os
@@ -47,7 +48,7 @@ def report(name, tr, mfma_per_stage_clks):
     print(f"   per wave, us: table/offsets {ph(t0, t1)}  first operands {ph(t1, t1b)}  stage loop {ph(t1b, t2)}  barrier wait {ph(t2, t3)}  "
           f"sum+store+stats {ph(t3, t4)}  total {ph(t0, t4)}")
     print(f"   taps per wave (live, masked kernel; walked, direct kernel): mean {taps.mean():.1f} max {taps.max()};  "
-          f"MFMA time of a wave's chain at the pipe's rate: mean {taps.mean() * mfma_per_stage_clks / 2400:.2f} us")
+          f"MFMA time of a wave's chain at the pipe's rate, per column tile it carries: mean {taps.mean() * mfma_per_stage_clks / 2400:.2f} us")
     ts = np.linspace(0, span, 9)[1:-1]
     alive = [(int(((us(t0) <= t) & (us(t4) > t)).sum())) for t in ts]
     print("   waves alive at", " ".join(f"{t:.0f}us:{a}" for t, a in zip(ts, alive)))
@@ -83,7 +84,6 @@ def main():
                 conv_call(x, packed, rb, c, c, out)
                 torch.cuda.synchronize()
                 probe(ctypes.c_void_p(0))
-                nt_per_wave = 1 if kind.startswith("direct") else int(os.environ.get("TRACE_NT", "0")) or 1
                 report(f"L{lvl} {c}->{c}, {rb.n_dst} rows, {kind}", trace.cpu().numpy(), (c // 16) * 4 * 32)
         idx, shape, _, _ = H.rulebook_down(idx, shape, 8)
 
