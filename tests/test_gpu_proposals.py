@@ -316,3 +316,31 @@ def test_validation_step_falls_back_when_a_neighbour_table_overflows(cuda, monke
         for name in KEPT_FIELDS:
             x, y = getattr(a, name), getattr(b, name)
             assert x.shape == y.shape and torch.equal(x, y), name
+
+
+def test_validation_step_with_batchnorm_in_the_conv_epilogues_equals_batchnorm_launches(cuda):
+    """round 6, the whole model at config 2's size (4 x 20k points, eval mode): the inference pass (every BatchNorm applied by the conv
+    launch that produces its input, GPN_NET_INFERENCE) against the same validation steps with the BatchNorm launches
+    (gpn_net_bn_fusion(0)): semantic predictions and every field the step keeps are EQUAL - the fold is the stand-alone pass's
+    arithmetic per element"""
+    from gapartnet_amd import _C
+    lib = _C.lib()
+    batches = [[pc.to(cuda) for pc in make_batch(4, 20000, seed0=1700 + 10 * j)] for j in range(2)]
+    kept = {}
+    for fused in (1, 0):
+        prev = lib.gpn_net_bn_fusion(fused)
+        try:
+            model = _eval_model(cuda)
+            outs = []
+            with torch.no_grad():
+                for i, batch in enumerate(batches):
+                    outs.append(model.validation_step(batch, i, 0))
+            kept[fused] = outs
+        finally:
+            lib.gpn_net_bn_fusion(prev)
+    for (ids_a, seg_a, a), (ids_b, seg_b, b) in zip(kept[1], kept[0]):
+        assert ids_a == ids_b and torch.equal(seg_a.sem_preds, seg_b.sem_preds)
+        assert a is not None and b is not None
+        for name in KEPT_FIELDS:
+            x, y = getattr(a, name), getattr(b, name)
+            assert x.shape == y.shape and torch.equal(x, y), name
